@@ -1,0 +1,394 @@
+/*
+ * oracle/classic_control_ref.c — CPU restatement of the Gym.NET classic-control hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gym.net_amd/ (the product) may include, link,
+ * import or execute this file.  Only tests/, __graft_entry__.smoke() and the cpu_baseline leg
+ * of bench.py use it, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference is C# (netcoreapp3.1/net6.0); no .NET toolchain exists in
+ * this image, so the reference cannot be built or run here, and its own CartPole test
+ * (tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35) asserts nothing.  This file is
+ * therefore a restatement from the C# text, cross-checked bit-for-bit against an independent
+ * second restatement (oracle/numpy_ref.py), against hand-derived closed forms and symmetry
+ * properties (tests/test_oracle.py).  Philox4x32-10 IS pinned: it is checked against the
+ * published Random123 known-answer vectors.
+ *
+ * What is restated, and from where (paths relative to /root/reference):
+ *   - CartPoleEnv constants      src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:24-36
+ *   - CartPoleEnv.Step           src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:137-186
+ *   - CartPoleEnv.Reset          src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:63-67
+ *   - Discrete.Contains(int)     src/Gym/Spaces/Discrete.cs:38-40
+ *   - Pendulum / MountainCar / Acrobot: ABSENT from the reference (README.md:69-76 lists them
+ *     as unchecked roadmap items).  Restated from the upstream openai/gym classic_control
+ *     algorithms as summarised in SURVEY.md Appendix B.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; contraction MUST stay off so that
+ * the float32 "kernel semantics" functions round after every operation like the HIP kernels).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+
+/* ------------------------------------------------------------------------------------------
+ * CartPole constants — CartPoleEnv.cs:24-36.  Every constant is a C# `const float`; inside
+ * Step() it is widened to double.  total_mass and polemass_length are const-folded in float.
+ * ---------------------------------------------------------------------------------------- */
+static const float CP_GRAVITY = 9.8f;
+static const float CP_MASSCART = 1.0f;
+static const float CP_MASSPOLE = 0.1f;
+#define CP_TOTAL_MASS ((float)(CP_MASSPOLE + CP_MASSCART))      /* 0x1.19999ap+0 */
+static const float CP_LENGTH = 0.5f;
+#define CP_POLEMASS_LENGTH ((float)(CP_MASSPOLE * CP_LENGTH))   /* 0x1.99999ap-5 */
+static const float CP_FORCE_MAG = 10.0f;
+static const float CP_TAU = 0.02f;
+/* (float)(12 * 2 * Math.PI / 360) — CartPoleEnv.cs:34 */
+#define CP_THETA_THRESHOLD ((float)(24.0 * 3.14159265358979323846 / 360.0))
+static const float CP_X_THRESHOLD = 2.4f;
+
+void ref_cartpole_constants(double *out10) {
+    out10[0] = CP_GRAVITY;  out10[1] = CP_MASSCART;  out10[2] = CP_MASSPOLE;
+    out10[3] = CP_TOTAL_MASS;  out10[4] = CP_LENGTH;  out10[5] = CP_POLEMASS_LENGTH;
+    out10[6] = CP_FORCE_MAG;  out10[7] = CP_TAU;  out10[8] = CP_THETA_THRESHOLD;
+    out10[9] = CP_X_THRESHOLD;
+}
+
+/* One CartPoleEnv.Step() in the reference's arithmetic (binary64 state, binary32-valued
+ * constants), CartPoleEnv.cs:137-186.  state[4] = x, x_dot, theta, theta_dot (in/out);
+ * *sbd = steps_beyond_done (in/out, -1 after Reset).  Returns done; *reward as the C# float.
+ * Any action != 1 pushes left: validity is only Debug.Assert'ed in the reference (:139). */
+int ref_cartpole_step_f64(double *state, int action, int *sbd, float *reward) {
+    double x = state[0], x_dot = state[1], theta = state[2], theta_dot = state[3];
+    float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;                           /* :146 */
+    double costheta = cos(theta);                                                       /* :147 */
+    double sintheta = sin(theta);                                                       /* :148 */
+    double temp = ((double)force + (double)CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta)
+                  / (double)CP_TOTAL_MASS;                                              /* :149 */
+    double thetaacc = ((double)CP_GRAVITY * sintheta - costheta * temp)
+                      / ((double)CP_LENGTH * (4.0 / 3.0 - (double)CP_MASSPOLE * costheta * costheta
+                                                            / (double)CP_TOTAL_MASS));  /* :150 */
+    double xacc = temp - (double)CP_POLEMASS_LENGTH * thetaacc * costheta
+                             / (double)CP_TOTAL_MASS;                                   /* :151 */
+    /* kinematics_integrator == "euler" (:32,153): explicit Euler, OLD velocities */
+    x = x + (double)CP_TAU * x_dot;                                                     /* :154 */
+    x_dot = x_dot + (double)CP_TAU * xacc;                                              /* :155 */
+    theta = theta + (double)CP_TAU * theta_dot;                                         /* :156 */
+    theta_dot = theta_dot + (double)CP_TAU * thetaacc;                                  /* :157 */
+    state[0] = x; state[1] = x_dot; state[2] = theta; state[3] = theta_dot;             /* :166 */
+    int done = x < -(double)CP_X_THRESHOLD || x > (double)CP_X_THRESHOLD
+            || theta < -(double)CP_THETA_THRESHOLD || theta > (double)CP_THETA_THRESHOLD; /* :167 */
+    if (!done) {                                                                        /* :169 */
+        *reward = 1.0f;
+    } else if (*sbd == -1) {                                                            /* :171 */
+        *sbd = 0;
+        *reward = 1.0f;
+    } else {                                                                            /* :175 */
+        *sbd += 1;
+        *reward = 0.0f;
+    }
+    return done;
+}
+
+/* The same Step() in the HIP kernel's arithmetic: every operation in binary32 with the same
+ * binary32 constants (4.0f/3.0f for the double literal), same association order, thresholds
+ * compared in binary32.  This is NOT the reference's arithmetic; it exists so tests can bound
+ * the kernel tightly (a few ulp, sinf/cosf implementations differ) in addition to the
+ * north_star bar of 1e-5 against ref_cartpole_step_f64. */
+int ref_cartpole_step_f32(float *state, int action, int *sbd, float *reward) {
+    float x = state[0], x_dot = state[1], theta = state[2], theta_dot = state[3];
+    float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
+    float costheta = cosf(theta);
+    float sintheta = sinf(theta);
+    float temp = (force + CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / CP_TOTAL_MASS;
+    float thetaacc = (CP_GRAVITY * sintheta - costheta * temp)
+                     / (CP_LENGTH * (4.0f / 3.0f - CP_MASSPOLE * costheta * costheta / CP_TOTAL_MASS));
+    float xacc = temp - CP_POLEMASS_LENGTH * thetaacc * costheta / CP_TOTAL_MASS;
+    x = x + CP_TAU * x_dot;
+    x_dot = x_dot + CP_TAU * xacc;
+    theta = theta + CP_TAU * theta_dot;
+    theta_dot = theta_dot + CP_TAU * thetaacc;
+    state[0] = x; state[1] = x_dot; state[2] = theta; state[3] = theta_dot;
+    int done = x < -CP_X_THRESHOLD || x > CP_X_THRESHOLD
+            || theta < -CP_THETA_THRESHOLD || theta > CP_THETA_THRESHOLD;
+    if (!done) { *reward = 1.0f; }
+    else if (*sbd == -1) { *sbd = 0; *reward = 1.0f; }
+    else { *sbd += 1; *reward = 0.0f; }
+    return done;
+}
+
+/* Batched conveniences over structure-of-arrays [4][n] (the engine's HBM layout). */
+void ref_cartpole_step_batch_f64(double *soa, const int32_t *action, int32_t *sbd,
+                                 float *reward, uint8_t *done, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        double s[4] = { soa[i], soa[n + i], soa[2 * n + i], soa[3 * n + i] };
+        int b = sbd[i];
+        done[i] = (uint8_t)ref_cartpole_step_f64(s, action[i], &b, &reward[i]);
+        sbd[i] = b;
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
+void ref_cartpole_step_batch_f32(float *soa, const int32_t *action, int32_t *sbd,
+                                 float *reward, uint8_t *done, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4] = { soa[i], soa[n + i], soa[2 * n + i], soa[3 * n + i] };
+        int b = sbd[i];
+        done[i] = (uint8_t)ref_cartpole_step_f32(s, action[i], &b, &reward[i]);
+        sbd[i] = b;
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
+/* Discrete.Contains(int) — src/Gym/Spaces/Discrete.cs:38-40 (ignores Start, as the reference). */
+int ref_discrete_contains(int x, int n) { return x >= 0 && x < n; }
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel Random Numbers: As Easy as 1, 2, 3",
+ * SC'11; Random123 v1.x).  north_star replaces the reference's un-vendored NumSharp RNG
+ * (CartPoleEnv.cs:49,65,196-198) with this counter-based generator; pinned by the Random123
+ * known-answer vectors in tests/test_oracle.py.
+ * ---------------------------------------------------------------------------------------- */
+void ref_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 24-bit uniform in [0,1): exact in binary32. */
+static inline float u01_24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+/* The engine's reset draw for global lane `lane` at engine tick `tick` with seed `seed`:
+ *   counter = (lane_lo, lane_hi, tick_lo, tick_hi), key = (seed_lo, seed_hi).
+ * Returns the four raw 32-bit words; each env maps them to its own reset distribution. */
+void ref_reset_words(uint64_t seed, uint64_t lane, uint64_t tick, uint32_t out[4]) {
+    uint32_t ctr[4] = { (uint32_t)lane, (uint32_t)(lane >> 32), (uint32_t)tick, (uint32_t)(tick >> 32) };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    ref_philox4x32_10(ctr, key, out);
+}
+
+/* CartPoleEnv.Reset() — CartPoleEnv.cs:63-67: sbd = -1; state ~ U(-0.05, 0.05)^4, computed as
+ * low + (high-low)*u.  Kernel semantics: binary32, (high-low) = 0.1f, no contraction. */
+void ref_cartpole_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float state[4]) {
+    uint32_t w[4];
+    ref_reset_words(seed, lane, tick, w);
+    for (int k = 0; k < 4; ++k) state[k] = -0.05f + 0.1f * u01_24(w[k]);
+}
+
+void ref_cartpole_reset_batch_f32(uint64_t seed, uint64_t lane0, uint64_t tick, float *soa, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4];
+        ref_cartpole_reset_f32(seed, lane0 + (uint64_t)i, tick, s);
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
+/* Discrete.Sample() — src/Gym/Spaces/Discrete.cs:17-28 (no mask): Start + randint(0, N).
+ * Engine semantics: Philox word 0 of counter (lane, tick), key = seed; value = start + hi32(w*n)
+ * (Lemire multiply-shift; exact-uniform when n is a power of two). */
+int32_t ref_discrete_sample(uint64_t seed, uint64_t lane, uint64_t tick, int32_t n, int32_t start) {
+    uint32_t w[4];
+    ref_reset_words(seed, lane, tick, w);
+    return start + (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32);
+}
+
+void ref_discrete_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, int32_t start,
+                               int32_t *out, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) out[i] = ref_discrete_sample(seed, lane0 + (uint64_t)i, tick, n, start);
+}
+
+/* Box.Sample() bounded regime — src/Gym/Spaces/Box.cs:69-90: uniform(low, high). Engine
+ * semantics (binary32): low + (high-low)*u with u = 24-bit uniform from Philox word 0. */
+void ref_box_uniform_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, float low, float high,
+                                  float *out, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) {
+        uint32_t w[4];
+        ref_reset_words(seed, lane0 + (uint64_t)i, tick, w);
+        out[i] = low + (high - low) * u01_24(w[0]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Envs that are NOT in the reference (README.md:69-76): upstream openai/gym classic_control,
+ * SURVEY.md Appendix B.  f64 = "upstream semantics", f32 = "kernel semantics".
+ * ---------------------------------------------------------------------------------------- */
+#define PI_D 3.14159265358979323846
+#define PI_F 3.14159265358979323846f
+
+/* Pendulum-v1.  state = (theta, theta_dot); obs = (cos th', sin th', thdot'); never terminates. */
+static inline double floored_mod_d(double a, double m) { double r = fmod(a, m); if (r < 0.0) r += m; return r; }
+static inline float floored_mod_f(float a, float m) { float r = fmodf(a, m); if (r < 0.0f) r += m; return r; }
+
+void ref_pendulum_step_f64(double *state, double a, double *obs3, double *reward) {
+    const double g = 10.0, m = 1.0, l = 1.0, dt = 0.05, max_speed = 8.0, max_torque = 2.0;
+    double th = state[0], thdot = state[1];
+    double u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
+    double nrm = floored_mod_d(th + PI_D, 2.0 * PI_D) - PI_D;
+    double costs = nrm * nrm + 0.1 * (thdot * thdot) + 0.001 * (u * u);
+    double newthdot = thdot + (3.0 * g / (2.0 * l) * sin(th) + 3.0 / (m * (l * l)) * u) * dt;
+    newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+    double newth = th + newthdot * dt;
+    state[0] = newth; state[1] = newthdot;
+    obs3[0] = cos(newth); obs3[1] = sin(newth); obs3[2] = newthdot;
+    *reward = -costs;
+}
+
+void ref_pendulum_step_f32(float *state, float a, float *obs3, float *reward) {
+    const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f;
+    float th = state[0], thdot = state[1];
+    float u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
+    float nrm = floored_mod_f(th + PI_F, 2.0f * PI_F) - PI_F;
+    float costs = nrm * nrm + 0.1f * (thdot * thdot) + 0.001f * (u * u);
+    float newthdot = thdot + (15.0f * sinf(th) + 3.0f * u) * dt;   /* 3g/(2l) = 15, 3/(m l^2) = 3 */
+    newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+    float newth = th + newthdot * dt;
+    state[0] = newth; state[1] = newthdot;
+    obs3[0] = cosf(newth); obs3[1] = sinf(newth); obs3[2] = newthdot;
+    *reward = -costs;
+}
+
+void ref_pendulum_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float state[2]) {
+    uint32_t w[4];
+    ref_reset_words(seed, lane, tick, w);
+    state[0] = -PI_F + (2.0f * PI_F) * u01_24(w[0]);
+    state[1] = -1.0f + 2.0f * u01_24(w[1]);
+}
+
+/* MountainCar-v0.  state = (position, velocity); a in {0,1,2}. */
+int ref_mountaincar_step_f64(double *state, int a, double *reward) {
+    double p = state[0], v = state[1];
+    v += (a - 1) * 0.001 + cos(3.0 * p) * (-0.0025);
+    v = v < -0.07 ? -0.07 : (v > 0.07 ? 0.07 : v);
+    p += v;
+    p = p < -1.2 ? -1.2 : (p > 0.6 ? 0.6 : p);
+    if (p == -1.2 && v < 0.0) v = 0.0;
+    state[0] = p; state[1] = v;
+    *reward = -1.0;
+    return p >= 0.5 && v >= 0.0;
+}
+
+int ref_mountaincar_step_f32(float *state, int a, float *reward) {
+    float p = state[0], v = state[1];
+    v += (float)(a - 1) * 0.001f + cosf(3.0f * p) * (-0.0025f);
+    v = v < -0.07f ? -0.07f : (v > 0.07f ? 0.07f : v);
+    p += v;
+    p = p < -1.2f ? -1.2f : (p > 0.6f ? 0.6f : p);
+    if (p == -1.2f && v < 0.0f) v = 0.0f;
+    state[0] = p; state[1] = v;
+    *reward = -1.0f;
+    return p >= 0.5f && v >= 0.0f;
+}
+
+void ref_mountaincar_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float state[2]) {
+    uint32_t w[4];
+    ref_reset_words(seed, lane, tick, w);
+    state[0] = -0.6f + 0.2f * u01_24(w[0]);
+    state[1] = 0.0f;
+}
+
+/* Acrobot-v1 ("book" dynamics, RK4, dt = 0.2).  state = (th1, th2, dth1, dth2); a in {0,1,2}. */
+static void acrobot_dsdt_f64(const double s[4], double tau, double d[4]) {
+    const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
+    double th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+    double d1 = m1 * lc1 * lc1 + m2 * (l1 * l1 + lc2 * lc2 + 2.0 * l1 * lc2 * cos(th2)) + I1 + I2;
+    double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos(th2)) + I2;
+    double phi2 = m2 * lc2 * g * cos(th1 + th2 - PI_D / 2.0);
+    double phi1 = -m2 * l1 * lc2 * dth2 * dth2 * sin(th2)
+                  - 2.0 * m2 * l1 * lc2 * dth2 * dth1 * sin(th2)
+                  + (m1 * lc1 + m2 * l1) * g * cos(th1 - PI_D / 2.0) + phi2;
+    double ddth2 = (tau + d2 / d1 * phi1 - m2 * l1 * lc2 * dth1 * dth1 * sin(th2) - phi2)
+                   / (m2 * lc2 * lc2 + I2 - d2 * d2 / d1);
+    double ddth1 = -(d2 * ddth2 + phi1) / d1;
+    d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+}
+
+static double wrap_d(double x, double m, double M) {
+    double diff = M - m;
+    while (x > M) x -= diff;
+    while (x < m) x += diff;
+    return x;
+}
+
+int ref_acrobot_step_f64(double *state, int a, double *obs6, double *reward) {
+    const double dt = 0.2, mv1 = 4.0 * PI_D, mv2 = 9.0 * PI_D;
+    double tau = (double)(a - 1);
+    double k1[4], k2[4], k3[4], k4[4], y[4];
+    acrobot_dsdt_f64(state, tau, k1);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0 * k1[i];
+    acrobot_dsdt_f64(y, tau, k2);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0 * k2[i];
+    acrobot_dsdt_f64(y, tau, k3);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt * k3[i];
+    acrobot_dsdt_f64(y, tau, k4);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    y[0] = wrap_d(y[0], -PI_D, PI_D);
+    y[1] = wrap_d(y[1], -PI_D, PI_D);
+    y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+    y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+    for (int i = 0; i < 4; ++i) state[i] = y[i];
+    int done = (-cos(y[0]) - cos(y[1] + y[0])) > 1.0;
+    *reward = done ? 0.0 : -1.0;
+    obs6[0] = cos(y[0]); obs6[1] = sin(y[0]); obs6[2] = cos(y[1]); obs6[3] = sin(y[1]);
+    obs6[4] = y[2]; obs6[5] = y[3];
+    return done;
+}
+
+static void acrobot_dsdt_f32(const float s[4], float tau, float d[4]) {
+    /* constants folded: m1=m2=l1=I1=I2=1, lc1=lc2=0.5, g=9.8 */
+    float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+    float c2 = cosf(th2), s2 = sinf(th2);
+    float d1 = 0.25f + (1.25f + c2) + 2.0f;          /* m1 lc1^2 + m2 (l1^2+lc2^2+2 l1 lc2 c2) + I1 + I2 */
+    float d2 = (0.25f + 0.5f * c2) + 1.0f;           /* m2 (lc2^2 + l1 lc2 c2) + I2 */
+    float phi2 = 4.9f * cosf(th1 + th2 - PI_F / 2.0f);                 /* m2 lc2 g = 4.9 */
+    float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2    /* m2 l1 lc2 = 0.5; 2 m2 l1 lc2 = 1 */
+                 + 14.7f * cosf(th1 - PI_F / 2.0f) + phi2;             /* (m1 lc1 + m2 l1) g = 14.7 */
+    float ddth2 = (tau + d2 / d1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2)
+                  / (1.25f - d2 * d2 / d1);                            /* m2 lc2^2 + I2 = 1.25 */
+    float ddth1 = -(d2 * ddth2 + phi1) / d1;
+    d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+}
+
+static float wrap_f(float x, float m, float M) {
+    float diff = M - m;
+    while (x > M) x -= diff;
+    while (x < m) x += diff;
+    return x;
+}
+
+int ref_acrobot_step_f32(float *state, int a, float *obs6, float *reward) {
+    const float dt = 0.2f, mv1 = 4.0f * PI_F, mv2 = 9.0f * PI_F;
+    float tau = (float)(a - 1);
+    float k1[4], k2[4], k3[4], k4[4], y[4];
+    acrobot_dsdt_f32(state, tau, k1);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k1[i];
+    acrobot_dsdt_f32(y, tau, k2);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k2[i];
+    acrobot_dsdt_f32(y, tau, k3);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt * k3[i];
+    acrobot_dsdt_f32(y, tau, k4);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+    y[0] = wrap_f(y[0], -PI_F, PI_F);
+    y[1] = wrap_f(y[1], -PI_F, PI_F);
+    y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+    y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+    for (int i = 0; i < 4; ++i) state[i] = y[i];
+    int done = (-cosf(y[0]) - cosf(y[1] + y[0])) > 1.0f;
+    *reward = done ? 0.0f : -1.0f;
+    obs6[0] = cosf(y[0]); obs6[1] = sinf(y[0]); obs6[2] = cosf(y[1]); obs6[3] = sinf(y[1]);
+    obs6[4] = y[2]; obs6[5] = y[3];
+    return done;
+}
+
+void ref_acrobot_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float state[4]) {
+    uint32_t w[4];
+    ref_reset_words(seed, lane, tick, w);
+    for (int k = 0; k < 4; ++k) state[k] = -0.1f + 0.2f * u01_24(w[k]);
+}

@@ -1,0 +1,252 @@
+"""CPU tests of the oracle itself: the restatement against its independent twin, hand-derived
+closed forms, symmetry, the committed golden vectors and the published Philox known answers.
+
+The reference pins nothing for CartPole (tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35
+asserts nothing) => parity unpinned; these tests are what stands in for the missing pins.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import numpy_ref as nr
+
+f32 = np.float32
+
+
+def test_constants_are_the_float32_values_of_the_csharp_consts(oracle):
+    # SURVEY Appendix A hex values (CartPoleEnv.cs:24-36)
+    c = oracle.cartpole_constants()
+    assert c["gravity"] == float.fromhex("0x1.39999ap+3")
+    assert c["masspole"] == float.fromhex("0x1.99999ap-4")
+    assert c["total_mass"] == float.fromhex("0x1.19999ap+0")
+    assert c["polemass_length"] == float.fromhex("0x1.99999ap-5")
+    assert c["tau"] == float.fromhex("0x1.47ae14p-6")
+    assert c["theta_threshold_radians"] == float.fromhex("0x1.aceeap-3")
+    assert c["x_threshold"] == float.fromhex("0x1.333334p+1")
+    assert c["length"] == 0.5 and c["force_mag"] == 10.0 and c["masscart"] == 1.0
+    # numpy twin agrees
+    assert float(nr.TOTAL_MASS) == c["total_mass"] and float(nr.POLEMASS_LENGTH) == c["polemass_length"]
+    assert float(nr.THETA_THRESHOLD) == c["theta_threshold_radians"] and float(nr.TAU) == c["tau"]
+    # observation-space bound, CartPoleEnv.cs:46
+    assert nr.OBS_HIGH[0] == f32(4.8000002) and nr.OBS_HIGH[2] == f32(0.41887903)
+
+
+def test_c_and_numpy_restatements_are_bit_identical_in_f64(oracle):
+    rng = np.random.default_rng(1)
+    n = 100_000
+    s = np.stack([rng.uniform(-3, 3, n), rng.uniform(-4, 4, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-4, 4, n)])
+    s = s.astype(f32).astype(np.float64)
+    a = rng.integers(0, 2, n).astype(np.int32)
+    sbd = rng.integers(-1, 3, n).astype(np.int32)
+    cs, cr, cd, cb = oracle.cartpole_step(s, a, sbd)
+    ps, pr, pd, pb = nr.cartpole_step(s, a, sbd)
+    assert np.array_equal(cs, ps)
+    assert np.array_equal(cr, pr) and np.array_equal(cd, pd.astype(np.uint8)) and np.array_equal(cb, pb)
+
+
+def test_hand_derived_upright_at_rest(oracle):
+    # state 0, action 1: sin=0, cos=1 => temp = 10/M; thetaacc = -temp/(L*(4/3 - mp/M)); xacc = temp - pml*thetaacc/M
+    c = oracle.cartpole_constants()
+    M, L, mp, pml, tau = c["total_mass"], c["length"], c["masspole"], c["polemass_length"], c["tau"]
+    temp = 10.0 / M
+    thetaacc = (0.0 - 1.0 * temp) / (L * (4.0 / 3.0 - mp / M))
+    xacc = temp - pml * thetaacc / M
+    s, r, d, b = oracle.cartpole_step(np.zeros((4, 1)), np.array([1], dtype=np.int32))
+    assert s[0, 0] == 0.0 and s[2, 0] == 0.0
+    assert s[1, 0] == tau * xacc and s[3, 0] == tau * thetaacc
+    assert r[0] == 1.0 and d[0] == 0 and b[0] == -1
+    # magnitudes as physics says: cart accelerates right, pole tips left
+    assert s[1, 0] == pytest.approx(0.19512195, abs=1e-7) and s[3, 0] == pytest.approx(-0.29268293, abs=1e-7)
+
+
+def test_mirror_symmetry_is_exact(oracle):
+    # step(-s, a=0) == -step(s, a=1): every operation is sign-symmetric in IEEE arithmetic
+    rng = np.random.default_rng(2)
+    n = 20_000
+    s = np.stack([rng.uniform(-3, 3, n), rng.uniform(-4, 4, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-4, 4, n)])
+    a1 = np.ones(n, dtype=np.int32)
+    p = oracle.cartpole_step(s, a1)
+    m = oracle.cartpole_step(-s, 1 - a1)
+    assert np.array_equal(p[0], -m[0]) and np.array_equal(p[2], m[2])
+
+
+def test_invalid_action_pushes_left_like_release_build(oracle):
+    # CartPoleEnv.cs:139 is a Debug.Assert (no-op in Release); :146 `iaction == 1 ? +F : -F`
+    s = np.array([[0.1], [0.2], [0.05], [-0.3]])
+    left = oracle.cartpole_step(s, np.array([0], dtype=np.int32))[0]
+    for bad in (2, -1, 7):
+        assert np.array_equal(oracle.cartpole_step(s, np.array([bad], dtype=np.int32))[0], left)
+    assert oracle.lib().ref_discrete_contains(0, 2) == 1 and oracle.lib().ref_discrete_contains(1, 2) == 1
+    assert oracle.lib().ref_discrete_contains(2, 2) == 0 and oracle.lib().ref_discrete_contains(-1, 2) == 0
+
+
+def test_golden_teacher_forced(oracle, golden):
+    g = golden("cartpole_teacher_forced")
+    ns, rew, done, sbd = oracle.cartpole_step(g["state"].astype(np.float64), g["action"])
+    assert np.array_equal(ns, g["next_state"])
+    assert np.array_equal(rew, g["reward"]) and np.array_equal(done, g["done"]) and np.array_equal(sbd, g["sbd"])
+    # numpy twin reproduces the fixture too
+    ps = nr.cartpole_step(g["state"].astype(np.float64), g["action"], np.full(ns.shape[1], -1, np.int32))
+    assert np.array_equal(ps[0], g["next_state"]) and np.array_equal(ps[2].astype(np.uint8), g["done"])
+    assert 0 < int(g["done"].sum()) < g["done"].size
+
+
+def test_golden_threshold_edges_strict_inequalities(oracle, golden):
+    g = golden("cartpole_edges")
+    with np.errstate(all="ignore"):
+        ns, rew, done, sbd = oracle.cartpole_step(g["state"].astype(np.float64), g["action"])
+    assert np.array_equal(ns, g["next_state"], equal_nan=True)
+    assert np.array_equal(done, g["done"])
+    c = oracle.cartpole_constants()
+    xt, tt = f32(c["x_threshold"]), f32(c["theta_threshold_radians"])
+    st = g["state"]
+    for i in range(st.shape[1]):
+        x, th = st[0, i], st[2, i]
+        if st[1, i] == 0 and st[3, i] == 0 and np.isfinite(st[:, i]).all():
+            # position-like components are unchanged by explicit Euler when velocities are 0
+            expect = (x < -xt) or (x > xt) or (th < -tt) or (th > tt)
+            assert bool(g["done"][i]) == bool(expect), (i, st[:, i])
+    # exactly-at-threshold is NOT done (strict < and >, CartPoleEnv.cs:167)
+    eq = (np.abs(st[0]) == xt) | (np.abs(st[2]) == tt)
+    assert eq.sum() >= 8 and not g["done"][eq].any()
+    # NaN state: all comparisons false => not done
+    nan_col = np.isnan(st[0])
+    assert nan_col.sum() == 1 and g["done"][nan_col][0] == 0
+
+
+def test_golden_steps_beyond_done_sequence(oracle, golden):
+    g = golden("cartpole_steps_beyond_done")
+    s = g["start"].astype(np.float64).reshape(4, 1)
+    sbd = np.array([-1], dtype=np.int32)
+    for t in range(g["reward"].shape[0]):
+        s, r, d, sbd = oracle.cartpole_step(s, np.array([1], dtype=np.int32), sbd)
+        assert np.array_equal(s[:, 0], g["states"][t])
+        assert r[0] == g["reward"][t] and d[0] == g["done"][t] and sbd[0] == g["sbd"][t]
+    first = int(np.argmax(g["done"]))
+    assert np.all(g["reward"][: first + 1] == 1.0)          # incl. the step on which the pole fell
+    assert np.all(g["reward"][first + 1:] == 0.0)           # every later step
+    assert list(g["sbd"][first:]) == list(range(0, len(g["sbd"]) - first))
+
+
+def test_golden_reference_test_shaped_trace(oracle, golden):
+    # 1000 x (Reset-if-done else Step(i % 2)): CartpoleEnvironment.cs:19-27 / README.md:34-47
+    g = golden("cartpole_reference_test_trace")
+    done, k, s, sbd, lens, cur = True, 0, None, None, [], 0
+    for i in range(1000):
+        if done:
+            s = g["resets"][k].astype(np.float64).reshape(4, 1); k += 1
+            sbd = np.array([-1], dtype=np.int32); done = False
+            if cur:
+                lens.append(cur)
+            cur = 0
+            assert g["it_was_step"][i] == 0
+        else:
+            s, r, d, sbd = oracle.cartpole_step(s, np.array([i % 2], dtype=np.int32), sbd)
+            done = bool(d[0]); cur += 1
+            assert r[0] == 1.0          # reset-on-done callers only ever see reward 1
+        assert int(done) == g["it_done"][i]
+        assert np.array_equal(s[:, 0], g["it_state"][i])
+    assert k == int(g["resets_used"]) and lens == list(g["episode_lengths"])
+    assert 20 <= np.mean(lens) <= 60   # alternating-action episodes average ~37 steps
+
+
+def test_f32_kernel_semantics_stay_within_1e5_of_reference_semantics(oracle, golden):
+    # north_star tolerance: 1e-5 abs on float32 state, teacher-forced single step
+    g = golden("cartpole_teacher_forced")
+    inr = slice(0, 3072)                      # the in-range block of the fixture
+    s32 = g["state"][:, inr]
+    ns32, r32, d32, _ = oracle.cartpole_step(s32, g["action"][inr], dtype=np.float32)
+    err = np.abs(ns32.astype(np.float64) - g["next_state"][:, inr])
+    assert err.max() <= 1e-5 and err.max() < 2e-6
+    assert np.array_equal(d32, g["done"][inr]) and np.array_equal(r32, g["reward"][inr])
+    # numpy f32 twin (different sinf/cosf implementation) agrees to a few ulp
+    p32 = nr.cartpole_step(s32, g["action"][inr], np.full(s32.shape[1], -1, np.int32), dtype=f32)[0]
+    assert np.abs(p32.astype(np.float64) - ns32.astype(np.float64)).max() < 2e-6
+
+
+def test_f32_free_run_drift_table(oracle):
+    # regression guard on the tolerance claim: free-running f32 leaves 1e-5 only
+    # after tens of steps; the first 20 steps stay below 1e-5
+    n = 4096
+    s64 = oracle.cartpole_reset(0x5EED, 0, 0, n).astype(np.float64)
+    s32 = s64.astype(f32)
+    rng = np.random.default_rng(3)
+    alive = np.ones(n, dtype=bool)
+    worst20 = 0.0
+    for t in range(20):
+        a = rng.integers(0, 2, n).astype(np.int32)
+        s64, _, d64, _ = oracle.cartpole_step(s64, a)
+        s32, _, d32, _ = oracle.cartpole_step(s32, a, dtype=np.float32)
+        alive &= (d64 == 0) & (d32 == 0)
+        worst20 = max(worst20, np.abs(s32.astype(np.float64) - s64)[:, alive].max())
+    assert worst20 < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# Philox4x32-10: PINNED by the published Random123 known-answer vectors (kat_vectors, philox4x32 10)
+# ------------------------------------------------------------------------------------------------
+KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+     [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expect", KAT)
+def test_philox_known_answers(oracle, ctr, key, expect):
+    assert list(oracle.philox4x32_10(ctr, key)) == expect
+    tw = nr.philox4x32_10(np.array(ctr, dtype=np.uint32).reshape(4, 1), np.array(key, dtype=np.uint32).reshape(2, 1))
+    assert list(tw[:, 0]) == expect
+
+
+def test_reset_distribution_and_golden(oracle, golden):
+    g = golden("philox_resets")
+    for k in range(len(g["seeds"])):
+        seed, lane0, tick = int(g["seeds"][k]), int(g["lane0"][k]), int(g["ticks"][k])
+        got = oracle.cartpole_reset(seed, lane0, tick, 16)
+        assert np.array_equal(got, g["cartpole"][k])
+        lanes = np.arange(lane0, lane0 + 16, dtype=np.uint64)
+        assert np.array_equal(nr.cartpole_reset(seed, lanes, tick), got)
+        assert np.array_equal(oracle.pendulum_reset(seed, lane0, tick, 16), g["pendulum"][k])
+        assert np.array_equal(oracle.mountaincar_reset(seed, lane0, tick, 16), g["mountaincar"][k])
+        assert np.array_equal(oracle.acrobot_reset(seed, lane0, tick, 16), g["acrobot"][k])
+        assert np.array_equal(oracle.discrete_sample(seed, lane0, tick, 3, 0, 32), g["discrete3"][k])
+        assert np.array_equal(oracle.box_uniform_sample(seed, lane0, tick, -2.0, 2.0, 32), g["box_pm2"][k])
+    # CartPoleEnv.Reset (CartPoleEnv.cs:63-67): 4 iid U(-0.05, 0.05) components
+    big = oracle.cartpole_reset(7, 0, 3, 200_000)
+    assert big.min() >= -0.05 and big.max() < 0.05
+    assert abs(big.mean()) < 2e-4 and abs(big.std() - 0.1 / math.sqrt(12)) < 2e-4
+    assert np.abs(np.corrcoef(big)[np.triu_indices(4, 1)]).max() < 0.01
+    # sharding invariance by construction: lane offset == global lane id
+    assert np.array_equal(oracle.cartpole_reset(7, 1000, 3, 64), big[:, 1000:1064])
+
+
+def test_other_envs_golden(oracle, golden):
+    # Pendulum / MountainCar / Acrobot are absent from the reference (README.md:69-76); these vectors
+    # only freeze our restatement of the upstream algorithms.
+    g = golden("other_envs")
+    ns, obs, rew, _ = oracle.pendulum_step(g["pe_state"].astype(np.float64), g["pe_action"].astype(np.float64))
+    assert np.array_equal(ns, g["pe_next"]) and np.array_equal(obs, g["pe_obs"]) and np.array_equal(rew, g["pe_reward"])
+    assert np.abs(ns[1]).max() <= 8.0 and rew.max() <= 0.0
+    ns, rew, done = oracle.mountaincar_step(g["mc_state"].astype(np.float64), g["mc_action"])
+    assert np.array_equal(ns, g["mc_next"]) and np.array_equal(done, g["mc_done"])
+    assert np.all(ns[1, :8] == 0.0) and np.all(ns[0, :8] == -1.2)     # inelastic left wall
+    assert np.all(done[8:16] == 1)                                     # goal reached
+    ns, obs, rew, done = oracle.acrobot_step(g["ac_state"].astype(np.float64), g["ac_action"])
+    assert np.array_equal(ns, g["ac_next"]) and np.array_equal(obs, g["ac_obs"]) and np.array_equal(done, g["ac_done"])
+    assert np.abs(ns[0]).max() <= math.pi and np.abs(ns[2]).max() <= 4 * math.pi and np.abs(ns[3]).max() <= 9 * math.pi
+    assert np.array_equal(rew, np.where(done == 1, 0.0, -1.0))
+    # f32 kernel semantics track f64 within the bars the GPU tests use
+    s32 = oracle.pendulum_step(g["pe_state"], g["pe_action"], dtype=np.float32)
+    assert np.abs(s32[0].astype(np.float64) - g["pe_next"]).max() < 1e-5
+    s32 = oracle.mountaincar_step(g["mc_state"], g["mc_action"], dtype=np.float32)
+    assert np.abs(s32[0].astype(np.float64) - g["mc_next"]).max() < 1e-6
+
+
+def test_cpu_baseline_runs_and_counts(oracle):
+    r = oracle.cpu_baseline(4096, 16, 2, alloc_faithful=True)
+    assert r["env_steps"] == 4096 * 16 and r["seconds"] > 0 and r["dones"] >= 0
+    r2 = oracle.cpu_baseline(4096, 16, 2, alloc_faithful=False)
+    assert r2["checksum"] == r["checksum"]       # same arithmetic with and without the allocations
