@@ -1,0 +1,176 @@
+"""ctypes binding of include/gymnet_amd.h — the same entry points a C# host would P/Invoke.
+
+The shared library is gym.net_amd/lib/libgymnet_amd.so (HIP kernels + C ABI, built by
+gym.net_amd/build.py).  There is no fallback: if the library is missing this module raises, and
+without a GPU every compute call returns GYMNET_ERR_NO_DEVICE which is raised as NoDeviceError.
+"""
+import ctypes as C
+import os
+
+from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDeviceError,
+                     NotSteppingError)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgymnet_amd.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_INVALID_ACTION = -2
+ERR_HIP = -3
+ERR_OOM = -4
+ERR_NO_DEVICE = -5
+ERR_ALREADY_STEPPING = -6
+ERR_NOT_STEPPING = -7
+ERR_UNSUPPORTED = -8
+
+ENV_CARTPOLE, ENV_PENDULUM, ENV_MOUNTAINCAR, ENV_ACROBOT = 0, 1, 2, 3
+ENV_IDS = {"CartPole-v1": 0, "Pendulum-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3}
+
+FLAG_AUTORESET = 0x01
+FLAG_VALIDATE_ACTIONS = 0x02
+FLAG_DONE_LIST = 0x04
+FLAG_EPISODE_STATS = 0x08
+FLAG_FINAL_OBS = 0x10
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("env_id", C.c_int32), ("num_envs", C.c_int64),
+                ("lane_offset", C.c_int64), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("seed", C.c_uint64), ("stream", C.c_void_p), ("d_ext_obs", C.c_void_p),
+                ("ext_obs_stride", C.c_int64), ("max_episode_steps", C.c_int32), ("reserved", C.c_int32)]
+
+
+class EnvInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("env_id", C.c_int32), ("name", C.c_char * 32),
+                ("state_dim", C.c_int32), ("obs_dim", C.c_int32), ("obs_aliases_state", C.c_int32),
+                ("action_is_box", C.c_int32), ("action_n", C.c_int32),
+                ("action_low", C.c_float), ("action_high", C.c_float),
+                ("obs_low", C.c_float * 8), ("obs_high", C.c_float * 8),
+                ("reward_low", C.c_float), ("reward_high", C.c_float),
+                ("algorithmic_bytes_per_step", C.c_int32)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("state_dim", C.c_int32), ("obs_dim", C.c_int32),
+                ("obs_aliases_state", C.c_int32), ("num_envs", C.c_int64), ("state_stride", C.c_int64),
+                ("obs_stride", C.c_int64), ("d_state", C.c_void_p), ("d_obs", C.c_void_p),
+                ("d_reward", C.c_void_p), ("d_done", C.c_void_p), ("d_steps_beyond_done", C.c_void_p),
+                ("d_final_obs", C.c_void_p), ("d_done_list", C.c_void_p),
+                ("d_episode_return", C.c_void_p), ("d_episode_length", C.c_void_p),
+                ("d_finished_return", C.c_void_p), ("d_finished_length", C.c_void_p),
+                ("stream", C.c_void_p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("tick", C.c_uint64),
+                ("lane_steps", C.c_uint64), ("stepped_after_done", C.c_uint64),
+                ("last_done_count", C.c_int64)]
+
+
+_H = C.c_void_p
+_P = C.c_void_p
+
+# name -> (restype, argtypes); exactly the functions include/gymnet_amd.h declares
+PROTOTYPES = {
+    "gymnet_abi_version": (C.c_int, []),
+    "gymnet_status_string": (C.c_char_p, [C.c_int]),
+    "gymnet_last_error": (C.c_char_p, []),
+    "gymnet_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gymnet_env_describe": (C.c_int, [C.c_int, C.POINTER(EnvInfo)]),
+    "gymnet_vecenv_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "gymnet_vecenv_destroy": (C.c_int, [_H]),
+    "gymnet_vecenv_seed": (C.c_int, [_H, C.c_uint64]),
+    "gymnet_vecenv_seed_lanes": (C.c_int, [_H, _P, C.c_int64]),
+    "gymnet_vecenv_reset": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_reset_where": (C.c_int, [_H, _P, _P]),
+    "gymnet_vecenv_step": (C.c_int, [_H, _P, _P, _P, _P]),
+    "gymnet_vecenv_step_broadcast": (C.c_int, [_H, C.c_int32, _P, _P, _P]),
+    "gymnet_vecenv_step_async": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_step_wait": (C.c_int, [_H, _P, _P, _P]),
+    "gymnet_vecenv_read": (C.c_int, [_H, _P, _P, _P]),
+    "gymnet_vecenv_reset_device": (C.c_int, [_H]),
+    "gymnet_vecenv_reset_where_device": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_step_device": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_rollout_device": (C.c_int, [_H, _P, C.c_int64, C.c_int64, C.c_int64]),
+    "gymnet_vecenv_pack_obs_device": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_sync": (C.c_int, [_H]),
+    "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),
+    "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_set_state": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_get_steps_beyond_done": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_set_steps_beyond_done": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_get_tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "gymnet_vecenv_set_tick": (C.c_int, [_H, C.c_uint64]),
+    "gymnet_vecenv_counters": (C.c_int, [_H, C.POINTER(Counters)]),
+    "gymnet_vecenv_done_lanes": (C.c_int, [_H, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "gymnet_vecenv_episode_stats": (C.c_int, [_H, _P, _P]),
+    "gymnet_vecenv_final_obs": (C.c_int, [_H, _P]),
+    "gymnet_sample_discrete_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32,
+                                                C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gymnet_sample_box_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_float, C.c_float,
+                                           C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gymnet_vecenv_sample_actions_device": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
+    "gymnet_vecenv_sample_actions": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libgymnet_amd.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GymNetError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gymnet_abi_version() != 1:
+        raise GymNetError("libgymnet_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load_library().gymnet_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+_ERRORS = {
+    ERR_INVALID_ARG: ValueError,                 # ArgumentException
+    ERR_INVALID_ACTION: InvalidActionError,
+    ERR_NO_DEVICE: NoDeviceError,
+    ERR_ALREADY_STEPPING: AlreadySteppingError,
+    ERR_NOT_STEPPING: NotSteppingError,
+    ERR_OOM: MemoryError,
+    ERR_UNSUPPORTED: NotImplementedError,        # NotSupportedException
+}
+
+
+def check(status):
+    """Maps a gymnet_status to the exception the reference would throw for the same condition."""
+    if status == OK:
+        return
+    exc = _ERRORS.get(status, GymNetError)
+    msg = last_error() or load_library().gymnet_status_string(status).decode()
+    if exc is InvalidActionError:
+        raise InvalidActionError(msg)
+    raise exc(f"{msg} (gymnet status {status})")
+
+
+def device_count():
+    """Number of HIP devices; 0 when there is none (no exception: callers probe with this)."""
+    n = C.c_int(0)
+    load_library().gymnet_device_count(C.byref(n))
+    return n.value
+
+
+def env_describe(env_id):
+    info = EnvInfo()
+    check(load_library().gymnet_env_describe(int(env_id), C.byref(info)))
+    return info

@@ -1,0 +1,753 @@
+// capi.hip — the C ABI (include/gymnet_amd.h) over the HIP kernels.  Host code only; compiled by hipcc.
+//
+// There is NO CPU fallback in this library: without a usable AMD GPU every compute entry point fails
+// with GYMNET_ERR_NO_DEVICE / GYMNET_ERR_HIP.  The CPU restatement under oracle/ is test infrastructure
+// and is never linked here.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gymnet_amd.h"
+#include "kernels.hpp"
+
+using namespace gymnet;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct EnvDesc {
+    const char *name;
+    int state_dim, obs_dim;
+    bool alias, box_action, has_sbd;
+    int action_n;
+    float action_low, action_high;
+    float obs_low[8], obs_high[8];
+    float reward_low, reward_high;
+    int algorithmic_bytes;
+};
+
+constexpr float FMAX = 3.4028234663852886e38f;
+constexpr float PI_F = 3.14159265358979323846f;
+
+// Observation bounds: CartPoleEnv.cs:46-48 (high = [x_thr*2, float.MaxValue, theta_thr*2, float.MaxValue]).
+// Algorithmic bytes per env-step: SURVEY.md §8(a)/(d).
+const EnvDesc kEnvs[4] = {
+    {"CartPole-v1", 4, 4, true, false, true, 2, 0.f, 0.f,
+     {-4.8000002f, -FMAX, -0.41887903f, -FMAX}, {4.8000002f, FMAX, 0.41887903f, FMAX}, 0.f, 1.f, 41},
+    {"Pendulum-v1", 2, 3, false, true, false, 0, -2.f, 2.f,
+     {-1.f, -1.f, -8.f}, {1.f, 1.f, 8.f}, -16.2736044f, 0.f, 37},
+    {"MountainCar-v0", 2, 2, true, false, false, 3, 0.f, 0.f,
+     {-1.2f, -0.07f}, {0.6f, 0.07f}, -1.f, -1.f, 25},
+    {"Acrobot-v1", 4, 6, false, false, false, 3, 0.f, 0.f,
+     {-1.f, -1.f, -1.f, -1.f, -4.f * PI_F, -9.f * PI_F}, {1.f, 1.f, 1.f, 1.f, 4.f * PI_F, 9.f * PI_F}, -1.f, 0.f, 65},
+};
+
+struct GraphEntry {
+    const void *actions;
+    int64_t len, stride, ring;
+    int parity, cparity;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+}  // namespace
+
+struct gymnet_vecenv {
+    gymnet_config cfg{};
+    const EnvDesc *desc = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, sstride = 0, ostride = 0;
+    bool autoreset = false, extras = false;
+    float *d_state = nullptr, *d_obs = nullptr;
+    bool own_state = false, own_obs = false;
+    float *d_reward = nullptr;
+    uint8_t *d_done = nullptr, *d_mask = nullptr;
+    int32_t *d_sbd = nullptr;
+    uint64_t *d_tick2 = nullptr;
+    void *d_actions = nullptr;     // staging for host-path / broadcast actions
+    float *d_pack = nullptr;       // row-major obs staging
+    float *d_final_obs = nullptr;
+    int32_t *d_done_list = nullptr;
+    uint32_t *d_done_count2 = nullptr;
+    float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
+    int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
+    uint64_t *d_lane_seed = nullptr;
+    unsigned long long *d_after_done = nullptr;
+    uint32_t *d_bad = nullptr;
+    uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
+    int last_cparity = -1;
+    bool async_pending = false;
+    std::atomic<bool> busy{false};
+    LaunchCfg lcfg{4, 256};
+    std::vector<GraphEntry> graphs;
+    std::vector<void *> owned;     // device allocations to free
+    std::string err;
+};
+
+namespace {
+
+int fail(gymnet_vecenv *h, int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (h) h->err = buf;
+    return status;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, e_ == hipErrorOutOfMemory ? GYMNET_ERR_OOM : GYMNET_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                       \
+    } while (0)
+
+#define ST_TRY(expr)                  \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ != GYMNET_OK) return s_; \
+    } while (0)
+
+struct BusyGuard {
+    gymnet_vecenv *h;
+    bool ok;
+    explicit BusyGuard(gymnet_vecenv *hh) : h(hh), ok(false) {
+        bool expect = false;
+        ok = h->busy.compare_exchange_strong(expect, true);
+    }
+    ~BusyGuard() { if (ok) h->busy.store(false); }
+};
+
+#define ENTER(h)                                                                                         \
+    if (!(h)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "%s: null handle", __func__);                 \
+    BusyGuard guard_(h);                                                                                 \
+    if (!guard_.ok) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "%s: handle is in use by another call", __func__); \
+    HIP_TRY(h, hipSetDevice((h)->device))
+
+template <class T>
+int dalloc(gymnet_vecenv *h, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 16);
+    if (e != hipSuccess) return fail(h, GYMNET_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    h->owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return GYMNET_OK;
+}
+
+void drop_graphs(gymnet_vecenv *h) {
+    for (auto &g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
+StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
+    StepArgs a{};
+    a.state = h->d_state;
+    a.obs = h->d_obs;
+    a.action = d_actions;
+    a.reward = h->d_reward;
+    a.done = h->d_done;
+    a.sbd = h->d_sbd;
+    a.tick2 = h->d_tick2;
+    a.final_obs = h->d_final_obs;
+    a.done_list = h->d_done_list;
+    a.done_count2 = h->d_done_count2;
+    a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
+    a.lane_seed = h->d_lane_seed;
+    a.after_done = h->d_after_done;
+    a.n = h->n; a.state_stride = h->sstride; a.obs_stride = h->ostride;
+    a.lane_offset = (uint64_t)h->cfg.lane_offset;
+    a.seed = h->seed;
+    a.parity = (int32_t)(h->tick & 1u);
+    a.cparity = (int32_t)(h->step_launches & 1u);
+    a.max_episode_steps = h->cfg.max_episode_steps;
+    return a;
+}
+
+// one vector step = one kernel launch; bumps the host mirrors of the device-side counters
+int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
+    StepArgs a = make_step_args(h, d_actions);
+    HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
+    h->last_cparity = a.cparity;
+    h->tick += 1;
+    h->step_launches += 1;
+    h->lane_steps += (uint64_t)h->n;
+    return GYMNET_OK;
+}
+
+int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
+    ResetArgs r{};
+    r.state = h->d_state; r.obs = h->d_obs; r.sbd = h->d_sbd; r.done = h->d_done;
+    r.mask = d_mask;
+    r.tick2 = h->d_tick2; r.lane_seed = h->d_lane_seed;
+    r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
+    r.n = h->n; r.state_stride = h->sstride; r.obs_stride = h->ostride;
+    r.lane_offset = (uint64_t)h->cfg.lane_offset; r.seed = h->seed;
+    r.parity = (int32_t)(h->tick & 1u);
+    HIP_TRY(h, launch_reset(h->cfg.env_id, r, h->stream));
+    h->tick += 1;
+    return GYMNET_OK;
+}
+
+int write_tick(gymnet_vecenv *h) {
+    uint64_t both[2] = {h->tick, h->tick};
+    HIP_TRY(h, hipMemcpyAsync(h->d_tick2, both, sizeof both, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // `both` is a stack temporary
+    return GYMNET_OK;
+}
+
+// copy the current results to host buffers (any may be NULL); blocks
+int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    const EnvDesc &d = *h->desc;
+    if (obs_out) {
+        HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (reward_out) HIP_TRY(h, hipMemcpyAsync(reward_out, h->d_reward, (size_t)h->n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (done_out) HIP_TRY(h, hipMemcpyAsync(done_out, h->d_done, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+// Discrete.Contains over the staged batch (only with GYMNET_FLAG_VALIDATE_ACTIONS); blocks
+int validate_staged_actions(gymnet_vecenv *h, const void *d_actions) {
+    const EnvDesc &d = *h->desc;
+    if (!(h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) || d.box_action) return GYMNET_OK;
+    HIP_TRY(h, hipMemsetAsync(h->d_bad, 0, sizeof(uint32_t), h->stream));
+    HIP_TRY(h, launch_validate_discrete(static_cast<const int32_t *>(d_actions), h->n, d.action_n, h->d_bad, h->stream));
+    uint32_t bad = 0;
+    HIP_TRY(h, hipMemcpyAsync(&bad, h->d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (bad)
+        return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%u of %lld lanes, Discrete(%d))",
+                    bad, (long long)h->n, d.action_n);
+    return GYMNET_OK;
+}
+
+int stage_host_actions(gymnet_vecenv *h, const void *actions) {
+    if (!actions) return fail(h, GYMNET_ERR_INVALID_ARG, "actions is null");
+    HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
+    return validate_staged_actions(h, h->d_actions);
+}
+
+void recompute_extras(gymnet_vecenv *h) {
+    h->extras = (h->cfg.flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS)) != 0 ||
+                h->d_lane_seed != nullptr;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int gymnet_abi_version(void) { return GYMNET_ABI_VERSION; }
+
+const char *gymnet_status_string(int status) {
+    switch (status) {
+        case GYMNET_OK: return "ok";
+        case GYMNET_ERR_INVALID_ARG: return "invalid argument";
+        case GYMNET_ERR_INVALID_ACTION: return "Action is outside of the configured action space.";
+        case GYMNET_ERR_HIP: return "HIP runtime error";
+        case GYMNET_ERR_OOM: return "out of memory";
+        case GYMNET_ERR_NO_DEVICE: return "no AMD GPU available (this engine has no CPU fallback)";
+        case GYMNET_ERR_ALREADY_STEPPING: return "already running an async step";
+        case GYMNET_ERR_NOT_STEPPING: return "not running an async step";
+        case GYMNET_ERR_UNSUPPORTED: return "unsupported for this environment / configuration";
+        default: return "unknown status";
+    }
+}
+
+const char *gymnet_last_error(void) { return g_last_error.c_str(); }
+
+int gymnet_device_count(int *count) {
+    if (!count) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *count = 0;
+        (void)hipGetLastError();
+        return fail(nullptr, GYMNET_ERR_NO_DEVICE, "hipGetDeviceCount: %s", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    *count = c;
+    return GYMNET_OK;
+}
+
+int gymnet_env_describe(int env_id, gymnet_env_info *out) {
+    if (!out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "out is null");
+    if (env_id < 0 || env_id > 3) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "unknown env_id %d", env_id);
+    const EnvDesc &d = kEnvs[env_id];
+    std::memset(out, 0, sizeof *out);
+    out->struct_size = sizeof *out;
+    out->env_id = env_id;
+    std::snprintf(out->name, sizeof out->name, "%s", d.name);
+    out->state_dim = d.state_dim; out->obs_dim = d.obs_dim; out->obs_aliases_state = d.alias;
+    out->action_is_box = d.box_action; out->action_n = d.action_n;
+    out->action_low = d.action_low; out->action_high = d.action_high;
+    for (int k = 0; k < 8; ++k) { out->obs_low[k] = d.obs_low[k]; out->obs_high[k] = d.obs_high[k]; }
+    out->reward_low = d.reward_low; out->reward_high = d.reward_high;
+    out->algorithmic_bytes_per_step = d.algorithmic_bytes;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_destroy(gymnet_vecenv *h) {
+    if (!h) return GYMNET_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    for (void *p : h->owned) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
+    if (!out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!cfg) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "cfg is null");
+    if (cfg->struct_size != sizeof(gymnet_config))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "cfg.struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(gymnet_config));
+    if (cfg->env_id < 0 || cfg->env_id > 3) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "unknown env_id %d", cfg->env_id);
+    if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 31)
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "num_envs %lld out of range [1, 2^31]", (long long)cfg->num_envs);
+    if (cfg->lane_offset < 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "lane_offset < 0");
+    if (cfg->max_episode_steps < 0 || (cfg->max_episode_steps > 0 && !(cfg->flags & GYMNET_FLAG_EPISODE_STATS)))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "max_episode_steps needs GYMNET_FLAG_EPISODE_STATS");
+    if ((cfg->flags & GYMNET_FLAG_FINAL_OBS) && !(cfg->flags & GYMNET_FLAG_AUTORESET))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "GYMNET_FLAG_FINAL_OBS needs GYMNET_FLAG_AUTORESET");
+    if (cfg->d_ext_obs && cfg->ext_obs_stride < cfg->num_envs)
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "ext_obs_stride %lld < num_envs", (long long)cfg->ext_obs_stride);
+
+    int ndev = 0;
+    int s = gymnet_device_count(&ndev);
+    if (s != GYMNET_OK) return s;
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "device %d not in [0, %d)", cfg->device, ndev);
+
+    gymnet_vecenv *h = new (std::nothrow) gymnet_vecenv();
+    if (!h) return fail(nullptr, GYMNET_ERR_OOM, "host allocation failed");
+    h->cfg = *cfg;
+    h->desc = &kEnvs[cfg->env_id];
+    h->device = cfg->device;
+    h->n = cfg->num_envs;
+    h->seed = cfg->seed;
+    h->autoreset = (cfg->flags & GYMNET_FLAG_AUTORESET) != 0;
+    const EnvDesc &d = *h->desc;
+
+#define CREATE_TRY(expr)                      \
+    do {                                      \
+        int s_ = (expr);                      \
+        if (s_ != GYMNET_OK) { gymnet_vecenv_destroy(h); return s_; } \
+    } while (0)
+#define CREATE_HIP(expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            int s_ = fail(nullptr, GYMNET_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            gymnet_vecenv_destroy(h);                                                       \
+            return s_;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(h->device));
+    if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); }
+    else { CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+
+    const int64_t padded = (h->n + 63) / 64 * 64;   // every component array starts 256-byte aligned
+    if (cfg->d_ext_obs) {
+        if (d.alias) { h->d_state = cfg->d_ext_obs; h->sstride = cfg->ext_obs_stride; h->d_obs = h->d_state; h->ostride = h->sstride; }
+        else {
+            h->d_obs = cfg->d_ext_obs; h->ostride = cfg->ext_obs_stride;
+            CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded; h->own_state = true;
+        }
+    } else {
+        CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded; h->own_state = true;
+        if (d.alias) { h->d_obs = h->d_state; h->ostride = h->sstride; }
+        else { CREATE_TRY(dalloc(h, &h->d_obs, (size_t)padded * d.obs_dim)); h->ostride = padded; h->own_obs = true; }
+    }
+    CREATE_TRY(dalloc(h, &h->d_reward, (size_t)padded));
+    CREATE_TRY(dalloc(h, &h->d_done, (size_t)padded));
+    CREATE_TRY(dalloc(h, &h->d_mask, (size_t)padded));
+    CREATE_TRY(dalloc(h, &h->d_tick2, 2));
+    CREATE_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)padded));
+    CREATE_TRY(dalloc(h, &h->d_pack, (size_t)padded * d.obs_dim));
+    CREATE_TRY(dalloc(h, &h->d_after_done, 1));
+    CREATE_TRY(dalloc(h, &h->d_bad, 1));
+    if (d.has_sbd && !h->autoreset) CREATE_TRY(dalloc(h, &h->d_sbd, (size_t)padded));
+    if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, &h->d_final_obs, (size_t)h->n * d.obs_dim));
+    if (cfg->flags & GYMNET_FLAG_DONE_LIST) {
+        CREATE_TRY(dalloc(h, &h->d_done_list, (size_t)padded));
+        CREATE_TRY(dalloc(h, &h->d_done_count2, 2));
+        CREATE_HIP(hipMemsetAsync(h->d_done_count2, 0, 2 * sizeof(uint32_t), h->stream));
+    }
+    if (cfg->flags & GYMNET_FLAG_EPISODE_STATS) {
+        CREATE_TRY(dalloc(h, &h->d_ep_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_ep_len, (size_t)padded));
+        CREATE_TRY(dalloc(h, &h->d_fin_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_fin_len, (size_t)padded));
+        CREATE_HIP(hipMemsetAsync(h->d_ep_ret, 0, (size_t)padded * 4, h->stream));
+        CREATE_HIP(hipMemsetAsync(h->d_ep_len, 0, (size_t)padded * 4, h->stream));
+        CREATE_HIP(hipMemsetAsync(h->d_fin_ret, 0, (size_t)padded * 4, h->stream));
+        CREATE_HIP(hipMemsetAsync(h->d_fin_len, 0, (size_t)padded * 4, h->stream));
+    }
+    recompute_extras(h);
+    // defined start: zero state, reward, done; sbd = -1
+    CREATE_HIP(hipMemsetAsync(h->d_state, 0, (size_t)h->sstride * (d.state_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
+    if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
+    CREATE_HIP(hipMemsetAsync(h->d_reward, 0, (size_t)padded * 4, h->stream));
+    CREATE_HIP(hipMemsetAsync(h->d_done, 0, (size_t)padded, h->stream));
+    CREATE_HIP(hipMemsetAsync(h->d_after_done, 0, sizeof(unsigned long long), h->stream));
+    if (h->d_final_obs) CREATE_HIP(hipMemsetAsync(h->d_final_obs, 0, (size_t)h->n * d.obs_dim * 4, h->stream));
+    if (h->d_sbd) CREATE_HIP(launch_fill_i32(h->d_sbd, -1, h->n, h->stream));
+    CREATE_TRY(write_tick(h));
+
+    // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
+    const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0);
+    h->lcfg.vec = can_vec4 ? 4 : 1;
+    if (const char *e = std::getenv("GYMNET_VEC")) { int v = std::atoi(e); if (v == 1 || (v == 4 && can_vec4)) h->lcfg.vec = v; }
+    if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
+#undef CREATE_TRY
+#undef CREATE_HIP
+    *out = h;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed) {
+    ENTER(h);
+    h->seed = seed;
+    h->tick = 0;
+    drop_graphs(h);   // the seed is a (frozen) kernel argument of captured launches
+    h->d_lane_seed = nullptr;   // back to one key for all lanes (the old array stays owned until destroy)
+    recompute_extras(h);
+    return write_tick(h);
+}
+
+int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t count) {
+    ENTER(h);
+    if (!seeds) return fail(h, GYMNET_ERR_INVALID_ARG, "seeds is null");
+    if (count != h->n)   // VecEnv.cs:49
+        return fail(h, GYMNET_ERR_INVALID_ARG, "Number of seeds passed should be equals to number of environments (%lld != %lld)",
+                    (long long)count, (long long)h->n);
+    uint64_t *p = nullptr;
+    ST_TRY(dalloc(h, &p, (size_t)h->n));
+    HIP_TRY(h, hipMemcpyAsync(p, seeds, (size_t)h->n * 8, hipMemcpyHostToDevice, h->stream));
+    h->d_lane_seed = p;
+    recompute_extras(h);
+    h->tick = 0;
+    drop_graphs(h);
+    return write_tick(h);
+}
+
+int gymnet_vecenv_reset_device(gymnet_vecenv *h) {
+    ENTER(h);
+    return launch_reset_lanes(h, nullptr);
+}
+
+int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
+    ENTER(h);
+    if (!d_mask) {   // own done flags: snapshot them, because the reset kernel clears done for reset lanes
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+        d_mask = h->d_mask;
+    }
+    return launch_reset_lanes(h, d_mask);
+}
+
+int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out) {
+    ENTER(h);
+    ST_TRY(launch_reset_lanes(h, nullptr));
+    return copy_out(h, obs_out, nullptr, nullptr);
+}
+
+int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out) {
+    ENTER(h);
+    if (mask) HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    ST_TRY(launch_reset_lanes(h, h->d_mask));
+    return copy_out(h, obs_out, nullptr, nullptr);
+}
+
+int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) {
+    ENTER(h);
+    if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
+    ST_TRY(stage_host_actions(h, actions));
+    ST_TRY(launch_one_step(h, h->d_actions));
+    return copy_out(h, obs_out, reward_out, done_out);
+}
+
+int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_out, float *reward_out, uint8_t *done_out) {
+    ENTER(h);
+    if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
+    const EnvDesc &d = *h->desc;
+    if (d.box_action) {   // IVecEnv.Step(int) on a Box space: the int is the (scalar) torque
+        float f = (float)action;
+        int32_t bits;
+        std::memcpy(&bits, &f, 4);
+        HIP_TRY(h, launch_fill_i32(static_cast<int32_t *>(h->d_actions), bits, h->n, h->stream));
+    } else {
+        if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && (action < 0 || action >= d.action_n))
+            return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%d, Discrete(%d))", action, d.action_n);
+        HIP_TRY(h, launch_fill_i32(static_cast<int32_t *>(h->d_actions), action, h->n, h->stream));
+    }
+    ST_TRY(launch_one_step(h, h->d_actions));
+    return copy_out(h, obs_out, reward_out, done_out);
+}
+
+int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions) {
+    ENTER(h);
+    if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
+    ST_TRY(stage_host_actions(h, actions));
+    ST_TRY(launch_one_step(h, h->d_actions));
+    h->async_pending = true;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    ENTER(h);
+    if (!h->async_pending) return fail(h, GYMNET_ERR_NOT_STEPPING, "not running an async step");
+    h->async_pending = false;
+    return copy_out(h, obs_out, reward_out, done_out);
+}
+
+int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    ENTER(h);
+    return copy_out(h, obs_out, reward_out, done_out);
+}
+
+int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions) {
+    ENTER(h);
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    if (h->lcfg.vec == 4 && !aligned16(d_actions)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions must be 16-byte aligned");
+    ST_TRY(validate_staged_actions(h, d_actions));
+    return launch_one_step(h, d_actions);
+}
+
+int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring) {
+    ENTER(h);
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
+    if (h->lcfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be 16-byte aligned");
+    const char *base = static_cast<const char *>(d_actions);
+    auto slice = [&](int64_t t) -> const void * { return base + (size_t)((t % ring) * action_stride) * 4; };
+
+    // graph length: a multiple of `ring` (so every replay starts at slice 0) and even (so the
+    // double-buffered device tick / done-count parities are the same at every replay)
+    int64_t glen = (ring % 2 == 0) ? ring : 2 * ring;
+    int64_t t = 0;
+    if (glen <= 4096 && steps >= glen) {
+        const int parity = (int)(h->tick & 1u), cparity = (int)(h->step_launches & 1u);
+        GraphEntry *ge = nullptr;
+        for (auto &g : h->graphs)
+            if (g.actions == d_actions && g.len == glen && g.stride == action_stride && g.ring == ring && g.parity == parity && g.cparity == cparity)
+                ge = &g;
+        if (!ge) {
+            const uint64_t tick0 = h->tick, sl0 = h->step_launches, ls0 = h->lane_steps;
+            HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            int s = GYMNET_OK;
+            for (int64_t k = 0; k < glen && s == GYMNET_OK; ++k) s = launch_one_step(h, slice(k));
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            h->tick = tick0; h->step_launches = sl0; h->lane_steps = ls0;   // capturing launched nothing
+            if (s != GYMNET_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
+            if (e != hipSuccess) return fail(h, GYMNET_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            hipGraphExec_t exec = nullptr;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail(h, GYMNET_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+            h->graphs.push_back(GraphEntry{d_actions, glen, action_stride, ring, parity, cparity, graph, exec});
+            ge = &h->graphs.back();
+        }
+        for (; t + glen <= steps; t += glen) {
+            HIP_TRY(h, hipGraphLaunch(ge->exec, h->stream));
+            h->tick += (uint64_t)glen;
+            h->step_launches += (uint64_t)glen;
+            h->lane_steps += (uint64_t)glen * (uint64_t)h->n;
+            h->last_cparity = (int)((h->step_launches - 1) & 1u);
+        }
+    }
+    for (; t < steps; ++t) ST_TRY(launch_one_step(h, slice(t)));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor) {
+    ENTER(h);
+    if (!d_obs_rowmajor) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor is null");
+    if (!aligned16(d_obs_rowmajor)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor must be 16-byte aligned");
+    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_obs, h->ostride, d_obs_rowmajor, h->n, h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_sync(gymnet_vecenv *h) {
+    ENTER(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
+    if (!h || !out) return fail(h, GYMNET_ERR_INVALID_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->struct_size = sizeof *out;
+    out->state_dim = h->desc->state_dim; out->obs_dim = h->desc->obs_dim; out->obs_aliases_state = h->desc->alias;
+    out->num_envs = h->n; out->state_stride = h->sstride; out->obs_stride = h->ostride;
+    out->d_state = h->d_state; out->d_obs = h->d_obs; out->d_reward = h->d_reward; out->d_done = h->d_done;
+    out->d_steps_beyond_done = h->d_sbd; out->d_final_obs = h->d_final_obs; out->d_done_list = h->d_done_list;
+    out->d_episode_return = h->d_ep_ret; out->d_episode_length = h->d_ep_len;
+    out->d_finished_return = h->d_fin_ret; out->d_finished_length = h->d_fin_len;
+    out->stream = h->stream;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa) {
+    ENTER(h);
+    if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    HIP_TRY(h, hipMemcpy2DAsync(state_soa, (size_t)h->n * 4, h->d_state, (size_t)h->sstride * 4, (size_t)h->n * 4,
+                                (size_t)h->desc->state_dim, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa) {
+    ENTER(h);
+    if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    HIP_TRY(h, hipMemcpy2DAsync(h->d_state, (size_t)h->sstride * 4, state_soa, (size_t)h->n * 4, (size_t)h->n * 4,
+                                (size_t)h->desc->state_dim, hipMemcpyHostToDevice, h->stream));
+    if (!h->desc->alias)
+        HIP_TRY(h, launch_observe(h->cfg.env_id, h->d_state, h->sstride, h->d_obs, h->ostride, h->n, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_get_steps_beyond_done(gymnet_vecenv *h, int32_t *out) {
+    ENTER(h);
+    if (!h->d_sbd) return fail(h, GYMNET_ERR_UNSUPPORTED, "steps_beyond_done exists only for CartPole without GYMNET_FLAG_AUTORESET");
+    if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_sbd, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_set_steps_beyond_done(gymnet_vecenv *h, const int32_t *in) {
+    ENTER(h);
+    if (!h->d_sbd) return fail(h, GYMNET_ERR_UNSUPPORTED, "steps_beyond_done exists only for CartPole without GYMNET_FLAG_AUTORESET");
+    if (!in) return fail(h, GYMNET_ERR_INVALID_ARG, "in is null");
+    HIP_TRY(h, hipMemcpyAsync(h->d_sbd, in, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_get_tick(gymnet_vecenv *h, uint64_t *tick) {
+    if (!h || !tick) return fail(h, GYMNET_ERR_INVALID_ARG, "null argument");
+    *tick = h->tick;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_set_tick(gymnet_vecenv *h, uint64_t tick) {
+    ENTER(h);
+    h->tick = tick;
+    return write_tick(h);
+}
+
+int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out) {
+    ENTER(h);
+    if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
+    std::memset(out, 0, sizeof *out);
+    out->struct_size = sizeof *out;
+    unsigned long long ad = 0;
+    HIP_TRY(h, hipMemcpyAsync(&ad, h->d_after_done, sizeof ad, hipMemcpyDeviceToHost, h->stream));
+    uint32_t cnt[2] = {0, 0};
+    if (h->d_done_count2) HIP_TRY(h, hipMemcpyAsync(cnt, h->d_done_count2, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint64_t dtick[2] = {0, 0};
+    HIP_TRY(h, hipMemcpy(dtick, h->d_tick2, sizeof dtick, hipMemcpyDeviceToHost));
+    out->tick = dtick[h->tick & 1u];   // the device's own count (== host mirror h->tick)
+    out->lane_steps = h->lane_steps;
+    out->stepped_after_done = ad;
+    out->last_done_count = (h->d_done_count2 && h->last_cparity >= 0) ? (int64_t)cnt[h->last_cparity] : -1;
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capacity, int64_t *count) {
+    ENTER(h);
+    if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
+    if (!count || capacity < 0 || (capacity > 0 && !lanes_out)) return fail(h, GYMNET_ERR_INVALID_ARG, "bad count/capacity/lanes_out");
+    uint32_t cnt[2] = {0, 0};
+    HIP_TRY(h, hipMemcpyAsync(cnt, h->d_done_count2, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int64_t c = h->last_cparity >= 0 ? (int64_t)cnt[h->last_cparity] : 0;
+    *count = c;
+    const int64_t m = c < capacity ? c : capacity;
+    if (m > 0) HIP_TRY(h, hipMemcpy(lanes_out, h->d_done_list, (size_t)m * 4, hipMemcpyDeviceToHost));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length) {
+    ENTER(h);
+    if (!h->d_fin_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_EPISODE_STATS");
+    if (finished_return) HIP_TRY(h, hipMemcpyAsync(finished_return, h->d_fin_ret, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (finished_length) HIP_TRY(h, hipMemcpyAsync(finished_length, h->d_fin_len, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
+    ENTER(h);
+    if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
+    if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
+    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_final_obs, h->n, h->d_pack, h->n, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
+                                  uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    if (!d_out || count < 0 || n <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/n");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_sample_discrete(d_out, count, n, start, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+}
+
+int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t count, float low, float high,
+                             uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    if (!d_out || count < 0 || !(low <= high)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/bounds");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_sample_box(d_out, count, low, high, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick) {
+    ENTER(h);
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    const EnvDesc &d = *h->desc;
+    if (d.box_action)
+        HIP_TRY(h, launch_sample_box(static_cast<float *>(d_actions), h->n, d.action_low, d.action_high, seed,
+                                     (uint64_t)h->cfg.lane_offset, tick, h->stream));
+    else
+        HIP_TRY(h, launch_sample_discrete(static_cast<int32_t *>(d_actions), h->n, d.action_n, 0, seed,
+                                          (uint64_t)h->cfg.lane_offset, tick, h->stream));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick) {
+    if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
+    if (!actions_out) return fail(h, GYMNET_ERR_INVALID_ARG, "actions_out is null");
+    ST_TRY(gymnet_vecenv_sample_actions_device(h, h->d_actions, seed, tick));
+    ENTER(h);
+    HIP_TRY(h, hipMemcpyAsync(actions_out, h->d_actions, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+}
+
+}  // extern "C"

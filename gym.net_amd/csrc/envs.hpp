@@ -1,0 +1,219 @@
+// envs.hpp — per-lane dynamics of the classic-control environments, binary32, one env per GPU lane.
+//
+// This translation unit is compiled with -ffp-contract=off: every operation rounds to binary32 on
+// its own, in the association order written here, so the arithmetic is reproducible and can be
+// bounded tightly against the reference's binary64 arithmetic (<= 1e-5 abs per step, north_star).
+//
+// CartPole follows src/Gym.Environments/Envs/Classic/CartPoleEnv.cs (paths relative to the Gym.NET
+// tree): constants :24-36 (the C# `const float` bit patterns), Step :137-186, Reset :63-67.
+// Pendulum / MountainCar / Acrobot do not exist in the reference (README.md:69-76, unchecked roadmap
+// items); they follow the upstream openai/gym classic_control algorithms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace gymnet {
+
+// ---------------------------------------------------------------------------------------------
+// CartPole-v1  (CartPoleEnv.cs)
+// ---------------------------------------------------------------------------------------------
+struct CartPole {
+    static constexpr int S = 4;              // x, x_dot, theta, theta_dot       (:141-144)
+    static constexpr int O = 4;              // observation == state             (:166,185)
+    static constexpr bool OBS_ALIASES_STATE = true;
+    static constexpr bool HAS_SBD = true;    // steps_beyond_done state machine  (:41,168-183)
+    static constexpr bool BOX_ACTION = false;
+    using Action = int32_t;                  // Discrete(2)                      (:47)
+
+    // :24-36 — the float32 values of the C# consts (total_mass, polemass_length const-folded in float)
+    static constexpr float gravity = 9.8f;
+    static constexpr float masspole = 0.1f;
+    static constexpr float total_mass = 0.1f + 1.0f;
+    static constexpr float length = 0.5f;
+    static constexpr float polemass_length = 0.1f * 0.5f;
+    static constexpr float force_mag = 10.0f;
+    static constexpr float tau = 0.02f;
+    static constexpr float theta_threshold = 0.20943951606750488f;   // (float)(12*2*Math.PI/360) = 0x1.aceeap-3
+    static constexpr float x_threshold = 2.4f;
+
+    // :146-167.  Any action != 1 pushes left (validity is only Debug.Assert'ed, :139).
+    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+        const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+        const float force = (a == 1) ? force_mag : -force_mag;                                   // :146
+        float sintheta, costheta;
+        sincosf(theta, &sintheta, &costheta);                                                    // :147-148
+        const float temp = (force + polemass_length * theta_dot * theta_dot * sintheta) / total_mass;   // :149
+        const float thetaacc = (gravity * sintheta - costheta * temp)
+                               / (length * (4.0f / 3.0f - masspole * costheta * costheta / total_mass)); // :150
+        const float xacc = temp - polemass_length * thetaacc * costheta / total_mass;            // :151
+        // explicit Euler (:32,153-158): positions advance with the OLD velocities
+        const float nx = x + tau * x_dot;
+        const float nx_dot = x_dot + tau * xacc;
+        const float ntheta = theta + tau * theta_dot;
+        const float ntheta_dot = theta_dot + tau * thetaacc;
+        s[0] = nx; s[1] = nx_dot; s[2] = ntheta; s[3] = ntheta_dot;                              // :166
+        done = nx < -x_threshold || nx > x_threshold || ntheta < -theta_threshold || ntheta > theta_threshold;  // :167
+        reward = 1.0f;   // the steps_beyond_done rule (:168-183) is applied by the kernel, which owns sbd
+    }
+
+    // :63-67 — state = uniform(-0.05, 0.05, 4) as low + (high-low)*u
+    __device__ __forceinline__ static void reset(float (&s)[S], const PhiloxWords &r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = -0.05f + 0.1f * u01_24(r.w[k]);
+    }
+
+    __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = s[k];
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Pendulum-v1  (upstream gym; semi-implicit Euler; never terminates)
+// ---------------------------------------------------------------------------------------------
+struct Pendulum {
+    static constexpr int S = 2;              // theta, theta_dot
+    static constexpr int O = 3;              // cos, sin, theta_dot
+    static constexpr bool OBS_ALIASES_STATE = false;
+    static constexpr bool HAS_SBD = false;
+    static constexpr bool BOX_ACTION = true;
+    using Action = float;                    // Box(-2, 2, (1,))
+    static constexpr float PI = 3.14159265358979323846f;
+
+    __device__ __forceinline__ static float floored_mod(float a, float m) {
+        float r = fmodf(a, m);
+        if (r < 0.0f) r += m;
+        return r;
+    }
+
+    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+        const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f;
+        const float th = s[0], thdot = s[1];
+        const float u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
+        const float nrm = floored_mod(th + PI, 2.0f * PI) - PI;
+        const float costs = nrm * nrm + 0.1f * (thdot * thdot) + 0.001f * (u * u);
+        float newthdot = thdot + (15.0f * sinf(th) + 3.0f * u) * dt;     // 3g/(2l) = 15, 3/(m l^2) = 3
+        newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+        const float newth = th + newthdot * dt;
+        s[0] = newth; s[1] = newthdot;
+        reward = -costs;
+        done = false;
+    }
+
+    __device__ __forceinline__ static void reset(float (&s)[S], const PhiloxWords &r) {
+        s[0] = -PI + (2.0f * PI) * u01_24(r.w[0]);
+        s[1] = -1.0f + 2.0f * u01_24(r.w[1]);
+    }
+
+    __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
+        o[0] = cosf(s[0]); o[1] = sinf(s[0]); o[2] = s[1];
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// MountainCar-v0  (upstream gym)
+// ---------------------------------------------------------------------------------------------
+struct MountainCar {
+    static constexpr int S = 2;              // position, velocity
+    static constexpr int O = 2;
+    static constexpr bool OBS_ALIASES_STATE = true;
+    static constexpr bool HAS_SBD = false;
+    static constexpr bool BOX_ACTION = false;
+    using Action = int32_t;                  // Discrete(3)
+
+    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+        float p = s[0], v = s[1];
+        v += (float)(a - 1) * 0.001f + cosf(3.0f * p) * (-0.0025f);
+        v = v < -0.07f ? -0.07f : (v > 0.07f ? 0.07f : v);
+        p += v;
+        p = p < -1.2f ? -1.2f : (p > 0.6f ? 0.6f : p);
+        if (p == -1.2f && v < 0.0f) v = 0.0f;
+        s[0] = p; s[1] = v;
+        reward = -1.0f;
+        done = p >= 0.5f && v >= 0.0f;
+    }
+
+    __device__ __forceinline__ static void reset(float (&s)[S], const PhiloxWords &r) {
+        s[0] = -0.6f + 0.2f * u01_24(r.w[0]);
+        s[1] = 0.0f;
+    }
+
+    __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) { o[0] = s[0]; o[1] = s[1]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Acrobot-v1  (upstream gym; "book" dynamics; one classical RK4 step of dt = 0.2)
+// ---------------------------------------------------------------------------------------------
+struct Acrobot {
+    static constexpr int S = 4;              // theta1, theta2, dtheta1, dtheta2
+    static constexpr int O = 6;              // cos1, sin1, cos2, sin2, dtheta1, dtheta2
+    static constexpr bool OBS_ALIASES_STATE = false;
+    static constexpr bool HAS_SBD = false;
+    static constexpr bool BOX_ACTION = false;
+    using Action = int32_t;                  // Discrete(3): torque = a - 1
+    static constexpr float PI = 3.14159265358979323846f;
+
+    // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals
+    __device__ __forceinline__ static void dsdt(const float (&s)[4], float torque, float (&d)[4]) {
+        const float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+        float s2, c2;
+        sincosf(th2, &s2, &c2);
+        const float d1 = 0.25f + (1.25f + c2) + 2.0f;
+        const float d2 = (0.25f + 0.5f * c2) + 1.0f;
+        const float phi2 = 4.9f * cosf(th1 + th2 - PI / 2.0f);
+        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * cosf(th1 - PI / 2.0f) + phi2;
+        const float ddth2 = (torque + d2 / d1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 / d1);
+        const float ddth1 = -(d2 * ddth2 + phi1) / d1;
+        d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+    }
+
+    __device__ __forceinline__ static float wrap(float x, float m, float M) {
+        // upstream loops `while x > M: x -= diff`; bounded here so a non-finite state cannot hang the GPU
+        const float diff = M - m;
+        for (int it = 0; it < 64 && x > M; ++it) x -= diff;
+        for (int it = 0; it < 64 && x < m; ++it) x += diff;
+        return x;
+    }
+
+    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+        const float dt = 0.2f, mv1 = 4.0f * PI, mv2 = 9.0f * PI;
+        const float torque = (float)(a - 1);
+        float k1[4], k2[4], k3[4], k4[4], y[4];
+        dsdt(s, torque, k1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 2.0f * k1[i];
+        dsdt(y, torque, k2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 2.0f * k2[i];
+        dsdt(y, torque, k3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
+        dsdt(y, torque, k4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+        y[0] = wrap(y[0], -PI, PI);
+        y[1] = wrap(y[1], -PI, PI);
+        y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+        y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = y[i];
+        done = (-cosf(y[0]) - cosf(y[1] + y[0])) > 1.0f;
+        reward = done ? 0.0f : -1.0f;
+    }
+
+    __device__ __forceinline__ static void reset(float (&s)[S], const PhiloxWords &r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = -0.1f + 0.2f * u01_24(r.w[k]);
+    }
+
+    __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
+        float s1, c1, s2, c2;
+        sincosf(s[0], &s1, &c1);
+        sincosf(s[1], &s2, &c2);
+        o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
+    }
+};
+
+}  // namespace gymnet

@@ -1,0 +1,455 @@
+// kernels.hip — HIP kernels of the batched classic-control engine, written for gfx950 (CDNA4, wave64).
+//
+// The hot path is HBM-bound streaming (CartPole: 41 algorithmic bytes per env-step against ~40 flop +
+// one sincos), so the design rules are the memory ones: structure-of-arrays, one env per lane, 16-byte
+// (dwordx4) accesses per lane on every stream, a static block->lane map (block b always owns the same
+// lanes and the dispatcher places block b on XCD b % 8, so a batch that fits the 8 x 4 MiB L2s is
+// re-read from its own XCD's L2 on the next step), no LDS (there is no reuse to stage: each state
+// word is read once and written once), no MFMA (no dense contraction exists on this path).
+// Auto-reset is a divergent Philox4x32-10 call executed only by waves that contain a finished lane
+// (exec-mask skip); done-lane compaction is one wave ballot + one atomic per wave.
+//
+// Compiled with -ffp-contract=off (see envs.hpp).
+#include "kernels.hpp"
+
+#include "envs.hpp"
+
+namespace gymnet {
+
+// ---------------------------------------------------------------------------------------------
+// VEC-wide lane access helpers.  i0 is a multiple of VEC; arrays are 16-byte aligned (capi.hip
+// checks this before it picks VEC = 4), so the full-vector path is one dwordx4 per lane.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0, int64_t n, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (i0 + 4 <= n) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + i0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = (i0 + j < n) ? p[i0 + j] : 0.0f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int64_t n, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<float4 *>(p + i0) = make_float4(v[0], v[1], v[2], v[3]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+        if (i0 + j < n) p[i0 + j] = v[j];
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t i0, int64_t n, int32_t (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (i0 + 4 <= n) {
+            const int4 t = *reinterpret_cast<const int4 *>(p + i0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = (i0 + j < n) ? p[i0 + j] : 0;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, int64_t n, const int32_t (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<int4 *>(p + i0) = make_int4(v[0], v[1], v[2], v[3]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+        if (i0 + j < n) p[i0 + j] = v[j];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, int64_t n, const uint8_t (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<uint32_t *>(p + i0) =
+                (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+        if (i0 + j < n) p[i0 + j] = v[j];
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The vector step: ONE launch advances every lane by one env-step.
+//   Env       dynamics (envs.hpp)
+//   VEC       envs per thread (4 = dwordx4 streams; 1 = fallback for unaligned external buffers)
+//   AUTORESET fuse the caller's `if (done) Reset()` (README.md:36-40) as a masked Philox reset
+//   EXTRAS    done-list compaction, episode statistics, terminal observations, per-lane seeds, time limit
+// ---------------------------------------------------------------------------------------------
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS>
+__global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
+    constexpr int S = Env::S, O = Env::O;
+    using Act = typename Env::Action;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const int64_t n = a.n;
+
+    // engine tick (Philox counter word): double-buffered in device memory so that a replayed
+    // hipGraph, whose kernel arguments are frozen, still advances it.
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.tick2[a.parity ^ 1] = tick + 1;
+        if constexpr (EXTRAS) {
+            if (a.done_count2) a.done_count2[a.cparity ^ 1] = 0u;   // the NEXT step launch's counter
+        }
+    }
+    if (i0 >= n) return;
+
+    float s[S][VEC];
+#pragma unroll
+    for (int k = 0; k < S; ++k) load_f32<VEC>(a.state + k * a.state_stride, i0, n, s[k]);
+    Act act[VEC];
+    if constexpr (Env::BOX_ACTION) load_f32<VEC>(static_cast<const float *>(a.action), i0, n, act);
+    else load_i32<VEC>(static_cast<const int32_t *>(a.action), i0, n, act);
+
+    int32_t sbd[VEC];
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC>(a.sbd, i0, n, sbd);
+
+    float ep_ret[VEC];
+    int32_t ep_len[VEC];
+    bool stats = false;
+    if constexpr (EXTRAS) {
+        stats = a.ep_ret != nullptr;
+        if (stats) { load_f32<VEC>(a.ep_ret, i0, n, ep_ret); load_i32<VEC>(a.ep_len, i0, n, ep_len); }
+    }
+
+    float reward[VEC];
+    uint8_t done[VEC];
+    bool finished[VEC];
+    float o[O][VEC];
+
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        float sj[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+        bool dn;
+        float rw;
+        Env::step(sj, act[j], rw, dn);
+
+        if constexpr (!AUTORESET && Env::HAS_SBD) {
+            // CartPoleEnv.cs:168-183 — reward 1 until and including the step the pole falls, 0 afterwards
+            if (dn) {
+                if (sbd[j] == -1) { sbd[j] = 0; }
+                else {
+                    if (i0 + j < n) atomicAdd(a.after_done, 1ull);   // the reference's console warning, counted
+                    sbd[j] += 1;
+                    rw = 0.0f;
+                }
+            }
+        }
+
+        uint8_t db = dn ? 1 : 0;
+        if constexpr (EXTRAS) {
+            if (stats) {
+                ep_ret[j] += rw;
+                ep_len[j] += 1;
+                if (a.max_episode_steps > 0 && ep_len[j] >= a.max_episode_steps) db |= 2;   // truncated (extension)
+            }
+        }
+        const bool fin = db != 0;
+        finished[j] = fin && (i0 + j < n);
+        done[j] = db;
+        reward[j] = rw;
+
+        if constexpr (EXTRAS) {
+            if (fin && a.final_obs && i0 + j < n) {
+                float fo[O];
+                Env::observe(sj, fo);
+#pragma unroll
+                for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = fo[k];
+            }
+            if (stats && fin && i0 + j < n) {
+                a.fin_ret[i0 + j] = ep_ret[j];
+                a.fin_len[i0 + j] = ep_len[j];
+                if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
+            }
+        }
+
+        if constexpr (AUTORESET) {
+            if (fin) {   // divergent: waves without a finished lane skip the Philox rounds entirely
+                uint64_t key = a.seed;
+                if constexpr (EXTRAS) {
+                    if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
+                }
+                const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
+                Env::reset(sj, r);
+            }
+        }
+
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+        if constexpr (!Env::OBS_ALIASES_STATE) {
+            float oj[O];
+            Env::observe(sj, oj);
+#pragma unroll
+            for (int k = 0; k < O; ++k) o[k][j] = oj[k];
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < S; ++k) store_f32<VEC>(a.state + k * a.state_stride, i0, n, s[k]);
+    if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) store_f32<VEC>(a.obs + k * a.obs_stride, i0, n, o[k]);
+    }
+    store_f32<VEC>(a.reward, i0, n, reward);
+    store_u8<VEC>(a.done, i0, n, done);
+    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC>(a.sbd, i0, n, sbd);
+
+    if constexpr (EXTRAS) {
+        if (stats) { store_f32<VEC>(a.ep_ret, i0, n, ep_ret); store_i32<VEC>(a.ep_len, i0, n, ep_len); }
+        if (a.done_list) {
+            // wave64 compaction: ballot per sub-lane, one atomic per wave, order inside the list is unspecified
+            const uint32_t lane = lane_id();
+            const uint64_t below = (1ull << lane) - 1ull;
+            uint32_t off[VEC];
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint64_t m = __ballot(finished[j]);
+                off[j] = total + (uint32_t)__popcll(m & below);
+                total += (uint32_t)__popcll(m);
+            }
+            if (total) {   // wave-uniform
+                const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&a.done_count2[a.cparity], total);
+                base = __shfl(base, leader);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (finished[j]) a.done_list[base + off[j]] = (int32_t)(i0 + j);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reset: all lanes, or the lanes selected by a byte mask (the caller's `if (done) Reset()`).
+// ---------------------------------------------------------------------------------------------
+template <class Env>
+__global__ __launch_bounds__(256) void reset_kernel(const ResetArgs a) {
+    constexpr int S = Env::S, O = Env::O;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    if (i >= a.n) return;
+    if (a.mask && a.mask[i] == 0) return;
+    const uint64_t key = a.lane_seed ? a.lane_seed[i] : a.seed;
+    const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)i, tick);
+    float s[S];
+    Env::reset(s, r);
+#pragma unroll
+    for (int k = 0; k < S; ++k) a.state[k * a.state_stride + i] = s[k];
+    if constexpr (!Env::OBS_ALIASES_STATE) {
+        float o[O];
+        Env::observe(s, o);
+#pragma unroll
+        for (int k = 0; k < O; ++k) a.obs[k * a.obs_stride + i] = o[k];
+    }
+    if (a.sbd) a.sbd[i] = -1;            // CartPoleEnv.cs:64
+    if (a.done) a.done[i] = 0;
+    if (a.ep_ret) { a.ep_ret[i] = 0.0f; a.ep_len[i] = 0; }
+}
+
+template <class Env>
+__global__ __launch_bounds__(256) void observe_kernel(const float *__restrict__ state, int64_t sstride,
+                                                      float *__restrict__ obs, int64_t ostride, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s[Env::S], o[Env::O];
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k) s[k] = state[k * sstride + i];
+    Env::observe(s, o);
+#pragma unroll
+    for (int k = 0; k < Env::O; ++k) obs[k * ostride + i] = o[k];
+}
+
+// SoA [O][stride] -> row-major [n][O] (the NDArray layout at the host boundary).  Reads are coalesced per
+// component; each lane then writes its O contiguous floats, so a wave writes 64*O*4 contiguous bytes.
+template <int O>
+__global__ __launch_bounds__(256) void pack_obs_kernel(const float *__restrict__ obs, int64_t stride,
+                                                       float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) v[k] = obs[k * stride + i];
+    if constexpr (O == 4) {
+        *reinterpret_cast<float4 *>(out + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (O % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < O; k += 2) *reinterpret_cast<float2 *>(out + i * O + k) = make_float2(v[k], v[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < O; ++k) out[i * O + k] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_i32_kernel(int32_t *p, int32_t v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// Discrete.Contains(int) (Discrete.cs:38-40) over a batch: counts actions outside [0, nvals)
+__global__ __launch_bounds__(256) void validate_discrete_kernel(const int32_t *__restrict__ a, int64_t n, int32_t nvals,
+                                                                uint32_t *bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool invalid = i < n && (a[i] < 0 || a[i] >= nvals);
+    const uint64_t m = __ballot(invalid);
+    if (m && lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(bad, (uint32_t)__popcll(m));
+}
+
+// Discrete.Sample() (Discrete.cs:17-28, no mask): start + randint(0, n)
+__global__ __launch_bounds__(256) void sample_discrete_kernel(int32_t *__restrict__ out, int64_t n, int32_t nvals,
+                                                              int32_t start, uint64_t seed, uint64_t lane_offset,
+                                                              uint64_t tick) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    out[i] = start + (int32_t)__umulhi(r.w[0], (uint32_t)nvals);
+}
+
+// Box.Sample() (Box.cs:69-90): the reference's four regimes, selected by which bounds are finite
+__global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out, int64_t n, float low, float high,
+                                                         uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    const bool blo = low > -INFINITY, bhi = high < INFINITY;     // Box.CheckBounded (Box.cs:53-58)
+    const float u = u01_24(r.w[0]);
+    float v;
+    if (blo && bhi) {
+        v = low + (high - low) * u;                               // Box.cs:85 uniform(low, high)
+    } else if (blo) {
+        v = -logf(1.0f - u) + low;                                // Box.cs:83 exponential(1) + low
+    } else if (bhi) {
+        v = -logf(1.0f - u) + high;                               // Box.cs:84 exponential(1) + high (sic)
+    } else {
+        const float u1 = (float)((r.w[0] >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
+        const float u2 = u01_24(r.w[1]);
+        v = 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
+    }
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
+
+template <class Env>
+static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
+    const int block = cfg.block;
+    const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
+    const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
+#define GYMNET_LAUNCH(V, AR, EX) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX>), grid, blk, 0, st, a)
+    if (cfg.vec == 4) {
+        if (autoreset) { if (extras) GYMNET_LAUNCH(4, true, true); else GYMNET_LAUNCH(4, true, false); }
+        else           { if (extras) GYMNET_LAUNCH(4, false, true); else GYMNET_LAUNCH(4, false, false); }
+    } else {
+        if (autoreset) { if (extras) GYMNET_LAUNCH(1, true, true); else GYMNET_LAUNCH(1, true, false); }
+        else           { if (extras) GYMNET_LAUNCH(1, false, true); else GYMNET_LAUNCH(1, false, false); }
+    }
+#undef GYMNET_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
+    if (cfg.vec != 4) cfg.vec = 1;
+    if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
+    switch (env_id) {
+        case 0: return launch_step_env<CartPole>(autoreset, extras, a, cfg, st);
+        case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);
+        case 2: return launch_step_env<MountainCar>(autoreset, extras, a, cfg, st);
+        case 3: return launch_step_env<Acrobot>(autoreset, extras, a, cfg, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t st) {
+    const dim3 grid(grid_for(a.n > 0 ? a.n : 1, 256)), blk(256);
+    switch (env_id) {
+        case 0: hipLaunchKernelGGL(reset_kernel<CartPole>, grid, blk, 0, st, a); break;
+        case 1: hipLaunchKernelGGL(reset_kernel<Pendulum>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(reset_kernel<MountainCar>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(reset_kernel<Acrobot>, grid, blk, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_observe(int env_id, const float *state, int64_t sstride, float *obs, int64_t ostride, int64_t n,
+                          hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid(grid_for(n, 256)), blk(256);
+    switch (env_id) {
+        case 1: hipLaunchKernelGGL(observe_kernel<Pendulum>, grid, blk, 0, st, state, sstride, obs, ostride, n); break;
+        case 3: hipLaunchKernelGGL(observe_kernel<Acrobot>, grid, blk, 0, st, state, sstride, obs, ostride, n); break;
+        default: return hipSuccess;   // aliasing envs: nothing to recompute
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float *out, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid(grid_for(n, 256)), blk(256);
+    switch (obs_dim) {
+        case 2: hipLaunchKernelGGL(pack_obs_kernel<2>, grid, blk, 0, st, obs, stride, out, n); break;
+        case 3: hipLaunchKernelGGL(pack_obs_kernel<3>, grid, blk, 0, st, obs, stride, out, n); break;
+        case 4: hipLaunchKernelGGL(pack_obs_kernel<4>, grid, blk, 0, st, obs, stride, out, n); break;
+        case 6: hipLaunchKernelGGL(pack_obs_kernel<6>, grid, blk, 0, st, obs, stride, out, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(validate_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, a, n, nvals, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
+                                  uint64_t lane_offset, uint64_t tick, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, seed,
+                       lane_offset, tick);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,
+                             uint64_t tick, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_box_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, low, high, seed,
+                       lane_offset, tick);
+    return hipGetLastError();
+}
+
+}  // namespace gymnet

@@ -1,0 +1,60 @@
+// kernels.hpp — launch interface between the C-ABI layer (capi.hip) and the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gymnet {
+
+// Everything one vector-step launch needs.  Passed by value (kernarg segment).
+struct StepArgs {
+    float *state;            // [S][state_stride]  structure-of-arrays, one env per lane
+    float *obs;              // [O][obs_stride]    (unused when the env's observation aliases its state)
+    const void *action;      // int32[n] (Discrete) or float32[n] (Box)
+    float *reward;           // [n]
+    uint8_t *done;           // [n]
+    int32_t *sbd;            // [n] CartPole steps_beyond_done (CartPoleEnv.cs:41); NULL with auto-reset
+    uint64_t *tick2;         // device tick, double-buffered: launch with tick t reads tick2[t&1], writes tick2[(t+1)&1]=t+1
+    // extras (all NULL / 0 in the lean hot-path variant)
+    float *final_obs;        // [O][n]
+    int32_t *done_list;      // [n]
+    uint32_t *done_count2;   // [2] double-buffered: this launch fills [cparity] and zeroes [cparity^1] for the next
+    float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;
+    const uint64_t *lane_seed;       // [n] per-lane Philox keys (VecEnv.Seed(int[])) or NULL
+    unsigned long long *after_done;  // counter: steps taken on already-done lanes (CartPoleEnv.cs:176-179)
+    int64_t n, state_stride, obs_stride;
+    uint64_t lane_offset, seed;
+    int32_t parity;          // tick & 1 of this launch
+    int32_t cparity;         // (number of step launches so far) & 1: which done_count2 slot this launch fills
+    int32_t max_episode_steps;
+};
+
+struct LaunchCfg { int vec; int block; };
+
+// env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
+hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);
+
+struct ResetArgs {
+    float *state; float *obs; int32_t *sbd; uint8_t *done;   // done flags cleared for reset lanes
+    const uint8_t *mask;      // NULL = all lanes
+    uint64_t *tick2; const uint64_t *lane_seed;
+    float *ep_ret; int32_t *ep_len;
+    int64_t n, state_stride, obs_stride;
+    uint64_t lane_offset, seed;
+    int32_t parity;
+};
+hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t st);
+
+// observations: SoA [O][stride] -> row-major [n][O]
+hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float *out_rowmajor, int64_t n, hipStream_t st);
+// recompute obs from state (after set_state) for envs whose observation is derived
+hipError_t launch_observe(int env_id, const float *state, int64_t state_stride, float *obs, int64_t obs_stride,
+                          int64_t n, hipStream_t st);
+hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st);
+// counts actions outside [0, nvals) into *bad
+hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
+hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
+                                  uint64_t lane_offset, uint64_t tick, hipStream_t st);
+hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,
+                             uint64_t tick, hipStream_t st);
+
+}  // namespace gymnet

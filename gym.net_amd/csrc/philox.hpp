@@ -1,0 +1,44 @@
+// philox.hpp — Philox4x32-10 counter-based RNG (Salmon et al., SC'11), device + host.
+//
+// north_star replaces the reference's un-vendored NumSharp RNG (CartPoleEnv.cs:49,65,196-198) with a
+// stateless per-lane generator: counter = (global lane lo, hi, tick lo, hi), key = (seed lo, hi).
+// No RNG state lives in HBM; a reset costs ten rounds of 2 mul_hi + 2 mul_lo.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gymnet {
+
+struct PhiloxWords { uint32_t w[4]; };
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+__host__ __device__ __forceinline__ PhiloxWords philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                              uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    PhiloxWords o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+__host__ __device__ __forceinline__ PhiloxWords lane_words(uint64_t seed, uint64_t lane, uint64_t tick) {
+    return philox4x32_10((uint32_t)lane, (uint32_t)(lane >> 32), (uint32_t)tick, (uint32_t)(tick >> 32),
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// 24-bit uniform in [0,1): exactly representable in binary32
+__host__ __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace gymnet

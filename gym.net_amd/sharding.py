@@ -1,0 +1,143 @@
+"""Lane-block sharding of one logical batch over the GPUs of a node — one process per GPU.
+
+The reference has no distributed code at all (its `Distributed*` classes are an in-process thread
+pool, src/Gym/Internal/Threading/*); what shards here is the independence the reference's own
+vector wrapper already has: VecEnvWrapper.Step maps envs independently
+(src/Gym/Envs/VecEnvWrapper.cs:22-24), and nothing in CartPoleEnv.Step couples two instances
+(src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:137-186).
+
+  - rank r of G owns the contiguous global lanes [r*N/G, (r+1)*N/G);
+  - reset draws are keyed by the GLOBAL lane id (gymnet_config.lane_offset), so the results do not
+    depend on G (sharding invariance: concat of the shards == the one-GPU batch, bitwise);
+  - the data path needs NO collective.  The one exchange north_star names — an all-gather of the
+    observations so every rank sees [N, D] (e.g. for a replicated policy) — is optional, runs through
+    torch.distributed (backend "nccl" = RCCL over xGMI), and is zero-copy on the send side: the
+    rank's observation arrays live INSIDE the gather buffer (gymnet_config.d_ext_obs), laid out
+    rank-major [G][D][N/G] so one all-gather moves everything with no repack.
+
+torch is used here for device memory and the collective only (plumbing, not compute).
+"""
+from .vector_env import VectorEnv
+
+
+class ShardPlan:
+    """Contiguous lane blocks.  N must divide evenly when observations are gathered (equal-size blocks)."""
+
+    def __init__(self, global_num_envs, world_size):
+        if world_size < 1 or global_num_envs < world_size:
+            raise ValueError("need world_size >= 1 and at least one env per rank")
+        self.N, self.G = int(global_num_envs), int(world_size)
+
+    def offset(self, rank):
+        return self.N * rank // self.G
+
+    def count(self, rank):
+        return self.N * (rank + 1) // self.G - self.N * rank // self.G
+
+    def shard(self, rank):
+        if not 0 <= rank < self.G:
+            raise ValueError("rank out of range")
+        return self.offset(rank), self.count(rank)
+
+    @property
+    def even(self):
+        return self.N % self.G == 0
+
+    def owner(self, global_lane):
+        """(rank, local lane) of a global lane id."""
+        if not 0 <= global_lane < self.N:
+            raise ValueError("lane out of range")
+        r = min(self.G - 1, (global_lane * self.G + self.G - 1) // self.N)
+        while self.offset(r) > global_lane:
+            r -= 1
+        while self.offset(r) + self.count(r) <= global_lane:
+            r += 1
+        return r, global_lane - self.offset(r)
+
+
+def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream):
+    return VectorEnv(env, num_envs, device=device, seed=seed, auto_reset=auto_reset, lane_offset=lane_offset,
+                     ext_obs=ext_obs, ext_obs_stride=ext_obs_stride, stream=stream)
+
+
+class ShardedVectorEnv:
+    """This rank's shard of a global batch + the optional observation all-gather.
+
+    local_env_factory exists so the host-side sharding logic can be exercised without a GPU (the
+    CPU tests inject an oracle-backed stand-in); the default — and the only thing the product ever
+    uses — is the HIP VectorEnv.
+    """
+
+    def __init__(self, env, global_num_envs, rank=None, world_size=None, device=None, seed=0, auto_reset=True,
+                 gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.group = process_group
+        if world_size is None:
+            world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.plan = ShardPlan(global_num_envs, world_size)
+        self.gather_obs = bool(gather_obs) and world_size > 1
+        if gather_obs and not self.plan.even:
+            raise ValueError("global_num_envs must be a multiple of world_size to all-gather observations")
+        self.lane_offset, self.local_num_envs = self.plan.shard(self.rank)
+        factory = local_env_factory or _hip_local_env
+        if tensor_device is None:
+            tensor_device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.tensor_device = torch.device(tensor_device)
+        if device is None:
+            device = self.tensor_device.index if self.tensor_device.type == "cuda" else 0
+        from . import _capi
+        env_id = _capi.ENV_IDS[env] if isinstance(env, str) else int(env)
+        self.obs_dim = {0: 4, 1: 3, 2: 2, 3: 6}[env_id]
+        n_local = self.local_num_envs
+        # rank-major gather buffer [G][D][N/G]; this rank's observation arrays ARE slice [rank]
+        self.obs_all = torch.zeros((self.world_size, self.obs_dim, n_local), dtype=torch.float32, device=self.tensor_device)
+        stream = None
+        if self.tensor_device.type == "cuda":
+            stream = torch.cuda.current_stream(self.tensor_device).cuda_stream
+        self.local = factory(env, n_local, self.lane_offset, seed, auto_reset, self.obs_all[self.rank].data_ptr(),
+                             n_local, device, stream)
+        self._work = None
+
+    # ---- stepping -----------------------------------------------------------------------------------
+    def ResetDevice(self):
+        self.local.ResetDevice()
+
+    def StepDevice(self, d_actions):
+        """Step this rank's lanes; d_actions: this rank's slice of the global action array (device pointer/tensor)."""
+        self.local.StepDevice(d_actions)
+
+    def AllGatherObs(self, async_op=False):
+        """Everyone's observations into obs_all [G][D][N/G].  The send buffer is obs_all[rank] itself (in place)."""
+        if not self.gather_obs:
+            return None
+        dist, t = self._dist, self.obs_all
+        flat_out = t.view(-1)
+        flat_in = t[self.rank].reshape(-1)
+        try:
+            work = dist.all_gather_into_tensor(flat_out, flat_in, group=self.group, async_op=async_op)
+        except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
+            outs = [t[r].view(-1) for r in range(self.world_size)]
+            work = dist.all_gather(outs, flat_in.clone(), group=self.group, async_op=async_op)
+        self._work = work if async_op else None
+        return work
+
+    def Wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+    def GlobalObs(self):
+        """[N, D]-shaped logical view of the gathered observations as a [G, D, N/G] tensor:
+        global lane g = r * (N/G) + i  ->  obs_all[r, :, i]."""
+        return self.obs_all
+
+    def Sync(self):
+        self.local.Sync()
+
+    def Close(self):
+        self.local.Close()

@@ -1,0 +1,372 @@
+"""VectorEnv — the batched replacement for Gym.NET's VecEnv / Env hot path, over the C ABI.
+
+Mirrors (paths relative to the Gym.NET tree):
+  IVecEnv / VecEnv     src/Gym/Envs/IVecEnv.cs:8-19, src/Gym/Envs/VecEnv.cs:12-93
+  VecEnvWrapper        src/Gym/Envs/VecEnvWrapper.cs:9-30      (the sequential map this replaces)
+  IEnv / Env           src/Gym/Envs/IEnv.cs:11-22, src/Gym/Envs/Env.cs:13-41
+  CartPoleEnv          src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:43-67,137-198
+
+Same member names (Reset, Step, StepAsync, Seed, Close, ActionSpace, ObservationSpace, Metadata,
+RewardRange, NumberOfEnvironments), same argument meaning, same error behaviour.  Deviations, all
+forced by scale: results are ARRAYS — Reset() returns one ndarray [N, D] instead of
+NDArray[N], Step() returns a BatchStep whose items are the reference's Step records — and Step()
+also accepts one action PER LANE.  `Environments` is empty: 2^20 IEnv objects are never built.
+
+Everything here is a thin shim over libgymnet_amd.so: all compute happens in HIP kernels.  NDArray
+is numpy.ndarray on this side of the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .errors import AlreadySteppingError, NotSteppingError
+from .spaces import Box, Discrete
+from .step import Step
+
+
+def _ptr(x):
+    """Device pointer from an int, a ctypes pointer or anything with .data_ptr() (torch tensor)."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, C.c_void_p):
+        return x
+    return C.c_void_p(int(x))
+
+
+def _host(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class BatchStep:
+    """What `Step[]` (IVecEnv.cs:15) becomes at 2^20 lanes: three arrays.  Indexing / iterating yields the
+    reference's per-env Step records (Step.cs:7-20), materialised lazily."""
+    __slots__ = ("Observation", "Reward", "Done", "Information")
+
+    def __init__(self, observation, reward, done, information=None):
+        self.Observation, self.Reward, self.Done, self.Information = observation, reward, done, information
+
+    def __len__(self):
+        return self.Reward.shape[0]
+
+    def __getitem__(self, i):
+        return Step(self.Observation[i], float(self.Reward[i]), bool(self.Done[i]), self.Information)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def ToSteps(self):
+        return list(self)
+
+
+class PendingStep:
+    """Task<Step[]> of VecEnv.StepAsync (VecEnv.cs:63-65): Result() blocks like Task.Result."""
+
+    def __init__(self, env):
+        self._env, self._result = env, None
+
+    def Result(self):
+        if self._result is None:
+            self._result = self._env.StepWait()
+        return self._result
+
+
+class VectorEnv:
+    def __init__(self, env="CartPole-v1", num_envs=1, device=0, seed=0, auto_reset=False,
+                 validate_actions=False, done_list=False, episode_stats=False, final_obs=False,
+                 lane_offset=0, stream=None, ext_obs=None, ext_obs_stride=0, max_episode_steps=0):
+        env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
+        self._lib = capi.load_library()
+        self._info = capi.env_describe(env_id)
+        flags = ((capi.FLAG_AUTORESET if auto_reset else 0) | (capi.FLAG_VALIDATE_ACTIONS if validate_actions else 0)
+                 | (capi.FLAG_DONE_LIST if done_list else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0)
+                 | (capi.FLAG_FINAL_OBS if final_obs else 0))
+        cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=env_id, num_envs=int(num_envs),
+                          lane_offset=int(lane_offset), device=int(device), flags=flags,
+                          seed=int(seed) & 0xFFFFFFFFFFFFFFFF, stream=_ptr(stream), d_ext_obs=_ptr(ext_obs),
+                          ext_obs_stride=int(ext_obs_stride), max_episode_steps=int(max_episode_steps), reserved=0)
+        self._h = C.c_void_p()
+        capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
+        i = self._info
+        self.EnvId = env_id
+        self.Name = i.name.decode()
+        self.NumberOfEnvironments = int(num_envs)                                   # VecEnv.cs:14,24
+        self.StateDim, self.ObsDim = int(i.state_dim), int(i.obs_dim)
+        self.AutoReset = bool(auto_reset)
+        # spaces exactly as the env ctor builds them (CartPoleEnv.cs:46-48)
+        if i.action_is_box:
+            self.ActionSpace = Box(np.array([i.action_low], np.float32), np.array([i.action_high], np.float32), dtype=np.float32)
+            self._adtype = np.float32
+        else:
+            self.ActionSpace = Discrete(int(i.action_n))
+            self._adtype = np.int32
+        self.ObservationSpace = Box(np.array(i.obs_low[:self.ObsDim], np.float32), np.array(i.obs_high[:self.ObsDim], np.float32), dtype=np.float32)
+        self.Metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 50}   # CartPoleEnv.cs:51
+        self.RewardRange = (float(i.reward_low), float(i.reward_high))
+        self.Environments = []          # VecEnv.cs:17 — deliberately empty, see module docstring
+        self.AlgorithmicBytesPerStep = int(i.algorithmic_bytes_per_step)
+
+    # ---- lifecycle ------------------------------------------------------------------------------
+    def Close(self):                                                                 # VecEnvWrapper.cs:26-30
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.gymnet_vecenv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    Dispose = Close                                                                  # Env.cs:38-40
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.Close()
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+    def Seed(self, seed):                                                            # VecEnv.cs:44-53
+        if isinstance(seed, (int, np.integer)):
+            capi.check(self._lib.gymnet_vecenv_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+        else:
+            s = np.ascontiguousarray(np.asarray(seed, dtype=np.int64).astype(np.uint64))
+            capi.check(self._lib.gymnet_vecenv_seed_lanes(self._h, _host(s), s.shape[0]))
+
+    # ---- host-boundary path ---------------------------------------------------------------------
+    def _outs(self):
+        n = self.NumberOfEnvironments
+        return (np.empty((n, self.ObsDim), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8))
+
+    def Reset(self):                                                                 # VecEnvWrapper.cs:18-20
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        capi.check(self._lib.gymnet_vecenv_reset(self._h, _host(obs)))
+        return obs
+
+    def ResetWhere(self, mask=None):
+        """Batched `if (done) Reset()` (README.md:36-40). mask None = lanes whose last Done flag is set."""
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if m is not None and m.shape[0] != self.NumberOfEnvironments:
+            raise ValueError("mask length must equal NumberOfEnvironments")
+        capi.check(self._lib.gymnet_vecenv_reset_where(self._h, None if m is None else _host(m), _host(obs)))
+        return obs
+
+    def _actions(self, action):
+        a = np.ascontiguousarray(np.asarray(action).reshape(-1).astype(self._adtype, copy=False))
+        if a.shape[0] != self.NumberOfEnvironments:
+            raise ValueError("Number of actions passed should be equals to number of environments")
+        return a
+
+    def Step(self, action):
+        """IVecEnv.Step(int action) (IVecEnv.cs:15, VecEnvWrapper.cs:22-24) broadcasts ONE scalar action;
+        an array-like gives one action per lane (extension)."""
+        obs, rew, done = self._outs()
+        if isinstance(action, (int, np.integer)) and not isinstance(action, (bool, np.bool_)):
+            capi.check(self._lib.gymnet_vecenv_step_broadcast(self._h, int(action), _host(obs), _host(rew), _host(done)))
+        else:
+            a = self._actions(action)
+            capi.check(self._lib.gymnet_vecenv_step(self._h, _host(a), _host(obs), _host(rew), _host(done)))
+        return BatchStep(obs, rew, done.astype(bool), None)
+
+    def StepAsync(self, action):                                                     # VecEnv.cs:63-65
+        if isinstance(action, (int, np.integer)):
+            action = np.full(self.NumberOfEnvironments, action, dtype=self._adtype)
+        a = self._actions(action)
+        capi.check(self._lib.gymnet_vecenv_step_async(self._h, _host(a)))
+        return PendingStep(self)
+
+    def StepWait(self):
+        obs, rew, done = self._outs()
+        capi.check(self._lib.gymnet_vecenv_step_wait(self._h, _host(obs), _host(rew), _host(done)))
+        return BatchStep(obs, rew, done.astype(bool), None)
+
+    def Read(self):
+        obs, rew, done = self._outs()
+        capi.check(self._lib.gymnet_vecenv_read(self._h, _host(obs), _host(rew), _host(done)))
+        return BatchStep(obs, rew, done.astype(bool), None)
+
+    def SampleActions(self, seed=0, tick=0):
+        """ActionSpace.Sample() for every lane, on the device (TrainingPlaySession.cs:46-49 batched)."""
+        a = np.empty(self.NumberOfEnvironments, self._adtype)
+        capi.check(self._lib.gymnet_vecenv_sample_actions(self._h, _host(a), int(seed), int(tick)))
+        return a
+
+    # ---- device-resident path (device pointers: ints, ctypes pointers or torch tensors) -------------
+    def ResetDevice(self):
+        capi.check(self._lib.gymnet_vecenv_reset_device(self._h))
+
+    def ResetWhereDevice(self, d_mask=None):
+        capi.check(self._lib.gymnet_vecenv_reset_where_device(self._h, _ptr(d_mask)))
+
+    def StepDevice(self, d_actions):
+        capi.check(self._lib.gymnet_vecenv_step_device(self._h, _ptr(d_actions)))
+
+    def RolloutDevice(self, d_actions, steps, action_stride, ring):
+        capi.check(self._lib.gymnet_vecenv_rollout_device(self._h, _ptr(d_actions), int(steps), int(action_stride), int(ring)))
+
+    def SampleActionsDevice(self, d_actions, seed=0, tick=0):
+        capi.check(self._lib.gymnet_vecenv_sample_actions_device(self._h, _ptr(d_actions), int(seed), int(tick)))
+
+    def PackObsDevice(self, d_obs_rowmajor):
+        capi.check(self._lib.gymnet_vecenv_pack_obs_device(self._h, _ptr(d_obs_rowmajor)))
+
+    def Sync(self):
+        capi.check(self._lib.gymnet_vecenv_sync(self._h))
+
+    def DeviceView(self):
+        v = capi.DeviceView()
+        capi.check(self._lib.gymnet_vecenv_device_view(self._h, C.byref(v)))
+        return v
+
+    # ---- state access / bookkeeping -----------------------------------------------------------------
+    def GetState(self):
+        s = np.empty((self.StateDim, self.NumberOfEnvironments), np.float32)
+        capi.check(self._lib.gymnet_vecenv_get_state(self._h, _host(s)))
+        return s
+
+    def SetState(self, state_soa):
+        s = np.ascontiguousarray(np.asarray(state_soa, dtype=np.float32))
+        if s.shape != (self.StateDim, self.NumberOfEnvironments):
+            raise ValueError(f"state must have shape ({self.StateDim}, {self.NumberOfEnvironments})")
+        capi.check(self._lib.gymnet_vecenv_set_state(self._h, _host(s)))
+
+    def GetStepsBeyondDone(self):
+        b = np.empty(self.NumberOfEnvironments, np.int32)
+        capi.check(self._lib.gymnet_vecenv_get_steps_beyond_done(self._h, _host(b)))
+        return b
+
+    def SetStepsBeyondDone(self, sbd):
+        b = np.ascontiguousarray(np.asarray(sbd, dtype=np.int32))
+        if b.shape[0] != self.NumberOfEnvironments:
+            raise ValueError("length must equal NumberOfEnvironments")
+        capi.check(self._lib.gymnet_vecenv_set_steps_beyond_done(self._h, _host(b)))
+
+    @property
+    def Tick(self):
+        t = C.c_uint64()
+        capi.check(self._lib.gymnet_vecenv_get_tick(self._h, C.byref(t)))
+        return t.value
+
+    @Tick.setter
+    def Tick(self, value):
+        capi.check(self._lib.gymnet_vecenv_set_tick(self._h, int(value)))
+
+    def Counters(self):
+        c = capi.Counters()
+        capi.check(self._lib.gymnet_vecenv_counters(self._h, C.byref(c)))
+        return {"tick": c.tick, "lane_steps": c.lane_steps, "stepped_after_done": c.stepped_after_done,
+                "last_done_count": c.last_done_count}
+
+    def DoneLanes(self):
+        n = self.NumberOfEnvironments
+        lanes = np.empty(n, np.int32)
+        cnt = C.c_int64()
+        capi.check(self._lib.gymnet_vecenv_done_lanes(self._h, _host(lanes), n, C.byref(cnt)))
+        return lanes[:cnt.value].copy()
+
+    def EpisodeStats(self):
+        n = self.NumberOfEnvironments
+        ret, ln = np.empty(n, np.float32), np.empty(n, np.int32)
+        capi.check(self._lib.gymnet_vecenv_episode_stats(self._h, _host(ret), _host(ln)))
+        return ret, ln
+
+    def FinalObs(self):
+        o = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        capi.check(self._lib.gymnet_vecenv_final_obs(self._h, _host(o)))
+        return o
+
+    # VecEnv.get_attr / set_attr (VecEnv.cs:74-92) select over IEnv objects; here the per-lane
+    # attributes that exist are exposed by name.
+    def get_attr(self, name):
+        if name is None:
+            raise ValueError("selector")                       # ArgumentNullException
+        if name == "state":
+            return self.GetState().T.copy()
+        if name == "steps_beyond_done":
+            return self.GetStepsBeyondDone()
+        raise AttributeError(name)
+
+    def set_attr(self, name, value):
+        if value is None:
+            raise ValueError("object")                         # ArgumentNullException, VecEnv.cs:88
+        if name == "state":
+            return self.SetState(np.asarray(value, np.float32).T)
+        if name == "steps_beyond_done":
+            return self.SetStepsBeyondDone(value)
+        raise AttributeError(name)
+
+    # python-style aliases
+    reset, step, seed, close = Reset, Step, Seed, Close
+
+
+class GpuEnv:
+    """Single-instance `Env` façade (Env.cs:13-41) over a 1-lane VectorEnv: Reset() -> NDArray[D],
+    Step(object action) -> Step.  Exists so an existing per-instance loop (README.md:32-52,
+    tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35) runs unmodified on the engine."""
+    ENV = "CartPole-v1"
+
+    def __init__(self, device=0, seed=0, validate_actions=False):
+        self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions)
+        self.ActionSpace, self.ObservationSpace = self._v.ActionSpace, self._v.ObservationSpace
+        self.Metadata, self.RewardRange = self._v.Metadata, self._v.RewardRange
+        self._pending = None
+
+    def Reset(self):                                                                 # CartPoleEnv.cs:63-67
+        return self._v.Reset()[0]
+
+    def Step(self, action):                                                          # CartPoleEnv.cs:137-186
+        if isinstance(action, (bool, np.bool_)) or not isinstance(action, (int, np.integer)):
+            if isinstance(self.ActionSpace, Discrete):
+                raise TypeError(f"Specified cast is not valid: {type(action).__name__} -> int")   # InvalidCastException, :138
+        a = np.array([action], dtype=self._v._adtype)
+        return self._v.Step(a)[0]
+
+    def StepAsync(self, action):                                                     # Env.cs:23-25
+        a = np.array([action], dtype=self._v._adtype)
+        p = self._v.StepAsync(a)
+
+        class _One:
+            def Result(_self):
+                return p.Result()[0]
+        return _One()
+
+    def Render(self, mode="human"):
+        return None            # rendering is out of scope for the engine (NullEnvViewer semantics)
+
+    def CloseEnvironment(self):                                                      # CartPoleEnv.cs:189-194
+        self._v.Close()
+
+    Close = Dispose = CloseEnvironment
+
+    def Seed(self, seed):                                                            # CartPoleEnv.cs:196-198
+        self._v.Seed(int(seed))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.CloseEnvironment()
+
+
+class CartPoleEnv(GpuEnv):
+    ENV = "CartPole-v1"
+
+
+class PendulumEnv(GpuEnv):
+    ENV = "Pendulum-v1"
+
+
+class MountainCarEnv(GpuEnv):
+    ENV = "MountainCar-v0"
+
+
+class AcrobotEnv(GpuEnv):
+    ENV = "Acrobot-v1"
+
+
+__all__ = ["VectorEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
+           "AcrobotEnv", "AlreadySteppingError", "NotSteppingError"]

@@ -1,0 +1,233 @@
+/*
+ * gymnet_amd.h — C ABI of the MI355X-native batched classic-control environment engine.
+ *
+ * This is the drop-in boundary for ONE path of SciSharp/Gym.NET: the per-instance
+ * Env.Step()/Reset() hot path of the classic-control environments, replaced by one HIP kernel
+ * launch over a structure-of-arrays batch held in HBM (one environment instance per GPU lane).
+ * Plain C types only: no torch types, no C++ types, no callbacks.  A C# host binds it with
+ * [DllImport("gymnet_amd")]; a C++ or ctypes host binds it the same way.
+ *
+ * Every entry point cites the reference interface it replaces, as path:line relative to the
+ * Gym.NET source tree (/root/reference in the build container):
+ *   IEnv / Env            src/Gym/Envs/IEnv.cs:11-22, src/Gym/Envs/Env.cs:13-41
+ *   IVecEnv / VecEnv      src/Gym/Envs/IVecEnv.cs:8-19, src/Gym/Envs/VecEnv.cs:12-93
+ *   VecEnvWrapper         src/Gym/Envs/VecEnvWrapper.cs:9-30
+ *   CartPoleEnv           src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:24-67,137-198
+ *   Space/Box/Discrete    src/Gym/Spaces/{Space.cs:5-18,Box.cs:25-96,Discrete.cs:11-44}
+ *   Step                  src/Gym/Observations/Step.cs:7-20
+ *   errors                src/Gym/Exceptions/{InvalidActionError,AlreadySteppingError,NotSteppingError}.cs
+ *
+ * Conventions
+ *   - Every function returns a gymnet_status (0 = ok, negative = error) unless documented
+ *     otherwise; nothing throws or aborts across the ABI.  The message for the most recent
+ *     failure on the calling thread is gymnet_last_error().
+ *   - "host" pointers are ordinary CPU memory owned by the caller; "device" pointers (names
+ *     starting with d_) are HIP device memory on the handle's device.  The library never keeps a
+ *     caller pointer after the call returns, except: gymnet_vecenv_step_async keeps `actions`
+ *     until it returns (it copies), and *_device calls use d_ pointers until the work queued on
+ *     the handle's stream has run (gymnet_vecenv_sync).
+ *   - Layouts.  Inside the engine everything is structure-of-arrays: state[state_dim][stride],
+ *     obs[obs_dim][stride], reward[n], done[n].  At the HOST boundary observations are
+ *     row-major [num_envs, obs_dim] float32 (what an NDArray of shape (N, D) holds), reward is
+ *     float32[num_envs], done is uint8[num_envs] (0 / 1).
+ *   - Dtypes: Discrete action int32; Box action float32; observation float32 (the DECLARED dtype
+ *     of CartPoleEnv.ObservationSpace, CartPoleEnv.cs:48); reward float32 (Step.cs:9); done uint8.
+ *   - A handle is single-caller-at-a-time (like an Env instance, which has no re-entrancy guard);
+ *     different handles may be used from different threads.  All work of a handle is ordered on
+ *     one HIP stream.
+ */
+#ifndef GYMNET_AMD_H
+#define GYMNET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYMNET_ABI_VERSION 1
+
+typedef enum gymnet_status {
+    GYMNET_OK = 0,
+    GYMNET_ERR_INVALID_ARG = -1,     /* ArgumentException / ArgumentNullException (VecEnv.cs:49, CartPoleEnv.cs:57) */
+    GYMNET_ERR_INVALID_ACTION = -2,  /* InvalidActionError (src/Gym/Exceptions/InvalidActionError.cs:7-10) */
+    GYMNET_ERR_HIP = -3,             /* a HIP runtime call failed */
+    GYMNET_ERR_OOM = -4,             /* device or host allocation failed */
+    GYMNET_ERR_NO_DEVICE = -5,       /* no usable AMD GPU: the engine has NO CPU fallback */
+    GYMNET_ERR_ALREADY_STEPPING = -6,/* AlreadySteppingError (src/Gym/Exceptions/AlreadySteppingError.cs:8-10) */
+    GYMNET_ERR_NOT_STEPPING = -7,    /* NotSteppingError (src/Gym/Exceptions/NotSteppingError.cs:4-6) */
+    GYMNET_ERR_UNSUPPORTED = -8
+} gymnet_status;
+
+typedef enum gymnet_env_id {
+    GYMNET_ENV_CARTPOLE = 0,     /* CartPoleEnv.cs (the only classic env present in the reference) */
+    GYMNET_ENV_PENDULUM = 1,     /* absent from the reference (README.md:69-76); upstream gym Pendulum-v1 */
+    GYMNET_ENV_MOUNTAINCAR = 2,  /* absent from the reference; upstream gym MountainCar-v0 */
+    GYMNET_ENV_ACROBOT = 3       /* absent from the reference; upstream gym Acrobot-v1 */
+} gymnet_env_id;
+
+/* gymnet_config.flags */
+#define GYMNET_FLAG_AUTORESET        0x01u /* fuse the caller's `if (done) Reset()` (README.md:36-40) into the step kernel */
+#define GYMNET_FLAG_VALIDATE_ACTIONS 0x02u /* reject actions outside Discrete(n) (Discrete.cs:38-40) before stepping, like
+                                              LunarLanderEnv.cs:604-607; default mirrors Release-build CartPole (CartPoleEnv.cs:139,146) */
+#define GYMNET_FLAG_DONE_LIST        0x04u /* emit the compacted list of lanes that finished in the last step */
+#define GYMNET_FLAG_EPISODE_STATS    0x08u /* per-lane episode return / length bookkeeping (BasePlaySession.cs:58-69) */
+#define GYMNET_FLAG_FINAL_OBS        0x10u /* with AUTORESET: keep the terminal observation of lanes that finished */
+
+typedef struct gymnet_vecenv gymnet_vecenv;   /* opaque handle: one batch ("VectorEnv") on one GPU */
+
+typedef struct gymnet_config {
+    uint32_t struct_size;       /* = sizeof(gymnet_config) */
+    int32_t  env_id;            /* gymnet_env_id */
+    int64_t  num_envs;          /* lanes owned by this handle (this rank's shard) — VecEnv.NumberOfEnvironments */
+    int64_t  lane_offset;       /* global id of this handle's lane 0; reset draws are keyed by GLOBAL lane id, so a
+                                   batch sharded over G handles/GPUs gives the same results as one handle */
+    int32_t  device;            /* HIP device ordinal */
+    uint32_t flags;             /* GYMNET_FLAG_* */
+    uint64_t seed;              /* Env.Seed(int) (CartPoleEnv.cs:196-198): Philox key */
+    void    *stream;            /* hipStream_t to order all work on; NULL = the library creates its own */
+    float   *d_ext_obs;         /* optional device buffer [obs_dim][ext_obs_stride] to keep observations in (e.g. this
+                                   rank's slice of an all-gather buffer); for envs whose observation IS the state
+                                   (CartPole, MountainCar) it becomes the live state storage.  NULL = library allocates */
+    int64_t  ext_obs_stride;    /* elements between component arrays of d_ext_obs (>= num_envs) */
+    int32_t  max_episode_steps; /* EXTENSION (the reference has no time limit): >0 truncates episodes;
+                                   requires GYMNET_FLAG_EPISODE_STATS; done byte gets bit 1 (value 2) for truncation */
+    int32_t  reserved;
+} gymnet_config;
+
+typedef struct gymnet_env_info {
+    uint32_t struct_size;
+    int32_t  env_id;
+    char     name[32];               /* "CartPole-v1", ... */
+    int32_t  state_dim;
+    int32_t  obs_dim;
+    int32_t  obs_aliases_state;      /* 1: the observation arrays ARE the state arrays */
+    int32_t  action_is_box;          /* 0: Discrete(action_n) int32; 1: Box(action_low, action_high, (1,)) float32 */
+    int32_t  action_n;
+    float    action_low, action_high;
+    float    obs_low[8], obs_high[8];/* ObservationSpace bounds (CartPoleEnv.cs:46-48) */
+    float    reward_low, reward_high;
+    int32_t  algorithmic_bytes_per_step; /* bytes one env-step must move (CartPole: 41) */
+} gymnet_env_info;
+
+/* Device-side view of a handle: zero-copy access for a GPU-resident policy / trainer. */
+typedef struct gymnet_device_view {
+    uint32_t struct_size;
+    int32_t  state_dim, obs_dim, obs_aliases_state;
+    int64_t  num_envs, state_stride, obs_stride;
+    float   *d_state;          /* [state_dim][state_stride] */
+    float   *d_obs;            /* [obs_dim][obs_stride] (== d_state when obs_aliases_state) */
+    float   *d_reward;         /* [num_envs] */
+    uint8_t *d_done;           /* [num_envs] */
+    int32_t *d_steps_beyond_done; /* CartPole without AUTORESET: CartPoleEnv.cs:41 per lane; else NULL */
+    float   *d_final_obs;      /* [obs_dim][num_envs], FINAL_OBS only */
+    int32_t *d_done_list;      /* [num_envs], DONE_LIST only */
+    float   *d_episode_return; int32_t *d_episode_length;     /* running, EPISODE_STATS only */
+    float   *d_finished_return; int32_t *d_finished_length;   /* last finished episode per lane */
+    void    *stream;           /* hipStream_t all of the handle's work is ordered on */
+} gymnet_device_view;
+
+typedef struct gymnet_counters {
+    uint32_t struct_size;
+    uint32_t reserved;
+    uint64_t tick;               /* engine tick: number of step/reset launches since seed (Philox counter word) */
+    uint64_t lane_steps;         /* total env-steps executed */
+    uint64_t stepped_after_done; /* lane-steps taken on an already-done lane: the reference's console warning
+                                    (CartPoleEnv.cs:176-179), counted instead of printed */
+    int64_t  last_done_count;    /* lanes that finished in the last step (DONE_LIST), else -1 */
+} gymnet_counters;
+
+/* ---- library-level ------------------------------------------------------------------------ */
+int         gymnet_abi_version(void);
+const char *gymnet_status_string(int status);
+const char *gymnet_last_error(void);                 /* thread-local message of the last failure */
+int         gymnet_device_count(int *count);         /* GYMNET_ERR_NO_DEVICE (count = 0) without a GPU */
+/* Space descriptors an env's ctor builds (CartPoleEnv.cs:43-52): ActionSpace, ObservationSpace bounds. */
+int         gymnet_env_describe(int env_id, gymnet_env_info *out);
+
+/* ---- lifecycle: new VecEnv(...) / Close() / Dispose() ------------------------------------- */
+/* VecEnv ctor (VecEnv.cs:13-18) + N x CartPoleEnv ctor (CartPoleEnv.cs:43-52).  State is undefined until reset. */
+int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out);
+/* VecEnv.Close() (VecEnvWrapper.cs:26-30) / Env.Dispose() (Env.cs:38-40). */
+int gymnet_vecenv_destroy(gymnet_vecenv *h);
+/* VecEnv.Seed(int) (VecEnv.cs:44-46) -> Env.Seed (CartPoleEnv.cs:196-198).  DEVIATION: the reference hands every
+ * env the SAME seed (identical reset streams); here lane i draws from Philox(key = seed, counter = (global lane, tick)).
+ * Also rewinds the engine tick to 0. */
+int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed);
+/* VecEnv.Seed(int[]) (VecEnv.cs:48-53): one seed per lane; count != num_envs -> GYMNET_ERR_INVALID_ARG
+ * (the reference throws ArgumentException).  Lane i then draws from Philox(key = seeds[i], ...). */
+int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t count);
+
+/* ---- host-boundary path (what an NDArray-based caller uses) --------------------------------- */
+/* VecEnv.Reset() (VecEnvWrapper.cs:18-20) -> N x CartPoleEnv.Reset() (CartPoleEnv.cs:63-67): steps_beyond_done = -1,
+ * state ~ U(-0.05,0.05)^4.  obs_out: host [num_envs, obs_dim] or NULL. */
+int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out);
+/* The caller's `if (done) Reset()` (README.md:36-40), batched: resets exactly the lanes with mask[i] != 0;
+ * mask == NULL resets the lanes whose last returned done flag is set.  obs_out as above (all lanes). */
+int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out);
+/* EXTENSION of IVecEnv.Step (per-lane actions): N x CartPoleEnv.Step (CartPoleEnv.cs:137-186).
+ * actions: host int32[num_envs] (Discrete) or float32[num_envs] (Box).  Outputs may each be NULL.  Blocks until
+ * the outputs are written. */
+int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out);
+/* IVecEnv.Step(int action) (IVecEnv.cs:15, VecEnvWrapper.cs:22-24): ONE scalar action broadcast to all lanes. */
+int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_out, float *reward_out, uint8_t *done_out);
+/* VecEnv.StepAsync (VecEnv.cs:63-65) / Env.StepAsync (Env.cs:23-25): queue the step, return immediately.
+ * A second call before gymnet_vecenv_step_wait -> GYMNET_ERR_ALREADY_STEPPING. */
+int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions);
+/* step_wait(): block until the queued step finished and copy its results out.  Without a pending
+ * gymnet_vecenv_step_async -> GYMNET_ERR_NOT_STEPPING. */
+int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
+/* Copy the results of the most recent step/reset again (Step record, Step.cs:8-10). */
+int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
+
+/* ---- device-resident path (no PCIe on the hot path; everything stream-ordered, non-blocking) -- */
+int gymnet_vecenv_reset_device(gymnet_vecenv *h);
+int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask);   /* NULL = own done flags */
+/* One vector step = ONE kernel launch.  d_actions: device int32[num_envs] / float32[num_envs]. */
+int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions);
+/* `steps` consecutive vector steps, one kernel launch each, replayed from a cached hipGraph: step t reads
+ * d_actions + (t % ring) * action_stride elements.  (The caller's hot loop, README.md:34-47, without host hops.) */
+int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_t steps,
+                                 int64_t action_stride, int64_t ring);
+/* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout). */
+int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
+int gymnet_vecenv_sync(gymnet_vecenv *h);
+int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
+
+/* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
+/* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */
+int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa);
+int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa);
+/* steps_beyond_done per lane (CartPoleEnv.cs:41); only for CartPole without AUTORESET, else GYMNET_ERR_UNSUPPORTED. */
+int gymnet_vecenv_get_steps_beyond_done(gymnet_vecenv *h, int32_t *out);
+int gymnet_vecenv_set_steps_beyond_done(gymnet_vecenv *h, const int32_t *in);
+int gymnet_vecenv_get_tick(gymnet_vecenv *h, uint64_t *tick);
+int gymnet_vecenv_set_tick(gymnet_vecenv *h, uint64_t tick);
+int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out);
+
+/* ---- episode bookkeeping (the step AFTER the path: BasePlaySession.cs:58-69) ------------------ */
+/* Lanes that finished in the most recent step (unordered). Needs GYMNET_FLAG_DONE_LIST. */
+int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capacity, int64_t *count);
+/* Last finished episode's return and length per lane (0 length = none finished yet). Needs EPISODE_STATS. */
+int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length);
+/* Terminal observations, host [num_envs, obs_dim]; rows of lanes that never finished are 0. Needs FINAL_OBS. */
+int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out);
+
+/* ---- batched space sampling (the step BEFORE the path: ActionSpace.Sample(), TrainingPlaySession.cs:46-49) -- */
+/* Discrete.Sample() without mask (Discrete.cs:17-28): start + randint(0, n).  Element i = start + hi32(w0 * n),
+ * w0 = word 0 of Philox(key = seed, counter = (lane_offset + i, tick)). */
+int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
+                                  uint64_t seed, uint64_t lane_offset, uint64_t tick);
+/* Box.Sample() (Box.cs:69-90), the reference's four regimes per element: bounded -> uniform(low, high);
+ * low only -> low + Exp(1); high only -> high + Exp(1) (sic, Box.cs:84); unbounded -> Normal(0.5, 1) (sic, Box.cs:82).
+ * low = -INFINITY / high = +INFINITY select the regime. */
+int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t count, float low, float high,
+                             uint64_t seed, uint64_t lane_offset, uint64_t tick);
+/* ActionSpace.Sample() for every lane of a handle into d_actions (int32 / float32 [num_envs]). */
+int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick);
+int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMNET_AMD_H */

@@ -1,0 +1,375 @@
+"""GPU parity tests for the CartPole hot path — every call goes through the C ABI (ctypes ->
+libgymnet_amd.so -> HIP kernels) and is checked against the oracle / the committed golden vectors.
+
+Bars (north_star): done flags, rewards, step counts bit-exact; float32 state within 1e-5 abs of the
+float64 restatement per teacher-forced step.  Shapes of the loops follow the reference's own test
+(tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35) and README example (README.md:32-52).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # north_star: 1e-5 abs on float32 state
+SEED = 0x5EED
+
+
+def _states(rng, n, wide=False):
+    k = 1.15 if wide else 1.0
+    return np.stack([rng.uniform(-2.4 * k, 2.4 * k, n), rng.uniform(-2.5, 2.5, n),
+                     rng.uniform(-0.2095 * k, 0.2095 * k, n), rng.uniform(-3, 3, n)]).astype(np.float32)
+
+
+def _near_threshold(ns64, margin=2e-6):
+    """lanes whose float64 next state sits within `margin` of a termination threshold: the only place
+    where a float32 kernel may legitimately disagree with the float64 reference on `done`."""
+    xt, tt = np.float32(2.4).astype(np.float64), np.float32(0.20943951606750488).astype(np.float64)
+    return (np.abs(np.abs(ns64[0]) - xt) < margin) | (np.abs(np.abs(ns64[2]) - tt) < margin)
+
+
+def test_teacher_forced_golden(gpu_pkg, golden):
+    g = golden("cartpole_teacher_forced")
+    n = g["state"].shape[1]
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env:
+        env.Reset()
+        env.SetState(g["state"])
+        out = env.Step(g["action"])
+        got = env.GetState().astype(np.float64)
+    want = g["next_state"]
+    err = np.abs(got - want)
+    assert err[:, :3072].max() <= TOL                                   # in-range block: absolute bar
+    assert (err / np.maximum(1.0, np.abs(want))).max() <= TOL           # wide block: values up to ~1e2
+    near = _near_threshold(want)
+    assert near.sum() == 0                                              # fixture has no ambiguous lane
+    assert np.array_equal(out.Done, g["done"].astype(bool))
+    assert np.array_equal(out.Reward, g["reward"])
+    assert np.array_equal(out.Observation, got.T.astype(np.float32))    # observation IS the new state (CartPoleEnv.cs:166,185)
+    assert out.Observation.dtype == np.float32
+
+
+def test_threshold_edges_bit_exact(gpu_pkg, golden):
+    g = golden("cartpole_edges")
+    n = g["state"].shape[1]
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env:
+        env.Reset()
+        env.SetState(g["state"])
+        out = env.Step(g["action"])
+        got = env.GetState()
+    assert np.array_equal(out.Done, g["done"].astype(bool))              # strict < / > on float32 thresholds
+    fin = np.isfinite(g["next_state"]).all(axis=0)
+    assert np.abs(got[:, fin].astype(np.float64) - g["next_state"][:, fin]).max() <= TOL
+    assert np.isnan(got[:, ~fin]).any(axis=0).all() or np.isinf(got[:, ~fin]).any(axis=0).all()
+
+
+def test_steps_beyond_done_reward_stream(gpu_pkg, golden):
+    # reward 1,...,1,1(done),0,0,... and a counted (not printed) step-after-done warning (CartPoleEnv.cs:168-183)
+    g = golden("cartpole_steps_beyond_done")
+    with gpu_pkg.VectorEnv("CartPole-v1", 1, seed=SEED) as env:
+        env.Reset()
+        env.SetState(g["start"].reshape(4, 1))
+        for t in range(g["reward"].shape[0]):
+            out = env.Step(1)                                            # IVecEnv.Step(int): scalar broadcast
+            assert out.Reward[0] == g["reward"][t] and bool(out.Done[0]) == bool(g["done"][t])
+            assert env.GetStepsBeyondDone()[0] == g["sbd"][t]
+            assert np.abs(env.GetState()[:, 0].astype(np.float64) - g["states"][t]).max() <= 1e-4   # free-running
+        after = int(g["done"].sum()) - 1
+        assert env.Counters()["stepped_after_done"] == after
+
+
+def test_reference_test_loop_shape(gpu_pkg, golden):
+    """1000 x (Reset-if-done else Step(i % 2)) — CartpoleEnvironment.cs:19-27 — on the single-instance Env
+    façade, with the reset states taken from the recorded list so that RNG is factored out."""
+    g = golden("cartpole_reference_test_trace")
+    cp = gpu_pkg.CartPoleEnv(seed=SEED)
+    try:
+        done, k, lens, cur = True, 0, [], 0
+        for i in range(1000):
+            if done:
+                cp.Reset()
+                cp._v.SetState(g["resets"][k].reshape(4, 1)); k += 1
+                done = False
+                if cur:
+                    lens.append(cur)
+                cur = 0
+            else:
+                observation, reward, _done, information = cp.Step(i % 2)      # Step.Deconstruct
+                done = _done; cur += 1
+                assert reward == 1.0 and information is None
+                assert np.abs(observation.astype(np.float64) - g["it_state"][i]).max() <= 1e-4   # free-running episode
+            assert int(done) == g["it_done"][i], i                             # integer: exact
+        assert k == int(g["resets_used"]) and lens == list(g["episode_lengths"])  # episode step counts exact
+    finally:
+        cp.CloseEnvironment()
+
+
+def test_teacher_forced_random_rollout_vs_oracle(gpu_pkg, oracle):
+    """Teacher-forced single steps along a real rollout (the SURVEY F9 protocol): each step starts from the
+    engine's own float32 state, the float64 restatement is applied to that same state."""
+    n, steps = 1 << 16, 40
+    rng = np.random.default_rng(5)
+    worst, mism, ambiguous, dones = 0.0, 0, 0, 0
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env:
+        env.Reset()
+        for t in range(steps):
+            s = env.GetState()
+            a = rng.integers(0, 2, n).astype(np.int32)
+            out = env.Step(a)
+            want_s, want_r, want_d, _ = oracle.cartpole_step(s.astype(np.float64), a)
+            got = env.GetState().astype(np.float64)
+            worst = max(worst, np.abs(got - want_s).max())
+            near = _near_threshold(want_s, 1e-6)
+            bad = out.Done != want_d.astype(bool)
+            mism += int((bad & ~near).sum()); ambiguous += int(near.sum()); dones += int(want_d.sum())
+            env.ResetWhere()                                                    # the caller's `if (done) Reset()`
+    assert worst <= TOL and worst < 2e-6
+    assert mism == 0 and ambiguous <= 2 and dones > n                            # ~4.5 % of lanes finish per step
+
+
+def test_fused_autoreset_matches_oracle_philox(gpu_pkg, oracle):
+    n, steps, off = 50_000, 25, 123_456_789_000                                  # lane ids above 2^32 too
+    rng = np.random.default_rng(6)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=off) as env:
+        first = env.Reset()
+        assert np.array_equal(first.T, oracle.cartpole_reset(SEED, off, 0, n))   # bit-exact Philox reset
+        assert first.min() >= -0.05 and first.max() < 0.05                      # U(-0.05, 0.05), CartPoleEnv.cs:65
+        total = 0
+        for t in range(steps):
+            s = env.GetState()
+            tick = env.Tick
+            a = rng.integers(0, 2, n).astype(np.int32)
+            out = env.Step(a)
+            want_s, _, want_d, _ = oracle.cartpole_step(s.astype(np.float64), a)
+            d = want_d.astype(bool)
+            got = env.GetState()
+            assert np.array_equal(out.Done, d)
+            assert np.all(out.Reward == 1.0)                                    # sbd is always -1 at entry
+            assert np.abs(got[:, ~d].astype(np.float64) - want_s[:, ~d]).max() <= TOL
+            fresh = oracle.cartpole_reset(SEED, off, tick, n)
+            assert np.array_equal(got[:, d], fresh[:, d])                       # reset lanes: oracle's draw, bitwise
+            assert np.array_equal(out.Observation, got.T)                       # obs of a finished lane = next episode's first obs
+            total += int(d.sum())
+        assert total > 0 and env.Tick == steps + 1
+        assert env.Counters()["lane_steps"] == steps * n
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 63, 65, 257, 1000])
+def test_ragged_batch_sizes(gpu_pkg, oracle, n):
+    rng = np.random.default_rng(n)
+    s = _states(rng, n, wide=True)
+    a = rng.integers(0, 2, n).astype(np.int32)
+    want_s, want_r, want_d, _ = oracle.cartpole_step(s.astype(np.float64), a)
+    for auto in (False, True):
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto) as env:
+            env.Reset(); env.SetState(s)
+            out = env.Step(a)
+            got = env.GetState()
+            d = want_d.astype(bool)
+            assert np.array_equal(out.Done, d) and out.Observation.shape == (n, 4)
+            keep = ~d if auto else np.ones(n, bool)
+            if keep.any():
+                assert np.abs(got[:, keep].astype(np.float64) - want_s[:, keep]).max() <= TOL
+
+
+def test_mirror_symmetry_bitwise_at_full_batch(gpu_pkg):
+    # size-independent property at BASELINE's full batch (2^20): step(-s, a=0) == -step(s, a=1), exactly
+    n = 1 << 20
+    rng = np.random.default_rng(7)
+    s = _states(rng, n, wide=True)
+    a = rng.integers(0, 2, n).astype(np.int32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as e1, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as e2:
+        e1.Reset(); e2.Reset()
+        e1.SetState(s); e2.SetState(-s)
+        o1 = e1.Step(a); o2 = e2.Step(1 - a)
+        assert np.array_equal(e1.GetState(), -e2.GetState())
+        assert np.array_equal(o1.Done, o2.Done) and 0 < o1.Done.sum() < n
+
+
+def test_graph_rollout_equals_eager_steps_bitwise(gpu_pkg):
+    # hipGraph replay (frozen kernel arguments, device-side tick) must give the eager result, bit for bit
+    import torch
+    n, ring, steps = 1 << 20, 8, 8 * 5 + 3
+    dev = torch.device("cuda", 0)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as g, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as e:
+        acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+        for t in range(ring):
+            g.SampleActionsDevice(acts[t], seed=SEED + 1, tick=t)
+        g.Sync()
+        a_host = acts.cpu().numpy()
+        assert set(np.unique(a_host)) == {0, 1} and abs(a_host.mean() - 0.5) < 1e-3
+        g.ResetDevice(); e.ResetDevice()
+        g.RolloutDevice(acts, steps, n, ring)
+        g.RolloutDevice(acts, ring * 2, n, ring)         # second call replays the cached graph
+        for t in range(steps):
+            e.StepDevice(acts[t % ring])
+        for t in range(ring * 2):
+            e.StepDevice(acts[t % ring])
+        g.Sync(); e.Sync()
+        assert g.Tick == e.Tick == 1 + steps + 2 * ring
+        assert np.array_equal(g.GetState(), e.GetState())
+        assert g.Counters()["tick"] == g.Tick            # the device-side tick agrees with the host mirror
+        r1, r2 = g.Read(), e.Read()
+        assert np.array_equal(r1.Done, r2.Done) and np.array_equal(r1.Reward, r2.Reward)
+        st = g.GetState()
+        assert np.isfinite(st).all() and np.abs(st[0]).max() < 2.6 and np.abs(st[2]).max() < 0.3   # auto-reset keeps lanes in range
+
+
+def test_sharding_invariance_bitwise(gpu_pkg):
+    # G logical shards with global lane offsets == one big batch, incl. Philox resets
+    n, G, steps = 1 << 16, 4, 30
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 2, (steps, n)).astype(np.int32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as whole:
+        whole.Reset()
+        for t in range(steps):
+            whole.Step(acts[t])
+        ref = whole.GetState()
+    parts = []
+    for r in range(G):
+        lo, hi = r * n // G, (r + 1) * n // G
+        with gpu_pkg.VectorEnv("CartPole-v1", hi - lo, seed=SEED, auto_reset=True, lane_offset=lo) as sh:
+            sh.Reset()
+            for t in range(steps):
+                sh.Step(acts[t, lo:hi])
+            parts.append(sh.GetState())
+    assert np.array_equal(np.concatenate(parts, axis=1), ref)
+
+
+def test_done_list_episode_stats_final_obs(gpu_pkg, oracle):
+    n, steps = 20_000, 60
+    rng = np.random.default_rng(9)
+    ret = np.zeros(n, np.float32); ln = np.zeros(n, np.int32)
+    fin_ret = np.zeros(n, np.float32); fin_len = np.zeros(n, np.int32)
+    fin_obs = np.zeros((n, 4), np.float32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, done_list=True, episode_stats=True,
+                           final_obs=True) as env:
+        env.Reset()
+        for t in range(steps):
+            s = env.GetState()
+            a = rng.integers(0, 2, n).astype(np.int32)
+            out = env.Step(a)
+            lanes = env.DoneLanes()
+            assert sorted(lanes.tolist()) == np.nonzero(out.Done)[0].tolist()       # wave-ballot compaction == mask
+            assert env.Counters()["last_done_count"] == int(out.Done.sum())
+            term = oracle.cartpole_step(s, a, dtype=np.float32)[0]                  # terminal obs, kernel semantics
+            ret += out.Reward; ln += 1
+            d = out.Done
+            fin_ret[d] = ret[d]; fin_len[d] = ln[d]; ret[d] = 0; ln[d] = 0
+            fin_obs[d] = term.T[d]
+        got_ret, got_len = env.EpisodeStats()
+        assert np.array_equal(got_len, fin_len) and np.array_equal(got_ret, fin_ret)   # integer step counts exact
+        assert np.abs(env.FinalObs() - fin_obs).max() <= 1e-6
+        assert 15 < fin_len[fin_len > 0].mean() < 30                                  # mean 22.25
+
+
+def test_time_limit_extension(gpu_pkg):
+    n = 512
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True, max_episode_steps=5) as env:
+        env.Reset()
+        longest = 0
+        for t in range(12):
+            out = env.Step(t % 2)
+            _, ln = env.EpisodeStats()
+            longest = max(longest, int(ln.max()))
+        assert longest == 5            # no episode outlives the limit; the reference itself has none
+    with pytest.raises(ValueError):
+        gpu_pkg.VectorEnv("CartPole-v1", n, max_episode_steps=5)        # needs episode_stats
+
+
+def test_seed_semantics(gpu_pkg):
+    n = 4096
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=1) as a, gpu_pkg.VectorEnv("CartPole-v1", n, seed=2) as b:
+        ra, rb = a.Reset(), b.Reset()
+        assert not np.array_equal(ra, rb)
+        b.Seed(1)                                                         # Env.Seed(int): same seed, same stream
+        assert np.array_equal(b.Reset(), ra)
+        assert len(np.unique(ra[:, 0])) > n * 0.99                        # lanes draw different values (documented deviation)
+        with pytest.raises(ValueError, match="Number of seeds"):          # VecEnv.cs:49 ArgumentException
+            a.Seed([1, 2, 3])
+        a.Seed(list(range(n)))                                            # VecEnv.Seed(int[])
+        r1 = a.Reset()
+        a.Seed(list(range(n)))
+        assert np.array_equal(a.Reset(), r1) and not np.array_equal(r1, ra)
+
+
+def test_invalid_actions(gpu_pkg, oracle):
+    n = 1000
+    s = _states(np.random.default_rng(10), n)
+    acts = np.zeros(n, np.int32); acts[17] = 2; acts[900] = -1
+    # default = Release-build CartPole: anything != 1 pushes left (CartPoleEnv.cs:139,146)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env:
+        env.Reset(); env.SetState(s)
+        env.Step(acts)
+        left = oracle.cartpole_step(s.astype(np.float64), np.zeros(n, np.int32))[0]
+        assert np.abs(env.GetState().astype(np.float64) - left).max() <= TOL
+    # validate_actions = LunarLander-style throw before any state change (LunarLanderEnv.cs:604-607)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, validate_actions=True) as env:
+        env.Reset(); env.SetState(s)
+        with pytest.raises(gpu_pkg.InvalidActionError, match="outside of the configured action space"):
+            env.Step(acts)
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            env.Step(2)
+        assert np.array_equal(env.GetState(), s)
+        env.Step(np.ones(n, np.int32))
+    cp = gpu_pkg.CartPoleEnv()
+    with pytest.raises(TypeError):                                       # (int)action InvalidCastException, CartPoleEnv.cs:138
+        cp.Step(0.5)
+    cp.Close()
+
+
+def test_step_async_and_errors(gpu_pkg):
+    n = 2048
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as ref:
+        env.Reset(); ref.Reset()
+        with pytest.raises(gpu_pkg.NotSteppingError):
+            env.StepWait()
+        task = env.StepAsync(1)                                           # VecEnv.StepAsync(int)
+        with pytest.raises(gpu_pkg.AlreadySteppingError):
+            env.StepAsync(0)
+        with pytest.raises(gpu_pkg.AlreadySteppingError):
+            env.Step(0)
+        got = task.Result()
+        want = ref.Step(1)
+        assert np.array_equal(got.Observation, want.Observation) and np.array_equal(got.Done, want.Done)
+        assert isinstance(got[0], gpu_pkg.Step) and len(got.ToSteps()) == n
+    with pytest.raises(ValueError):
+        gpu_pkg.VectorEnv("CartPole-v1", 0)
+    with pytest.raises(ValueError):
+        gpu_pkg.VectorEnv("CartPole-v1", 16, device=99)
+
+
+def test_external_obs_buffer_and_unaligned_fallback(gpu_pkg):
+    # state living inside a caller-provided buffer (the all-gather layout), aligned (dwordx4 path) and
+    # deliberately misaligned (scalar fallback): identical results
+    import torch
+    n, steps = 4096 + 8, 12
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    acts = rng.integers(0, 2, (steps, n)).astype(np.int32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as own:
+        own.Reset()
+        for t in range(steps):
+            own.Step(acts[t])
+        ref = own.GetState()
+    for shift in (0, 1):
+        buf = torch.zeros(4 * n + 8, dtype=torch.float32, device=dev)
+        view = buf[shift:shift + 4 * n]
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, ext_obs=view.data_ptr(), ext_obs_stride=n) as env:
+            env.Reset()
+            for t in range(steps):
+                env.Step(acts[t])
+            env.Sync()
+            assert np.array_equal(env.GetState(), ref)
+            assert np.array_equal(view.view(4, n).cpu().numpy(), ref)     # zero-copy: the buffer IS the state
+
+
+def test_batched_space_sampling(gpu_pkg, oracle):
+    n = 10_000
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, lane_offset=77) as env:
+        a = env.SampleActions(seed=9, tick=4)
+        assert np.array_equal(a, oracle.discrete_sample(9, 77, 4, 2, 0, n))   # Discrete.Sample(): start + randint(0, N)
+        assert all(env.ActionSpace.Contains(int(x)) for x in a[:100])
+    with gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED) as env:
+        a = env.SampleActions(seed=9, tick=4)
+        assert np.array_equal(a, oracle.box_uniform_sample(9, 0, 4, -2.0, 2.0, n))   # Box.Sample(), bounded regime
+        assert a.min() >= -2.0 and a.max() <= 2.0                                   # BoxTest.cs:36-41
