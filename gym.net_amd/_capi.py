@@ -5,7 +5,9 @@ gym.net_amd/build.py).  There is no fallback: if the library is missing this mod
 without a GPU every compute call returns GYMNET_ERR_NO_DEVICE which is raised as NoDeviceError.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDeviceError,
                      NotSteppingError)
@@ -116,6 +118,24 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, the same soname this library needs); if this library were loaded first it would
+    bring in /opt/rocm's copy and a later `import torch` would start a SECOND runtime that finds no GPU.
+    So when torch is installed (it is only located, not imported) its copy is loaded first and this
+    library binds to it by soname.  GYMNET_HIP_RUNTIME=system opts out (hosts that never load torch)."""
+    if os.environ.get("GYMNET_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Loads libgymnet_amd.so.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -125,6 +145,7 @@ def load_library():
         raise GymNetError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

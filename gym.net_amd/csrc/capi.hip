@@ -89,7 +89,7 @@ struct gymnet_vecenv {
     int last_cparity = -1;
     bool async_pending = false;
     std::atomic<bool> busy{false};
-    LaunchCfg lcfg{4, 256};
+    LaunchCfg lcfg{4, 256, 0};
     std::vector<GraphEntry> graphs;
     std::vector<void *> owned;     // device allocations to free
     std::string err;
@@ -416,8 +416,20 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
     const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0);
-    h->lcfg.vec = can_vec4 ? 4 : 1;
+    // Launch policy, measured with tools/probe_step.hip on MI355X (profiles/probe_r01.txt):
+    //  - state <= 8 MiB: scalar lanes (4x the waves hide latency better than dwordx4 when the grid is small);
+    //  - state <= 16 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
+    //  - state <= 256 MiB (fits the Infinity Cache): dwordx4, keep the state cacheable and stream only the
+    //    action / reward / done arrays past it, so the next launch re-reads the state from the cache;
+    //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal.
+    const size_t state_bytes = (size_t)h->n * d.state_dim * 4;
+    if (state_bytes <= ((size_t)8 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    else if (state_bytes <= ((size_t)16 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
+    else if (state_bytes <= ((size_t)256 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
+    else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    if (!can_vec4) h->lcfg.vec = 1;
     if (const char *e = std::getenv("GYMNET_VEC")) { int v = std::atoi(e); if (v == 1 || (v == 4 && can_vec4)) h->lcfg.vec = v; }
+    if (const char *e = std::getenv("GYMNET_NT")) { int v = std::atoi(e); if (v == 0 || v == 12 || v == 15) h->lcfg.nt = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY
 #undef CREATE_HIP

@@ -19,71 +19,92 @@ namespace gymnet {
 // ---------------------------------------------------------------------------------------------
 // VEC-wide lane access helpers.  i0 is a multiple of VEC; arrays are 16-byte aligned (capi.hip
 // checks this before it picks VEC = 4), so the full-vector path is one dwordx4 per lane.
+// NT = non-temporal (streaming) access: `global_load/store ... nt`.  Which streams get it is a
+// measured policy (tools/probe_step.hip): it decides what stays in the 256 MiB
+// Infinity Cache between two launches.
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+template <int VEC, bool NT>
 __device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0, int64_t n, float (&v)[VEC]) {
     if constexpr (VEC == 4) {
         if (i0 + 4 <= n) {
-            const float4 t = *reinterpret_cast<const float4 *>(p + i0);
+            f32x4 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + i0));
+            else t = *reinterpret_cast<const f32x4 *>(p + i0);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = (i0 + j < n) ? p[i0 + j] : 0.0f;
+    for (int j = 0; j < VEC; ++j) {
+        if (i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
+        else v[j] = 0.0f;
+    }
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int64_t n, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
         if (i0 + 4 <= n) {
-            *reinterpret_cast<float4 *>(p + i0) = make_float4(v[0], v[1], v[2], v[3]);
+            f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+            if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p + i0));
+            else *reinterpret_cast<f32x4 *>(p + i0) = t;
             return;
         }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) p[i0 + j] = v[j];
+        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t i0, int64_t n, int32_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
         if (i0 + 4 <= n) {
-            const int4 t = *reinterpret_cast<const int4 *>(p + i0);
+            i32x4 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p + i0));
+            else t = *reinterpret_cast<const i32x4 *>(p + i0);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = (i0 + j < n) ? p[i0 + j] : 0;
+    for (int j = 0; j < VEC; ++j) {
+        if (i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
+        else v[j] = 0;
+    }
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, int64_t n, const int32_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
         if (i0 + 4 <= n) {
-            *reinterpret_cast<int4 *>(p + i0) = make_int4(v[0], v[1], v[2], v[3]);
+            i32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+            if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<i32x4 *>(p + i0));
+            else *reinterpret_cast<i32x4 *>(p + i0) = t;
             return;
         }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) p[i0 + j] = v[j];
+        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, int64_t n, const uint8_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
         if (i0 + 4 <= n) {
-            *reinterpret_cast<uint32_t *>(p + i0) =
-                (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            const uint32_t w = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p + i0));
+            else *reinterpret_cast<uint32_t *>(p + i0) = w;
             return;
         }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) p[i0 + j] = v[j];
+        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
 __device__ __forceinline__ uint32_t lane_id() {
@@ -96,10 +117,12 @@ __device__ __forceinline__ uint32_t lane_id() {
 //   VEC       envs per thread (4 = dwordx4 streams; 1 = fallback for unaligned external buffers)
 //   AUTORESET fuse the caller's `if (done) Reset()` (README.md:36-40) as a masked Philox reset
 //   EXTRAS    done-list compaction, episode statistics, terminal observations, per-lane seeds, time limit
+//   NT        non-temporal mask: 1 state loads, 2 state/obs stores, 4 action load, 8 reward/done stores
 // ---------------------------------------------------------------------------------------------
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     constexpr int S = Env::S, O = Env::O;
+    constexpr bool NT_SL = (NT & 1) != 0, NT_SS = (NT & 2) != 0, NT_A = (NT & 4) != 0, NT_O = (NT & 8) != 0;
     using Act = typename Env::Action;
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     const int64_t n = a.n;
@@ -117,26 +140,27 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
 
     float s[S][VEC];
 #pragma unroll
-    for (int k = 0; k < S; ++k) load_f32<VEC>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) load_f32<VEC, NT_SL>(a.state + k * a.state_stride, i0, n, s[k]);
     Act act[VEC];
-    if constexpr (Env::BOX_ACTION) load_f32<VEC>(static_cast<const float *>(a.action), i0, n, act);
-    else load_i32<VEC>(static_cast<const int32_t *>(a.action), i0, n, act);
+    if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A>(static_cast<const float *>(a.action), i0, n, act);
+    else load_i32<VEC, NT_A>(static_cast<const int32_t *>(a.action), i0, n, act);
 
     int32_t sbd[VEC];
-    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC>(a.sbd, i0, n, sbd);
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL>(a.sbd, i0, n, sbd);
 
     float ep_ret[VEC];
     int32_t ep_len[VEC];
     bool stats = false;
     if constexpr (EXTRAS) {
         stats = a.ep_ret != nullptr;
-        if (stats) { load_f32<VEC>(a.ep_ret, i0, n, ep_ret); load_i32<VEC>(a.ep_len, i0, n, ep_len); }
+        if (stats) { load_f32<VEC, false>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, false>(a.ep_len, i0, n, ep_len); }
     }
 
     float reward[VEC];
     uint8_t done[VEC];
     bool finished[VEC];
     float o[O][VEC];
+    uint32_t pending = 0;     // sub-lanes of this thread that finished and await their reset draw
 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -186,16 +210,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
             }
         }
 
-        if constexpr (AUTORESET) {
-            if (fin) {   // divergent: waves without a finished lane skip the Philox rounds entirely
-                uint64_t key = a.seed;
-                if constexpr (EXTRAS) {
-                    if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
-                }
-                const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
-                Env::reset(sj, r);
-            }
-        }
+        if constexpr (AUTORESET) pending |= fin ? (1u << j) : 0u;
 
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k][j] = sj[k];
@@ -207,18 +222,52 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         }
     }
 
+    // reward / done do not depend on the reset draw: get them on their way before the Philox rounds
+    store_f32<VEC, NT_O>(a.reward, i0, n, reward);
+    store_u8<VEC, NT_O>(a.done, i0, n, done);
+
+    if constexpr (AUTORESET) {
+        // Fused auto-reset.  ~4.5 % of CartPole lanes finish per step, so ~95 % of 64-lane waves hold a finished
+        // lane in EVERY sub-lane position: a per-sub-lane `if (done) philox()` would make every wave pay VEC
+        // Philox passes.  Instead each thread drains its finished sub-lanes one per loop trip; the trips a wave
+        // pays are max over its lanes of #finished sub-lanes (1.6 on average instead of 3.8), and waves with no
+        // finished lane skip the loop through the exec mask.
+        while (pending) {
+            const int j = __ffs(pending) - 1;
+            pending &= pending - 1;
+            uint64_t key = a.seed;
+            if constexpr (EXTRAS) {
+                if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
+            }
+            const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
+            float sj[S];
+            Env::reset(sj, r);
+            float oj[O];
+            if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC>(a.state + k * a.state_stride, i0, n, s[k]);
+            for (int jj = 0; jj < VEC; ++jj) {
+                if (jj == j) {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) s[k][jj] = sj[k];
+                    if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                        for (int k = 0; k < O; ++k) o[k][jj] = oj[k];
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS>(a.state + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
-        for (int k = 0; k < O; ++k) store_f32<VEC>(a.obs + k * a.obs_stride, i0, n, o[k]);
+        for (int k = 0; k < O; ++k) store_f32<VEC, NT_SS>(a.obs + k * a.obs_stride, i0, n, o[k]);
     }
-    store_f32<VEC>(a.reward, i0, n, reward);
-    store_u8<VEC>(a.done, i0, n, done);
-    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC>(a.sbd, i0, n, sbd);
+    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, NT_SS>(a.sbd, i0, n, sbd);
 
     if constexpr (EXTRAS) {
-        if (stats) { store_f32<VEC>(a.ep_ret, i0, n, ep_ret); store_i32<VEC>(a.ep_len, i0, n, ep_len); }
+        if (stats) { store_f32<VEC, false>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, false>(a.ep_len, i0, n, ep_len); }
         if (a.done_list) {
             // wave64 compaction: ballot per sub-lane, one atomic per wave, order inside the list is unspecified
             const uint32_t lane = lane_id();
@@ -363,14 +412,22 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
     const int block = cfg.block;
     const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
     const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
-#define GYMNET_LAUNCH(V, AR, EX) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX>), grid, blk, 0, st, a)
-    if (cfg.vec == 4) {
-        if (autoreset) { if (extras) GYMNET_LAUNCH(4, true, true); else GYMNET_LAUNCH(4, true, false); }
-        else           { if (extras) GYMNET_LAUNCH(4, false, true); else GYMNET_LAUNCH(4, false, false); }
+#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, 0, st, a)
+#define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
+    do {                                                              \
+        if (cfg.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);               \
+        else if (cfg.nt == 12) GYMNET_LAUNCH(V, AR, EX, 12);          \
+        else GYMNET_LAUNCH(V, AR, EX, 0);                             \
+    } while (0)
+    if (extras) {   // bookkeeping variants: not the measured hot path, one NT policy (none) is enough
+        if (cfg.vec == 4) { if (autoreset) GYMNET_LAUNCH(4, true, true, 0); else GYMNET_LAUNCH(4, false, true, 0); }
+        else              { if (autoreset) GYMNET_LAUNCH(1, true, true, 0); else GYMNET_LAUNCH(1, false, true, 0); }
+    } else if (cfg.vec == 4) {
+        if (autoreset) GYMNET_LAUNCH_NT(4, true, false); else GYMNET_LAUNCH_NT(4, false, false);
     } else {
-        if (autoreset) { if (extras) GYMNET_LAUNCH(1, true, true); else GYMNET_LAUNCH(1, true, false); }
-        else           { if (extras) GYMNET_LAUNCH(1, false, true); else GYMNET_LAUNCH(1, false, false); }
+        if (autoreset) GYMNET_LAUNCH_NT(1, true, false); else GYMNET_LAUNCH_NT(1, false, false);
     }
+#undef GYMNET_LAUNCH_NT
 #undef GYMNET_LAUNCH
     return hipGetLastError();
 }
@@ -378,6 +435,7 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     if (cfg.vec != 4) cfg.vec = 1;
     if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
+    if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
     switch (env_id) {
         case 0: return launch_step_env<CartPole>(autoreset, extras, a, cfg, st);
         case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);

@@ -28,7 +28,9 @@ struct StepArgs {
     int32_t max_episode_steps;
 };
 
-struct LaunchCfg { int vec; int block; };
+// vec: envs per thread (4 = dwordx4 streams, 1 = scalar); block: threads per workgroup;
+// nt: non-temporal mask (0 none, 12 action + reward/done streams, 15 every stream)
+struct LaunchCfg { int vec; int block; int nt; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

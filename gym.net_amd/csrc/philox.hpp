@@ -11,22 +11,16 @@ namespace gymnet {
 
 struct PhiloxWords { uint32_t w[4]; };
 
-__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
-#endif
-}
-
+// One round = two 32x32->64 products.  Written as 64-bit multiplies so that gfx950 emits ONE v_mad_u64_u32 per
+// product (quarter-rate) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the multiplies dominate a Philox pass.
 __host__ __device__ __forceinline__ PhiloxWords philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                               uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     PhiloxWords o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;

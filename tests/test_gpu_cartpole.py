@@ -122,7 +122,9 @@ def test_teacher_forced_random_rollout_vs_oracle(gpu_pkg, oracle):
             mism += int((bad & ~near).sum()); ambiguous += int(near.sum()); dones += int(want_d.sum())
             env.ResetWhere()                                                    # the caller's `if (done) Reset()`
     assert worst <= TOL and worst < 2e-6
-    assert mism == 0 and ambiguous <= 2 and dones > n                            # ~4.5 % of lanes finish per step
+    # `ambiguous` = lanes whose float64 x'/theta' lies within 1e-6 of a threshold (a few per million); everywhere
+    # else the integer done flag must agree exactly
+    assert mism == 0 and ambiguous <= 64 and dones > n                           # ~4.5 % of lanes finish per step
 
 
 def test_fused_autoreset_matches_oracle_philox(gpu_pkg, oracle):
@@ -373,3 +375,27 @@ def test_batched_space_sampling(gpu_pkg, oracle):
         a = env.SampleActions(seed=9, tick=4)
         assert np.array_equal(a, oracle.box_uniform_sample(9, 0, 4, -2.0, 2.0, n))   # Box.Sample(), bounded regime
         assert a.min() >= -2.0 and a.max() <= 2.0                                   # BoxTest.cs:36-41
+
+
+def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
+    # the launch policy (scalar vs dwordx4 lanes, which streams are non-temporal) is a performance choice
+    # made from the batch size; every variant must compute the same bits
+    n, steps = 8192 + 5, 20
+    rng = np.random.default_rng(13)
+    acts = rng.integers(0, 2, (steps, n)).astype(np.int32)
+    results = []
+    for vec, nt in ((1, 0), (1, 12), (1, 15), (4, 0), (4, 12), (4, 15)):
+        monkeypatch.setenv("GYMNET_VEC", str(vec))
+        monkeypatch.setenv("GYMNET_NT", str(nt))
+        for auto in (True, False):
+            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto) as env:
+                env.Reset()
+                dones = 0
+                for t in range(steps):
+                    dones += int(env.Step(acts[t]).Done.sum())
+                results.append((auto, env.GetState(), dones))
+    for auto in (True, False):
+        same = [r for r in results if r[0] == auto]
+        assert len(same) == 6 and same[0][2] > 0
+        for r in same[1:]:
+            assert np.array_equal(r[1], same[0][1], equal_nan=True) and r[2] == same[0][2]
