@@ -1,0 +1,98 @@
+// Native.cs — P/Invoke declarations for include/gymnet_amd.h (libgymnet_amd.so).
+// UNVERIFIED: no .NET toolchain exists in the build image, so this file has never been compiled.
+// It is the binding a Gym.NET maintainer would add next to src/Gym/Envs/VecEnv.cs; struct layouts
+// mirror the header field by field (checked on the Python side by tests/test_host_api.py).
+using System;
+using System.Runtime.InteropServices;
+
+namespace Gym.Envs.Amd {
+    public enum GymnetStatus {
+        Ok = 0, InvalidArg = -1, InvalidAction = -2, Hip = -3, Oom = -4, NoDevice = -5,
+        AlreadyStepping = -6, NotStepping = -7, Unsupported = -8
+    }
+
+    public enum GymnetEnvId { CartPole = 0, Pendulum = 1, MountainCar = 2, Acrobot = 3 }
+
+    [Flags]
+    public enum GymnetFlags : uint {
+        None = 0, AutoReset = 0x01, ValidateActions = 0x02, DoneList = 0x04, EpisodeStats = 0x08, FinalObs = 0x10
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct GymnetConfig {
+        public uint struct_size; public int env_id; public long num_envs; public long lane_offset;
+        public int device; public uint flags; public ulong seed; public IntPtr stream;
+        public IntPtr d_ext_obs; public long ext_obs_stride; public int max_episode_steps; public int reserved;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct GymnetEnvInfo {
+        public uint struct_size; public int env_id; public fixed byte name[32];
+        public int state_dim, obs_dim, obs_aliases_state, action_is_box, action_n;
+        public float action_low, action_high;
+        public fixed float obs_low[8]; public fixed float obs_high[8];
+        public float reward_low, reward_high; public int algorithmic_bytes_per_step;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct GymnetCounters {
+        public uint struct_size, reserved; public ulong tick, lane_steps, stepped_after_done; public long last_done_count;
+    }
+
+    internal static unsafe class Native {
+        private const string Lib = "gymnet_amd";   // libgymnet_amd.so on the loader path
+
+        [DllImport(Lib)] public static extern int gymnet_abi_version();
+        [DllImport(Lib)] public static extern IntPtr gymnet_status_string(int status);
+        [DllImport(Lib)] public static extern IntPtr gymnet_last_error();
+        [DllImport(Lib)] public static extern int gymnet_device_count(out int count);
+        [DllImport(Lib)] public static extern int gymnet_env_describe(int env_id, out GymnetEnvInfo info);
+
+        [DllImport(Lib)] public static extern int gymnet_vecenv_create(ref GymnetConfig cfg, out IntPtr handle);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_destroy(IntPtr h);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_seed(IntPtr h, ulong seed);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_seed_lanes(IntPtr h, ulong[] seeds, long count);
+
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset(IntPtr h, float* obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset_where(IntPtr h, byte* mask, float* obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step(IntPtr h, void* actions, float* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_broadcast(IntPtr h, int action, float* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_async(IntPtr h, void* actions);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_wait(IntPtr h, float* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_read(IntPtr h, float* obs_out, float* reward_out, byte* done_out);
+
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset_device(IntPtr h);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset_where_device(IntPtr h, IntPtr d_mask);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_device(IntPtr h, IntPtr d_actions);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_device(IntPtr h, IntPtr d_actions, long steps, long action_stride, long ring);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_pack_obs_device(IntPtr h, IntPtr d_obs_rowmajor);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_sync(IntPtr h);
+
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, float* state_soa);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_state(IntPtr h, float* state_soa);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_steps_beyond_done(IntPtr h, int* out_sbd);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_steps_beyond_done(IntPtr h, int* in_sbd);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_tick(IntPtr h, out ulong tick);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_tick(IntPtr h, ulong tick);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_counters(IntPtr h, out GymnetCounters counters);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes(IntPtr h, int* lanes_out, long capacity, out long count);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_episode_stats(IntPtr h, float* finished_return, int* finished_length);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_final_obs(IntPtr h, float* final_obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions(IntPtr h, void* actions_out, ulong seed, ulong tick);
+
+        /// Maps a status to the exception the reference throws for the same condition.
+        public static void Check(int status) {
+            if (status == 0) return;
+            string msg = Marshal.PtrToStringAnsi(gymnet_last_error()) ?? Marshal.PtrToStringAnsi(gymnet_status_string(status));
+            switch ((GymnetStatus) status) {
+                case GymnetStatus.InvalidArg: throw new ArgumentException(msg);                       // VecEnv.cs:49
+                case GymnetStatus.InvalidAction: throw new Gym.Exceptions.InvalidActionError(msg);    // InvalidActionError.cs:7-10
+                case GymnetStatus.AlreadyStepping: throw new Gym.Exceptions.AlreadySteppingError();   // AlreadySteppingError.cs:8-10
+                case GymnetStatus.NotStepping: throw new Gym.Exceptions.NotSteppingError();
+                case GymnetStatus.Oom: throw new OutOfMemoryException(msg);
+                case GymnetStatus.Unsupported: throw new NotSupportedException(msg);
+                default: throw new InvalidOperationException($"gymnet_amd: {msg} (status {status})");
+            }
+        }
+    }
+}

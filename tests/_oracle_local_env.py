@@ -1,0 +1,40 @@
+"""TEST-ONLY stand-in for the HIP VectorEnv, backed by the oracle's float32 ("kernel semantics") CartPole.
+
+It exists so that the host-side sharding logic (gym.net_amd/sharding.py: lane offsets, the rank-major gather
+buffer the rank's state lives in, the all-gather) can be exercised with world_size 2 on the gloo backend in a
+container that has no GPU.  The product never imports this file (nothing under tests/ ships)."""
+import ctypes
+
+import numpy as np
+
+from oracle import capi as oracle
+
+
+class OracleLocalEnv:
+    def __init__(self, env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream):
+        assert env in ("CartPole-v1", 0) and auto_reset
+        self.n, self.lane_offset, self.seed, self.tick = num_envs, lane_offset, seed, 0
+        buf = (ctypes.c_float * (4 * ext_obs_stride)).from_address(int(ext_obs))
+        self.state = np.ctypeslib.as_array(buf).reshape(4, ext_obs_stride)[:, :num_envs]   # zero-copy view
+        self.reward = np.zeros(num_envs, np.float32)
+        self.done = np.zeros(num_envs, np.uint8)
+
+    def ResetDevice(self):
+        self.state[:] = oracle.cartpole_reset(self.seed, self.lane_offset, self.tick, self.n)
+        self.tick += 1
+
+    def StepDevice(self, actions):
+        a = actions.numpy() if hasattr(actions, "numpy") else np.asarray(actions)
+        s, r, d, _ = oracle.cartpole_step(self.state, a.astype(np.int32), dtype=np.float32)
+        fresh = oracle.cartpole_reset(self.seed, self.lane_offset, self.tick, self.n)
+        fin = d.astype(bool)
+        s[:, fin] = fresh[:, fin]
+        self.state[:] = s
+        self.reward[:], self.done[:] = r, d
+        self.tick += 1
+
+    def Sync(self):
+        pass
+
+    def Close(self):
+        pass

@@ -1,0 +1,72 @@
+"""world_size-2 test of the multi-GPU path on CPU (gloo): one process per rank, each owning a contiguous
+lane block whose observations live inside the rank-major all-gather buffer; after every step the gathered
+[G][D][N/G] buffer on EVERY rank must equal the single-shard batch bit for bit (sharding invariance,
+SURVEY.md §8(e)).  Compute is the oracle-backed stand-in from tests/_oracle_local_env.py — the HIP engine
+needs a GPU; what is under test here is gym.net_amd/sharding.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, STEPS, SEED = 4096, 25, 0x5EED
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from _oracle_local_env import OracleLocalEnv
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    env = pkg.ShardedVectorEnv("CartPole-v1", N, rank=rank, world_size=world, seed=SEED, auto_reset=True,
+                               gather_obs=True, local_env_factory=OracleLocalEnv, tensor_device="cpu")
+    assert env.local_num_envs == N // world and env.lane_offset == rank * N // world
+    rng = np.random.default_rng(99)                       # every rank derives the same GLOBAL action array
+    acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
+    lo, hi = env.lane_offset, env.lane_offset + env.local_num_envs
+    env.ResetDevice()
+    snaps = []
+    for t in range(STEPS):
+        env.StepDevice(torch.from_numpy(acts[t, lo:hi].copy()))
+        work = env.AllGatherObs(async_op=(t % 2 == 0))    # both the blocking and the overlapped form
+        env.Wait()
+        snaps.append(env.GlobalObs().clone().numpy())
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.stack(snaps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_rollout_equals_single_shard(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
+    assert np.array_equal(got[0], got[1])                 # every rank holds the same gathered observations
+    # single shard, same seed, same global actions, same float32 kernel-semantics oracle
+    rng = np.random.default_rng(99)
+    acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
+    s = oracle.cartpole_reset(SEED, 0, 0, N)
+    for t in range(STEPS):
+        s2, _, d, _ = oracle.cartpole_step(s, acts[t], dtype=np.float32)
+        fresh = oracle.cartpole_reset(SEED, 0, t + 1, N)
+        fin = d.astype(bool)
+        s2[:, fin] = fresh[:, fin]
+        s = s2
+        gathered = got[0][t]                               # [G, 4, N/G] rank-major
+        assert np.array_equal(np.concatenate(list(gathered), axis=1), s), t
