@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 "
+                   "(exercises the collective code path on a 1-GPU box)")
     return p.parse_args()
 
 
@@ -76,8 +78,10 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.num_envs
@@ -91,7 +95,8 @@ def main():
 
     # this rank's shard of the global batch; observations live inside the (optional) gather buffer
     env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=local_rank, seed=seed,
-                               auto_reset=True, gather_obs=args.allgather, tensor_device=dev)
+                               auto_reset=True, gather_obs=args.allgather, tensor_device=dev,
+                               force_gather=args.force_dist)
     local = env.local
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
     actions = torch.empty((ring, n), dtype=adtype, device=dev)
@@ -101,7 +106,7 @@ def main():
     env.Sync()
 
     def run(steps):
-        if args.allgather and world > 1:
+        if args.allgather and use_dist:
             for t in range(steps):
                 env.StepDevice(actions[t % ring].data_ptr())
                 env.AllGatherObs()
@@ -112,7 +117,7 @@ def main():
             local.RolloutDevice(actions.data_ptr(), steps, n, ring)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     run(W)
@@ -129,7 +134,7 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     ev_ms = e0.elapsed_time(e1)
-    if world > 1:
+    if use_dist:
         tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tw[0]), float(tw[1])
@@ -157,7 +162,7 @@ def main():
                                    "fused auto-reset, iid random actions pre-generated in HBM",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
                        "launch": "eager" if (args.no_graph or args.allgather) else "hipGraph replay, one kernel launch per step",
-                       "allgather_obs": bool(args.allgather and world > 1), "parallelism": f"lane-sharded x{world}"},
+                       "allgather_obs": bool(args.allgather and use_dist), "parallelism": f"lane-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
@@ -167,7 +172,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     env.Close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -26,10 +26,10 @@ namespace gymnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
-template <int VEC, bool NT>
+template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0, int64_t n, float (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        if (i0 + 4 <= n) {
+        if (!GUARD || i0 + 4 <= n) {
             f32x4 t;
             if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + i0));
             else t = *reinterpret_cast<const f32x4 *>(p + i0);
@@ -39,15 +39,15 @@ __device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        if (i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
+        if (!GUARD || i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
         else v[j] = 0.0f;
     }
 }
 
-template <int VEC, bool NT>
+template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int64_t n, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        if (i0 + 4 <= n) {
+        if (!GUARD || i0 + 4 <= n) {
             f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p + i0));
             else *reinterpret_cast<f32x4 *>(p + i0) = t;
@@ -56,13 +56,13 @@ __device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
+        if (!GUARD || i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
-template <int VEC, bool NT>
+template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t i0, int64_t n, int32_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        if (i0 + 4 <= n) {
+        if (!GUARD || i0 + 4 <= n) {
             i32x4 t;
             if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p + i0));
             else t = *reinterpret_cast<const i32x4 *>(p + i0);
@@ -72,15 +72,15 @@ __device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t 
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        if (i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
+        if (!GUARD || i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
         else v[j] = 0;
     }
 }
 
-template <int VEC, bool NT>
+template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, int64_t n, const int32_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        if (i0 + 4 <= n) {
+        if (!GUARD || i0 + 4 <= n) {
             i32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<i32x4 *>(p + i0));
             else *reinterpret_cast<i32x4 *>(p + i0) = t;
@@ -89,13 +89,13 @@ __device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, i
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
+        if (!GUARD || i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
-template <int VEC, bool NT>
+template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, int64_t n, const uint8_t (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        if (i0 + 4 <= n) {
+        if (!GUARD || i0 + 4 <= n) {
             const uint32_t w = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
             if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p + i0));
             else *reinterpret_cast<uint32_t *>(p + i0) = w;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, in
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
+        if (!GUARD || i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
 }
 
 __device__ __forceinline__ uint32_t lane_id() {
@@ -119,41 +119,30 @@ __device__ __forceinline__ uint32_t lane_id() {
 //   EXTRAS    done-list compaction, episode statistics, terminal observations, per-lane seeds, time limit
 //   NT        non-temporal mask: 1 state loads, 2 state/obs stores, 4 action load, 8 reward/done stores
 // ---------------------------------------------------------------------------------------------
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT>
-__global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
+//   GUARD     per-element bounds checks; only the last (partial) workgroup of a launch runs the guarded body
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD>
+__device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, const uint64_t tick) {
     constexpr int S = Env::S, O = Env::O;
     constexpr bool NT_SL = (NT & 1) != 0, NT_SS = (NT & 2) != 0, NT_A = (NT & 4) != 0, NT_O = (NT & 8) != 0;
     using Act = typename Env::Action;
-    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     const int64_t n = a.n;
-
-    // engine tick (Philox counter word): double-buffered in device memory so that a replayed
-    // hipGraph, whose kernel arguments are frozen, still advances it.
-    const uint64_t tick = a.tick2[a.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.tick2[a.parity ^ 1] = tick + 1;
-        if constexpr (EXTRAS) {
-            if (a.done_count2) a.done_count2[a.cparity ^ 1] = 0u;   // the NEXT step launch's counter
-        }
-    }
-    if (i0 >= n) return;
 
     float s[S][VEC];
 #pragma unroll
-    for (int k = 0; k < S; ++k) load_f32<VEC, NT_SL>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) load_f32<VEC, NT_SL, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
     Act act[VEC];
-    if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A>(static_cast<const float *>(a.action), i0, n, act);
-    else load_i32<VEC, NT_A>(static_cast<const int32_t *>(a.action), i0, n, act);
+    if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A, GUARD>(static_cast<const float *>(a.action), i0, n, act);
+    else load_i32<VEC, NT_A, GUARD>(static_cast<const int32_t *>(a.action), i0, n, act);
 
     int32_t sbd[VEC];
-    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL>(a.sbd, i0, n, sbd);
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, sbd);
 
     float ep_ret[VEC];
     int32_t ep_len[VEC];
     bool stats = false;
     if constexpr (EXTRAS) {
         stats = a.ep_ret != nullptr;
-        if (stats) { load_f32<VEC, false>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, false>(a.ep_len, i0, n, ep_len); }
+        if (stats) { load_f32<VEC, false, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, false, GUARD>(a.ep_len, i0, n, ep_len); }
     }
 
     float reward[VEC];
@@ -176,7 +165,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
             if (dn) {
                 if (sbd[j] == -1) { sbd[j] = 0; }
                 else {
-                    if (i0 + j < n) atomicAdd(a.after_done, 1ull);   // the reference's console warning, counted
+                    if (!GUARD || i0 + j < n) atomicAdd(a.after_done, 1ull);   // the reference's console warning, counted
                     sbd[j] += 1;
                     rw = 0.0f;
                 }
@@ -192,18 +181,18 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
             }
         }
         const bool fin = db != 0;
-        finished[j] = fin && (i0 + j < n);
+        finished[j] = fin && (!GUARD || i0 + j < n);
         done[j] = db;
         reward[j] = rw;
 
         if constexpr (EXTRAS) {
-            if (fin && a.final_obs && i0 + j < n) {
+            if (fin && a.final_obs && (!GUARD || i0 + j < n)) {
                 float fo[O];
                 Env::observe(sj, fo);
 #pragma unroll
                 for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = fo[k];
             }
-            if (stats && fin && i0 + j < n) {
+            if (stats && fin && (!GUARD || i0 + j < n)) {
                 a.fin_ret[i0 + j] = ep_ret[j];
                 a.fin_len[i0 + j] = ep_len[j];
                 if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
@@ -223,8 +212,8 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     }
 
     // reward / done do not depend on the reset draw: get them on their way before the Philox rounds
-    store_f32<VEC, NT_O>(a.reward, i0, n, reward);
-    store_u8<VEC, NT_O>(a.done, i0, n, done);
+    store_f32<VEC, NT_O, GUARD>(a.reward, i0, n, reward);
+    store_u8<VEC, NT_O, GUARD>(a.done, i0, n, done);
 
     if constexpr (AUTORESET) {
         // Fused auto-reset.  ~4.5 % of CartPole lanes finish per step, so ~95 % of 64-lane waves hold a finished
@@ -237,7 +226,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
             pending &= pending - 1;
             uint64_t key = a.seed;
             if constexpr (EXTRAS) {
-                if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
+                if (a.lane_seed && (!GUARD || i0 + j < n)) key = a.lane_seed[i0 + j];
             }
             const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
             float sj[S];
@@ -259,15 +248,15 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     }
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
-        for (int k = 0; k < O; ++k) store_f32<VEC, NT_SS>(a.obs + k * a.obs_stride, i0, n, o[k]);
+        for (int k = 0; k < O; ++k) store_f32<VEC, NT_SS, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
     }
-    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, NT_SS>(a.sbd, i0, n, sbd);
+    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, NT_SS, GUARD>(a.sbd, i0, n, sbd);
 
     if constexpr (EXTRAS) {
-        if (stats) { store_f32<VEC, false>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, false>(a.ep_len, i0, n, ep_len); }
+        if (stats) { store_f32<VEC, false, GUARD>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, false, GUARD>(a.ep_len, i0, n, ep_len); }
         if (a.done_list) {
             // wave64 compaction: ballot per sub-lane, one atomic per wave, order inside the list is unspecified
             const uint32_t lane = lane_id();
@@ -290,6 +279,27 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
                     if (finished[j]) a.done_list[base + off[j]] = (int32_t)(i0 + j);
             }
         }
+    }
+}
+
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT>
+__global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    // engine tick (Philox counter word): double-buffered in device memory so that a replayed
+    // hipGraph, whose kernel arguments are frozen, still advances it.
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.tick2[a.parity ^ 1] = tick + 1;
+        if constexpr (EXTRAS) {
+            if (a.done_count2) a.done_count2[a.cparity ^ 1] = 0u;   // the NEXT step launch's counter
+        }
+    }
+    // workgroup-uniform: every workgroup but (at most) the last runs the unguarded body
+    if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {
+        step_body<Env, VEC, AUTORESET, EXTRAS, NT, false>(a, i0, tick);
+    } else {
+        if (i0 >= a.n) return;
+        step_body<Env, VEC, AUTORESET, EXTRAS, NT, true>(a, i0, tick);
     }
 }
 

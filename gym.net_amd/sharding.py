@@ -69,7 +69,7 @@ class ShardedVectorEnv:
     """
 
     def __init__(self, env, global_num_envs, rank=None, world_size=None, device=None, seed=0, auto_reset=True,
-                 gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None):
+                 gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None, force_gather=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -80,7 +80,7 @@ class ShardedVectorEnv:
             rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.rank, self.world_size = int(rank), int(world_size)
         self.plan = ShardPlan(global_num_envs, world_size)
-        self.gather_obs = bool(gather_obs) and world_size > 1
+        self.gather_obs = bool(gather_obs) and (world_size > 1 or force_gather)
         if gather_obs and not self.plan.even:
             raise ValueError("global_num_envs must be a multiple of world_size to all-gather observations")
         self.lane_offset, self.local_num_envs = self.plan.shard(self.rank)

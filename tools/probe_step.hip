@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../gym.net_amd/csrc/envs.hpp"
+#include "../gym.net_amd/csrc/kernels.hpp"
 
 using namespace gymnet;
 
@@ -273,16 +274,30 @@ void LP(const Args &a, hipStream_t st) {
     hipLaunchKernelGGL((k_step_pipe<BLOCK, CH, RESET>), dim3((unsigned)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 }
 
+// the SHIPPED kernel (gym.net_amd/csrc/kernels.hip), launched through its own launcher, on the same buffers
+static uint64_t *g_tick2 = nullptr;
+static uint64_t g_host_tick = 0;
+template <int VEC, int NT>
+void LPROD(const Args &a, hipStream_t st) {
+    StepArgs s{};
+    s.state = a.s0; s.obs = a.s0; s.action = a.action; s.reward = a.reward; s.done = a.done;
+    s.tick2 = g_tick2; s.n = a.n; s.state_stride = a.s1 - a.s0; s.obs_stride = s.state_stride;
+    s.seed = a.seed; s.parity = (int32_t)(g_host_tick & 1); s.cparity = s.parity;
+    ++g_host_tick;
+    launch_step(0, true, false, s, LaunchCfg{VEC, 256, NT}, st);
+}
+
 int main(int argc, char **argv) {
     const int lg = argc > 1 ? atoi(argv[1]) : 20;
     const int rounds = argc > 2 ? atoi(argv[2]) : 20;
     const int steps = argc > 3 ? atoi(argv[3]) : 200;
     const int64_t n = (int64_t)1 << lg;
-    const int ring = lg <= 20 ? 64 : (lg <= 22 ? 16 : 4);
+    const int ring = argc > 4 ? atoi(argv[4]) : (lg <= 20 ? 64 : (lg <= 22 ? 16 : 4));
     hipStream_t st;
     CK(hipStreamCreate(&st));
     Args a{};
-    CK(hipMalloc(&a.s0, n * 4)); CK(hipMalloc(&a.s1, n * 4)); CK(hipMalloc(&a.s2, n * 4)); CK(hipMalloc(&a.s3, n * 4));
+    CK(hipMalloc(&a.s0, n * 16)); a.s1 = a.s0 + n; a.s2 = a.s1 + n; a.s3 = a.s2 + n;   // one SoA block, like the product
+    CK(hipMalloc(&g_tick2, 16)); CK(hipMemset(g_tick2, 0, 16));
     CK(hipMalloc(&a.reward, n * 4)); CK(hipMalloc(&a.done, n));
     int32_t *acts; CK(hipMalloc(&acts, (size_t)ring * n * 4));
     uint64_t *tick; CK(hipMalloc(&tick, 8)); CK(hipMemset(tick, 0, 8));
@@ -293,6 +308,10 @@ int main(int argc, char **argv) {
 #define ADD(nm, fn) V.push_back(Variant{nm, fn, {}})
     ADD("base    vec4 b256 reset=divergent ", (L<4, 256, 0, 0, 0>));
     ADD("loop    vec4 b256                 ", (L<4, 256, 0, 1, 0>));
+    ADD("SHIPPED vec4 nt=all               ", (LPROD<4, 15>));
+    ADD("SHIPPED vec4 nt=streams           ", (LPROD<4, 12>));
+    ADD("SHIPPED vec4 nt=none              ", (LPROD<4, 0>));
+    ADD("SHIPPED vec1 nt=all               ", (LPROD<1, 15>));
     ADD("copy    vec4 b256 (memory floor)  ", (L<4, 256, 1, 0, 0>));
     ADD("copy    vec4 b256 nt=all-stores   ", (L<4, 256, 1, 0, 10>));
     ADD("noreset vec4 b256 nt=all          ", (L<4, 256, 2, 0, 15>));
