@@ -559,7 +559,13 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
     // double-buffered device tick / done-count parities are the same at every replay)
     int64_t glen = (ring % 2 == 0) ? ring : 2 * ring;
     int64_t t = 0;
-    if (glen <= 4096 && steps >= glen) {
+    // Graph replay only pays while the host launch path (~3.5 us per launch) is the bottleneck: measured on
+    // MI355X, replay beats eager launches up to ~2^18 CartPole lanes (2.6 vs 5.7 us/step at 2^16), ties at 2^19
+    // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
+    const bool launch_bound = (size_t)h->n * (size_t)h->desc->algorithmic_bytes < ((size_t)24 << 20);
+    const char *force = std::getenv("GYMNET_GRAPH");
+    const bool use_graph = force ? std::atoi(force) != 0 : launch_bound;
+    if (use_graph && glen <= 4096 && steps >= glen) {
         const int parity = (int)(h->tick & 1u), cparity = (int)(h->step_launches & 1u);
         GraphEntry *ge = nullptr;
         for (auto &g : h->graphs)

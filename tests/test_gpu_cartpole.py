@@ -186,9 +186,12 @@ def test_mirror_symmetry_bitwise_at_full_batch(gpu_pkg):
         assert np.array_equal(o1.Done, o2.Done) and 0 < o1.Done.sum() < n
 
 
-def test_graph_rollout_equals_eager_steps_bitwise(gpu_pkg):
-    # hipGraph replay (frozen kernel arguments, device-side tick) must give the eager result, bit for bit
+@pytest.mark.parametrize("force_graph", ["1", "0"])
+def test_graph_rollout_equals_eager_steps_bitwise(gpu_pkg, monkeypatch, force_graph):
+    # hipGraph replay (frozen kernel arguments, device-side tick) must give the eager result, bit for bit.
+    # The library picks graph vs eager launches by batch size; GYMNET_GRAPH forces each path at full size.
     import torch
+    monkeypatch.setenv("GYMNET_GRAPH", force_graph)
     n, ring, steps = 1 << 20, 8, 8 * 5 + 3
     dev = torch.device("cuda", 0)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as g, \
