@@ -17,6 +17,53 @@
 namespace gymnet {
 
 // ---------------------------------------------------------------------------------------------
+// sin/cos — the reference calls Math.Sin / Math.Cos (CartPoleEnv.cs:147-148).  The step kernel at 2^20
+// lanes is balanced between its memory time and its ALU chain, so every instruction
+// counts: OCML's sincosf costs ~50 VALU per lane on its fast path.  This is a 3-constant Cody-Waite
+// reduction to [-pi/4, pi/4] plus the classic degree-7 / degree-8 minimax polynomials: 22 VALU, built
+// only from IEEE mul / fma / round-to-nearest-even, so the CPU restatement the tests check against
+// reproduces it BIT FOR BIT.  Measured against float64 sin/cos: |abs error| <= 9.3e-8 for every
+// |x| <= 1e5, <= 1.5 ulp for |x| <= 10.  sin(-0) returns +0.  |x| > 65536 (or inf) falls back to OCML.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) {
+    if (fabsf(x) > 65536.0f) {            // never taken by a sane rollout; keeps huge / infinite angles defined
+        sincosf(x, &s_out, &c_out);
+        return;
+    }
+    const float n = rintf(x * 0.636619772367581343f);                 // nearest multiple of pi/2
+    float r = fmaf(n, -1.5703125f, x);                                // pi/2 = 1.5703125 + 4.8375e-4 + 7.5498e-8
+    r = fmaf(n, -4.837512969970703125e-4f, r);
+    r = fmaf(n, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s = fmaf(r * z, ps, r);                               // sin r
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));            // cos r
+    const int q = (int)n & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    s_out = (q & 2) ? -ss : ss;
+    c_out = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ float sin_f32(float x) { float s, c; sincos_f32(x, s, c); return s; }
+__device__ __forceinline__ float cos_f32(float x) { float s, c; sincos_f32(x, s, c); return c; }
+
+// x / C for a compile-time constant C, as two IEEE operations instead of the 11-instruction division
+// sequence: q = fma(x, zh, x * zl) with zh = RN(1/C), zl = RN(1/C - zh) (Brisebarre, Muller, Raina:
+// "Accelerating correctly rounded floating-point division when the divisor is known in advance").
+// For C = total_mass = 0x1.19999ap+0 the result equals IEEE x / C for EVERY float with |x| >= 2^-104
+// (and for +-0, +-inf, NaN): checked exhaustively over all 2^23 significands per binade by the CPU tests.
+// Below 2^-104 (4.9e-32) the x*zl term goes subnormal and the last bit can differ.
+template <typename Dummy = void>
+struct DivByTotalMass {
+    static constexpr float C = 0.1f + 1.0f;
+    static constexpr float ZH = 1.0f / C;
+    static constexpr float ZL = (float)(1.0 / (double)C - (double)ZH);
+    __device__ __forceinline__ static float apply(float x) { return fmaf(x, ZH, x * ZL); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // CartPole-v1  (CartPoleEnv.cs)
 // ---------------------------------------------------------------------------------------------
 struct CartPole {
@@ -38,16 +85,19 @@ struct CartPole {
     static constexpr float theta_threshold = 0.20943951606750488f;   // (float)(12*2*Math.PI/360) = 0x1.aceeap-3
     static constexpr float x_threshold = 2.4f;
 
+    __device__ __forceinline__ static float div_tm(float x) { return DivByTotalMass<>::apply(x); }
+
     // :146-167.  Any action != 1 pushes left (validity is only Debug.Assert'ed, :139).
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const float force = (a == 1) ? force_mag : -force_mag;                                   // :146
         float sintheta, costheta;
-        sincosf(theta, &sintheta, &costheta);                                                    // :147-148
-        const float temp = (force + polemass_length * theta_dot * theta_dot * sintheta) / total_mass;   // :149
+        sincos_f32(theta, sintheta, costheta);                                                   // :147-148
+        // `/ total_mass` below is IEEE division by a constant, evaluated as DivByTotalMass (bit-identical)
+        const float temp = div_tm(force + polemass_length * theta_dot * theta_dot * sintheta);   // :149
         const float thetaacc = (gravity * sintheta - costheta * temp)
-                               / (length * (4.0f / 3.0f - masspole * costheta * costheta / total_mass)); // :150
-        const float xacc = temp - polemass_length * thetaacc * costheta / total_mass;            // :151
+                               / (length * (4.0f / 3.0f - div_tm(masspole * costheta * costheta))); // :150
+        const float xacc = temp - div_tm(polemass_length * thetaacc * costheta);                // :151
         // explicit Euler (:32,153-158): positions advance with the OLD velocities
         const float nx = x + tau * x_dot;
         const float nx_dot = x_dot + tau * xacc;
@@ -94,7 +144,7 @@ struct Pendulum {
         const float u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
         const float nrm = floored_mod(th + PI, 2.0f * PI) - PI;
         const float costs = nrm * nrm + 0.1f * (thdot * thdot) + 0.001f * (u * u);
-        float newthdot = thdot + (15.0f * sinf(th) + 3.0f * u) * dt;     // 3g/(2l) = 15, 3/(m l^2) = 3
+        float newthdot = thdot + (15.0f * sin_f32(th) + 3.0f * u) * dt;     // 3g/(2l) = 15, 3/(m l^2) = 3
         newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
         const float newth = th + newthdot * dt;
         s[0] = newth; s[1] = newthdot;
@@ -108,7 +158,9 @@ struct Pendulum {
     }
 
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
-        o[0] = cosf(s[0]); o[1] = sinf(s[0]); o[2] = s[1];
+        float sn, cs;
+        sincos_f32(s[0], sn, cs);
+        o[0] = cs; o[1] = sn; o[2] = s[1];
     }
 };
 
@@ -125,7 +177,7 @@ struct MountainCar {
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         float p = s[0], v = s[1];
-        v += (float)(a - 1) * 0.001f + cosf(3.0f * p) * (-0.0025f);
+        v += (float)(a - 1) * 0.001f + cos_f32(3.0f * p) * (-0.0025f);
         v = v < -0.07f ? -0.07f : (v > 0.07f ? 0.07f : v);
         p += v;
         p = p < -1.2f ? -1.2f : (p > 0.6f ? 0.6f : p);
@@ -159,11 +211,11 @@ struct Acrobot {
     __device__ __forceinline__ static void dsdt(const float (&s)[4], float torque, float (&d)[4]) {
         const float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
         float s2, c2;
-        sincosf(th2, &s2, &c2);
+        sincos_f32(th2, s2, c2);
         const float d1 = 0.25f + (1.25f + c2) + 2.0f;
         const float d2 = (0.25f + 0.5f * c2) + 1.0f;
-        const float phi2 = 4.9f * cosf(th1 + th2 - PI / 2.0f);
-        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * cosf(th1 - PI / 2.0f) + phi2;
+        const float phi2 = 4.9f * cos_f32(th1 + th2 - PI / 2.0f);
+        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * cos_f32(th1 - PI / 2.0f) + phi2;
         const float ddth2 = (torque + d2 / d1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 / d1);
         const float ddth1 = -(d2 * ddth2 + phi1) / d1;
         d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
@@ -199,7 +251,7 @@ struct Acrobot {
         y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = y[i];
-        done = (-cosf(y[0]) - cosf(y[1] + y[0])) > 1.0f;
+        done = (-cos_f32(y[0]) - cos_f32(y[1] + y[0])) > 1.0f;
         reward = done ? 0.0f : -1.0f;
     }
 
@@ -210,8 +262,8 @@ struct Acrobot {
 
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
         float s1, c1, s2, c2;
-        sincosf(s[0], &s1, &c1);
-        sincosf(s[1], &s2, &c2);
+        sincos_f32(s[0], s1, c1);
+        sincos_f32(s[1], s2, c2);
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
     }
 };

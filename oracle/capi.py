@@ -43,6 +43,11 @@ def lib():
     L.ref_cartpole_step_f32.restype = C.c_int
     L.ref_cartpole_step_batch_f64.argtypes = [_f64p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
     L.ref_cartpole_step_batch_f32.argtypes = [_f32p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
+    L.ref_sincos_f32_kernel.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ref_div_total_mass_kernel.argtypes = [C.c_float]
+    L.ref_div_total_mass_kernel.restype = C.c_float
+    L.ref_check_div_total_mass.argtypes = [_i32p, C.c_int32]
+    L.ref_check_div_total_mass.restype = C.c_int64
     L.ref_discrete_contains.argtypes = [C.c_int, C.c_int]
     L.ref_discrete_contains.restype = C.c_int
     L.ref_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
@@ -94,6 +99,23 @@ def cartpole_step(state, action, sbd=None, dtype=np.float64):
     else:
         lib().ref_cartpole_step_batch_f32(s, a, b, reward, done, n)
     return s, reward, done, b
+
+
+def sincos_kernel(x):
+    """The kernels' sin/cos restated on the CPU (bit-identical to the GPU for |x| <= 65536)."""
+    x = np.asarray(x, dtype=np.float32).reshape(-1)
+    s = np.empty_like(x); c = np.empty_like(x)
+    fs, fc = C.c_float(), C.c_float()
+    L = lib()
+    for i, v in enumerate(x):
+        L.ref_sincos_f32_kernel(float(v), C.byref(fs), C.byref(fc))
+        s[i], c[i] = fs.value, fc.value
+    return s, c
+
+
+def check_div_total_mass(biased_exponents):
+    e = np.ascontiguousarray(np.asarray(biased_exponents, dtype=np.int32))
+    return int(lib().ref_check_div_total_mass(e, e.shape[0]))
 
 
 def philox4x32_10(ctr, key):

@@ -88,16 +88,64 @@ int ref_cartpole_step_f64(double *state, int action, int *sbd, float *reward) {
     return done;
 }
 
+/* The HIP kernels' sin/cos (gym.net_amd/csrc/envs.hpp: sincos_f32), restated operation for operation: 3-constant
+ * Cody-Waite reduction + minimax polynomials, only IEEE mul / fma / rint => bit-identical on CPU and GPU.
+ * |x| > 65536 falls back to libm here (OCML on the GPU): outside that range the two may differ by an ulp. */
+void ref_sincos_f32_kernel(float x, float *s_out, float *c_out) {
+    if (fabsf(x) > 65536.0f) { *s_out = sinf(x); *c_out = cosf(x); return; }
+    const float n = rintf(x * 0.636619772367581343f);
+    float r = fmaf(n, -1.5703125f, x);
+    r = fmaf(n, -4.837512969970703125e-4f, r);
+    r = fmaf(n, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)n & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *s_out = (q & 2) ? -ss : ss;
+    *c_out = ((q + 1) & 2) ? -cc : cc;
+}
+static inline float ksin(float x) { float s, c; ref_sincos_f32_kernel(x, &s, &c); return s; }
+static inline float kcos(float x) { float s, c; ref_sincos_f32_kernel(x, &s, &c); return c; }
+
+/* x / total_mass the way the kernel evaluates it: fma(x, zh, x*zl), zh = RN(1/C), zl = RN(1/C - zh).
+ * Exposed so that tests can check it against IEEE division exhaustively. */
+float ref_div_total_mass_kernel(float x) {
+    const float C = CP_TOTAL_MASS;
+    const float zh = 1.0f / C;
+    const float zl = (float)(1.0 / (double)C - (double)zh);
+    return fmaf(x, zh, x * zl);
+}
+
+/* Exhaustive check: every significand, the given biased exponents.  Returns the number of x for which
+ * the kernel's constant division differs from IEEE x / total_mass. */
+int64_t ref_check_div_total_mass(const int32_t *biased_exponents, int32_t count) {
+    int64_t bad = 0;
+    for (int32_t e = 0; e < count; ++e)
+        for (uint32_t m = 0; m < (1u << 23); ++m) {
+            union { uint32_t u; float f; } v;
+            v.u = ((uint32_t)biased_exponents[e] << 23) | m;
+            if (ref_div_total_mass_kernel(v.f) != v.f / CP_TOTAL_MASS) ++bad;
+            if (ref_div_total_mass_kernel(-v.f) != -v.f / CP_TOTAL_MASS) ++bad;
+        }
+    return bad;
+}
+
 /* The same Step() in the HIP kernel's arithmetic: every operation in binary32 with the same
- * binary32 constants (4.0f/3.0f for the double literal), same association order, thresholds
- * compared in binary32.  This is NOT the reference's arithmetic; it exists so tests can bound
- * the kernel tightly (a few ulp, sinf/cosf implementations differ) in addition to the
+ * binary32 constants (4.0f/3.0f for the double literal), same association order, the kernel's own
+ * sin/cos, thresholds compared in binary32.  This is NOT the reference's arithmetic; it exists so
+ * tests can require the kernel to match it BIT FOR BIT (all operations are IEEE on both sides; the
+ * kernel's constant divisions are proven equal to the plain `/` written here), in addition to the
  * north_star bar of 1e-5 against ref_cartpole_step_f64. */
 int ref_cartpole_step_f32(float *state, int action, int *sbd, float *reward) {
     float x = state[0], x_dot = state[1], theta = state[2], theta_dot = state[3];
     float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
-    float costheta = cosf(theta);
-    float sintheta = sinf(theta);
+    float costheta, sintheta;
+    ref_sincos_f32_kernel(theta, &sintheta, &costheta);
     float temp = (force + CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / CP_TOTAL_MASS;
     float thetaacc = (CP_GRAVITY * sintheta - costheta * temp)
                      / (CP_LENGTH * (4.0f / 3.0f - CP_MASSPOLE * costheta * costheta / CP_TOTAL_MASS));
@@ -247,11 +295,11 @@ void ref_pendulum_step_f32(float *state, float a, float *obs3, float *reward) {
     float u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
     float nrm = floored_mod_f(th + PI_F, 2.0f * PI_F) - PI_F;
     float costs = nrm * nrm + 0.1f * (thdot * thdot) + 0.001f * (u * u);
-    float newthdot = thdot + (15.0f * sinf(th) + 3.0f * u) * dt;   /* 3g/(2l) = 15, 3/(m l^2) = 3 */
+    float newthdot = thdot + (15.0f * ksin(th) + 3.0f * u) * dt;   /* 3g/(2l) = 15, 3/(m l^2) = 3 */
     newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
     float newth = th + newthdot * dt;
     state[0] = newth; state[1] = newthdot;
-    obs3[0] = cosf(newth); obs3[1] = sinf(newth); obs3[2] = newthdot;
+    ref_sincos_f32_kernel(newth, &obs3[1], &obs3[0]); obs3[2] = newthdot;
     *reward = -costs;
 }
 
@@ -277,7 +325,7 @@ int ref_mountaincar_step_f64(double *state, int a, double *reward) {
 
 int ref_mountaincar_step_f32(float *state, int a, float *reward) {
     float p = state[0], v = state[1];
-    v += (float)(a - 1) * 0.001f + cosf(3.0f * p) * (-0.0025f);
+    v += (float)(a - 1) * 0.001f + kcos(3.0f * p) * (-0.0025f);
     v = v < -0.07f ? -0.07f : (v > 0.07f ? 0.07f : v);
     p += v;
     p = p < -1.2f ? -1.2f : (p > 0.6f ? 0.6f : p);
@@ -344,12 +392,13 @@ int ref_acrobot_step_f64(double *state, int a, double *obs6, double *reward) {
 static void acrobot_dsdt_f32(const float s[4], float tau, float d[4]) {
     /* constants folded: m1=m2=l1=I1=I2=1, lc1=lc2=0.5, g=9.8 */
     float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
-    float c2 = cosf(th2), s2 = sinf(th2);
+    float c2, s2;
+    ref_sincos_f32_kernel(th2, &s2, &c2);
     float d1 = 0.25f + (1.25f + c2) + 2.0f;          /* m1 lc1^2 + m2 (l1^2+lc2^2+2 l1 lc2 c2) + I1 + I2 */
     float d2 = (0.25f + 0.5f * c2) + 1.0f;           /* m2 (lc2^2 + l1 lc2 c2) + I2 */
-    float phi2 = 4.9f * cosf(th1 + th2 - PI_F / 2.0f);                 /* m2 lc2 g = 4.9 */
+    float phi2 = 4.9f * kcos(th1 + th2 - PI_F / 2.0f);                 /* m2 lc2 g = 4.9 */
     float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2    /* m2 l1 lc2 = 0.5; 2 m2 l1 lc2 = 1 */
-                 + 14.7f * cosf(th1 - PI_F / 2.0f) + phi2;             /* (m1 lc1 + m2 l1) g = 14.7 */
+                 + 14.7f * kcos(th1 - PI_F / 2.0f) + phi2;             /* (m1 lc1 + m2 l1) g = 14.7 */
     float ddth2 = (tau + d2 / d1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2)
                   / (1.25f - d2 * d2 / d1);                            /* m2 lc2^2 + I2 = 1.25 */
     float ddth1 = -(d2 * ddth2 + phi1) / d1;
@@ -380,9 +429,9 @@ int ref_acrobot_step_f32(float *state, int a, float *obs6, float *reward) {
     y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
     y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
     for (int i = 0; i < 4; ++i) state[i] = y[i];
-    int done = (-cosf(y[0]) - cosf(y[1] + y[0])) > 1.0f;
+    int done = (-kcos(y[0]) - kcos(y[1] + y[0])) > 1.0f;
     *reward = done ? 0.0f : -1.0f;
-    obs6[0] = cosf(y[0]); obs6[1] = sinf(y[0]); obs6[2] = cosf(y[1]); obs6[3] = sinf(y[1]);
+    ref_sincos_f32_kernel(y[0], &obs6[1], &obs6[0]); ref_sincos_f32_kernel(y[1], &obs6[3], &obs6[2]);
     obs6[4] = y[2]; obs6[5] = y[3];
     return done;
 }

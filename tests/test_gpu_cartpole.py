@@ -402,3 +402,31 @@ def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
         assert len(same) == 6 and same[0][2] > 0
         for r in same[1:]:
             assert np.array_equal(r[1], same[0][1], equal_nan=True) and r[2] == same[0][2]
+
+
+def test_kernel_is_bit_identical_to_the_float32_restatement(gpu_pkg, oracle):
+    """Beyond the 1e-5 bar: the kernel's float32 arithmetic (IEEE mul/add/fma/div, its own Cody-Waite sin/cos,
+    constant division as fma pairs) is restated operation for operation in the oracle's "kernel semantics"
+    functions, so states, rewards and done flags must agree BIT FOR BIT — at the full 2^20 batch."""
+    n = 1 << 20
+    rng = np.random.default_rng(21)
+    s = _states(rng, n, wide=True)
+    s[2, ::7] = rng.uniform(-30, 30, s[2, ::7].shape).astype(np.float32)       # large angles: all four quadrants
+    s[3, ::5] = rng.uniform(-40, 40, s[3, ::5].shape).astype(np.float32)
+    a = rng.integers(0, 2, n).astype(np.int32)
+    want_s, want_r, want_d, want_b = oracle.cartpole_step(s, a, dtype=np.float32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as env:
+        env.Reset(); env.SetState(s)
+        out = env.Step(a)
+        assert np.array_equal(env.GetState(), want_s)
+        assert np.array_equal(out.Done, want_d.astype(bool)) and np.array_equal(out.Reward, want_r)
+        assert np.array_equal(env.GetStepsBeyondDone(), want_b)
+        # and a free-running rollout stays bit-identical step after step (no drift between the two float32 paths)
+        cur = want_s
+        sbd = want_b
+        for t in range(10):
+            a = rng.integers(0, 2, n).astype(np.int32)
+            cur, r, d, sbd = oracle.cartpole_step(cur, a, sbd, dtype=np.float32)
+            out = env.Step(a)
+            assert np.array_equal(out.Reward, r) and np.array_equal(out.Done, d.astype(bool))
+        assert np.array_equal(env.GetState(), cur, equal_nan=True)

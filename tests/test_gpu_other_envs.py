@@ -89,3 +89,31 @@ def test_autoreset_rollout_stays_in_bounds_and_matches_f32_oracle(gpu_pkg, oracl
             got = env.GetState()[:, sub]
             if keep.any():
                 assert np.abs(got[:, keep] - ref[0][:, keep]).max() <= 3e-5
+
+
+@pytest.mark.parametrize("name", ["Pendulum-v1", "MountainCar-v0", "Acrobot-v1"])
+def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name):
+    # same claim as for CartPole: every float32 operation of the kernel is restated in the oracle's
+    # kernel-semantics functions (own sin/cos, IEEE ops) => bit-for-bit equal states, observations, flags
+    n = 4096
+    rng = np.random.default_rng(31)
+    if name == "Pendulum-v1":
+        s = np.stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n)]).astype(np.float32)
+        a = rng.uniform(-2.5, 2.5, n).astype(np.float32)
+        want = oracle.pendulum_step(s, a, dtype=np.float32)
+        ws, wo, wr, wd = want
+    elif name == "MountainCar-v0":
+        s = np.stack([rng.uniform(-1.2, 0.6, n), rng.uniform(-0.07, 0.07, n)]).astype(np.float32)
+        a = rng.integers(0, 3, n).astype(np.int32)
+        ws, wr, wd = oracle.mountaincar_step(s, a, dtype=np.float32)
+        wo = ws
+    else:
+        s = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
+        a = rng.integers(0, 3, n).astype(np.int32)
+        ws, wo, wr, wd = oracle.acrobot_step(s, a, dtype=np.float32)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED) as env:
+        env.Reset(); env.SetState(s)
+        out = env.Step(a)
+        assert np.array_equal(env.GetState(), ws)
+        assert np.array_equal(out.Observation, wo.T)
+        assert np.array_equal(out.Reward, wr.astype(np.float32)) and np.array_equal(out.Done, wd.astype(bool))

@@ -250,3 +250,35 @@ def test_cpu_baseline_runs_and_counts(oracle):
     assert r["env_steps"] == 4096 * 16 and r["seconds"] > 0 and r["dones"] >= 0
     r2 = oracle.cpu_baseline(4096, 16, 2, alloc_faithful=False)
     assert r2["checksum"] == r["checksum"]       # same arithmetic with and without the allocations
+
+
+# ------------------------------------------------------------------------------------------------
+# The kernel's two "cheap arithmetic" substitutions, proven / bounded on the CPU where the same IEEE
+# operations (mul, fma, rint) give the same bits as on the GPU.
+# ------------------------------------------------------------------------------------------------
+def test_kernel_constant_division_equals_ieee_division_exhaustively(oracle):
+    # fma(x, RN(1/C), x*RN(1/C - RN(1/C))) == x / C for C = total_mass: every one of the 2^23 significands,
+    # both signs, for every binade from 2^-104 up (biased exponent >= 23; a sample of binades, each complete)
+    assert oracle.check_div_total_mass([23, 24, 40, 60, 100, 126, 127, 128, 129, 150, 200, 253]) == 0
+    # ...and it is NOT exact below that (the x*zl term goes subnormal): documented limit of the claim
+    assert oracle.check_div_total_mass([22]) > 0 and oracle.check_div_total_mass([1]) > 0
+    for v in (0.0, -0.0, np.inf, -np.inf):
+        got = oracle.lib().ref_div_total_mass_kernel(v)
+        assert got == v and np.signbit(got) == np.signbit(v)
+    assert np.isnan(oracle.lib().ref_div_total_mass_kernel(float("nan")))
+
+
+def test_kernel_sincos_accuracy(oracle):
+    rng = np.random.default_rng(4)
+    for lo, hi, abs_bar in ((0.0, 0.3, 7e-8), (0.0, 10.0, 1e-7), (10.0, 65536.0, 1e-7)):
+        x = np.concatenate([rng.uniform(lo, hi, 40_000), -rng.uniform(lo, hi, 40_000)]).astype(f32)
+        s, c = oracle.sincos_kernel(x)
+        xs = x.astype(np.float64)
+        assert np.abs(s - np.sin(xs)).max() <= abs_bar and np.abs(c - np.cos(xs)).max() <= abs_bar
+    s, c = oracle.sincos_kernel(np.array([0.0, -0.0], dtype=f32))
+    assert s[0] == 0.0 and c[0] == 1.0 and s[1] == 0.0 and c[1] == 1.0     # sin(-0) = +0 (documented)
+    x = rng.uniform(-4, 4, 20_000).astype(f32)                     # odd / even symmetry is exact
+    s1, c1 = oracle.sincos_kernel(x); s2, c2 = oracle.sincos_kernel(-x)
+    assert np.array_equal(s1, -s2) and np.array_equal(c1, c2)
+    s, c = oracle.sincos_kernel(np.array([np.nan, np.inf], dtype=f32))
+    assert np.isnan(s).all() and np.isnan(c).all()

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(BLOCK) void k_step(const Args a) {
     float reward[VEC];
     uint8_t done[VEC];
     uint32_t pending = 0;
+    // RESET 3 = speculative: every sub-lane's reset draw is computed while the loads are still in flight
+    float spec[VEC][4];
+    if constexpr (MODE == 0 && RESET == 3) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const PhiloxWords r = lane_words(a.seed, (uint64_t)(i0 + j), tick);
+            CartPole::reset(spec[j], r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         if constexpr (MODE == 1) {
@@ -117,6 +127,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(const Args a) {
             float sj[4] = {s[0][j], s[1][j], s[2][j], s[3][j]};
             bool dn; float rw;
             CartPole::step(sj, act[j], rw, dn);
+            if constexpr (MODE >= 3) { CartPole::step(sj, act[j], rw, dn); }      // ALU-scaling experiment: 2x physics
+            if constexpr (MODE >= 4) { CartPole::step(sj, act[j], rw, dn); }      // 3x physics
             reward[j] = rw; done[j] = dn ? 1 : 0;
             if constexpr (MODE == 0 && RESET == 0) {
                 if (dn) {
@@ -125,6 +137,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(const Args a) {
                 }
             }
             if constexpr (MODE == 0 && RESET == 1) pending |= dn ? (1u << j) : 0u;
+            if constexpr (MODE == 0 && RESET == 3) {
+                sj[0] = dn ? spec[j][0] : sj[0]; sj[1] = dn ? spec[j][1] : sj[1];
+                sj[2] = dn ? spec[j][2] : sj[2]; sj[3] = dn ? spec[j][3] : sj[3];
+            }
             s[0][j] = sj[0]; s[1][j] = sj[1]; s[2][j] = sj[2]; s[3][j] = sj[3];
         }
     }
@@ -309,6 +325,11 @@ int main(int argc, char **argv) {
     ADD("base    vec4 b256 reset=divergent ", (L<4, 256, 0, 0, 0>));
     ADD("loop    vec4 b256                 ", (L<4, 256, 0, 1, 0>));
     ADD("SHIPPED vec4 nt=all               ", (LPROD<4, 15>));
+    ADD("noreset vec4 b256 nt=all 2x phys  ", (L<4, 256, 3, 0, 15>));
+    ADD("noreset vec4 b256 nt=all 3x phys  ", (L<4, 256, 4, 0, 15>));
+    ADD("spec    vec4 b256 nt=all          ", (L<4, 256, 0, 3, 15>));
+    ADD("spec    vec2 b256 nt=all          ", (L<2, 256, 0, 3, 15>));
+    ADD("spec    vec4 b256 nt=none         ", (L<4, 256, 0, 3, 0>));
     ADD("SHIPPED vec4 nt=streams           ", (LPROD<4, 12>));
     ADD("SHIPPED vec4 nt=none              ", (LPROD<4, 0>));
     ADD("SHIPPED vec1 nt=all               ", (LPROD<1, 15>));
