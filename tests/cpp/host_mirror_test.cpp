@@ -1,0 +1,161 @@
+// tests/cpp/host_mirror_test.cpp — exercises include/gymnet_amd.hpp (the compiled host mirror of the reference
+// interface) against libgymnet_amd.so.  `--cpu`: space / error semantics, no GPU needed (mirrors
+// tests/Gym.Tests/Spaces/BoxTest.cs:14-42).  `--gpu`: the reference's own loop shapes
+// (tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:19-27, README.md:32-52) and parity checks through the
+// C++ classes.  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "gymnet_amd.hpp"
+
+static int g_failed = 0;
+#define CHECK(cond, msg)                                                          \
+    do {                                                                          \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s  [%s]\n", __FILE__, __LINE__, #cond, msg); ++g_failed; } \
+    } while (0)
+
+template <class Ex, class F>
+static bool throws(F f) {
+    try { f(); } catch (const Ex &) { return true; } catch (...) { return false; }
+    return false;
+}
+
+static void cpu_tests() {
+    using gymnet::Box;
+    const float inf = std::numeric_limits<float>::infinity();
+    {   // BoxTest.TestBoxBoundedTest (BoxTest.cs:14-33)
+        Box a(-5.0f, 5.0f);
+        CHECK(a.IsBounded(Box::BoundedManner::Both), "Box should be bounded at both boundaries.");
+        Box b(-inf, 5.0f);
+        CHECK(!b.IsBounded(Box::BoundedManner::Below) && b.IsBounded(Box::BoundedManner::Above) && !b.IsBounded(), "unbound low");
+        Box c(5.0f, inf);
+        CHECK(!c.IsBounded(Box::BoundedManner::Above) && c.IsBounded(Box::BoundedManner::Below) && !c.IsBounded(), "unbound high");
+        Box d(-inf, inf);
+        CHECK(!d.IsBounded(Box::BoundedManner::Above) && !d.IsBounded(Box::BoundedManner::Below) && !d.IsBounded(), "unbounded");
+    }
+    {   // BoxTest.TestBoxBoundedSampling (BoxTest.cs:36-41)
+        Box box(-5.0f, 5.0f, 1, 3);
+        for (int i = 0; i < 200; ++i) { float s = box.Sample()[0]; CHECK(s >= -5.0f && s <= 5.0f, "Box sampling should be on the range [-5.0,5.0]"); }
+        Box lo(std::vector<float>{2.0f, -inf}, std::vector<float>{inf, 7.0f}, 1);
+        for (int i = 0; i < 200; ++i) { auto s = lo.Sample(); CHECK(s[0] >= 2.0f && s[1] >= 7.0f, "one-sided regimes as the reference writes them (Box.cs:83-84)"); }
+        CHECK(lo.Contains({3.0f, 1.0f}) && !lo.Contains({1.0f, 1.0f}), "Box.Contains");
+    }
+    {   // Discrete.Contains (Discrete.cs:38-40)
+        gymnet::Discrete d(2, 5);
+        CHECK(d.Contains(0) && d.Contains(1) && !d.Contains(2) && !d.Contains(-1), "0 <= x < N");
+        bool saw0 = false, saw1 = false;
+        for (int i = 0; i < 64; ++i) { int s = d.Sample(); saw0 |= s == 0; saw1 |= s == 1; CHECK(s == 0 || s == 1, "sample in range"); }
+        CHECK(saw0 && saw1, "both values sampled");
+        CHECK(gymnet::Discrete(3, 1, 10).Sample({0, 0, 1}) == 12 && gymnet::Discrete(3, 1, 10).Sample({0, 0, 0}) == 10, "masked sample");
+    }
+    CHECK(std::string(gymnet_status_string(GYMNET_ERR_INVALID_ACTION)) == "Action is outside of the configured action space.", "InvalidActionError text");
+    CHECK(std::string(gymnet::AlreadySteppingError().what()) == "already running an async step", "AlreadySteppingError text");
+    CHECK(gymnet_abi_version() == GYMNET_ABI_VERSION, "abi version");
+    gymnet_env_info info{};
+    gymnet::check(gymnet_env_describe(GYMNET_ENV_CARTPOLE, &info));
+    CHECK(info.obs_dim == 4 && info.action_n == 2 && info.algorithmic_bytes_per_step == 41, "CartPole description");
+    CHECK(throws<std::invalid_argument>([] { gymnet_env_info i{}; gymnet::check(gymnet_env_describe(42, &i)); }), "bad env id -> ArgumentException");
+    int ndev = 0;
+    if (gymnet_device_count(&ndev) != GYMNET_OK) {
+        // no GPU here: the engine must refuse loudly, never fall back to a CPU path
+        CHECK(ndev == 0, "count reported as 0");
+        CHECK(throws<gymnet::NoDeviceError>([] { gymnet::VectorEnv e(GYMNET_ENV_CARTPOLE, 16); }), "no device -> NoDeviceError");
+        CHECK(throws<gymnet::NoDeviceError>([] { gymnet::CartPoleEnv e; }), "no device -> NoDeviceError (single env)");
+    }
+}
+
+// CartPoleEnv.Step restated in double for one state (CartPoleEnv.cs:24-36,146-167) — the test's own closed form
+static void ref_step(const double s[4], int action, double out[4], bool &done) {
+    const double g = (double)9.8f, mp = (double)0.1f, M = (double)(0.1f + 1.0f), L = 0.5, pml = (double)(0.1f * 0.5f);
+    const double tau = (double)0.02f, xt = (double)2.4f, tt = (double)(float)(24.0 * M_PI / 360.0);
+    const double force = action == 1 ? 10.0 : -10.0, c = std::cos(s[2]), sn = std::sin(s[2]);
+    const double temp = (force + pml * s[3] * s[3] * sn) / M;
+    const double thetaacc = (g * sn - c * temp) / (L * (4.0 / 3.0 - mp * c * c / M));
+    const double xacc = temp - pml * thetaacc * c / M;
+    out[0] = s[0] + tau * s[1]; out[1] = s[1] + tau * xacc; out[2] = s[2] + tau * s[3]; out[3] = s[3] + tau * thetaacc;
+    done = out[0] < -xt || out[0] > xt || out[2] < -tt || out[2] > tt;
+}
+
+static void gpu_tests() {
+    {   // the reference's test loop: 1000 x (Reset if done else Step(i % 2)), CartpoleEnvironment.cs:19-27
+        gymnet::CartPoleEnv cp(0, 1234);
+        bool done = true;
+        int episodes = 0, steps = 0;
+        for (int i = 0; i < 1000; ++i) {
+            if (done) { auto obs = cp.Reset(); CHECK(obs.size() == 4, "Reset() -> NDArray[4]"); done = false; ++episodes;
+                        for (float v : obs) CHECK(v >= -0.05f && v < 0.05f, "reset ~ U(-0.05, 0.05)"); }
+            else { gymnet::Step st = cp.Step(i % 2); done = st.Done; ++steps; CHECK(st.Reward == 1.0f && st.Observation.size() == 4, "reward 1 until reset"); }
+        }
+        CHECK(episodes > 10 && episodes < 80 && steps + episodes == 1000, "alternating-action episodes average ~37 steps");
+        cp.CloseEnvironment();
+    }
+    {   // teacher-forced single steps vs the double closed form: |err| <= 1e-5, done exact (north_star bar)
+        const int64_t n = 4096;
+        gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, n, 0, 7);
+        env.Reset();
+        std::vector<float> s((size_t)4 * n);
+        std::mt19937 rng(5);
+        std::uniform_real_distribution<float> ux(-2.6f, 2.6f), uv(-2.5f, 2.5f), ut(-0.23f, 0.23f);
+        for (int64_t i = 0; i < n; ++i) { s[i] = ux(rng); s[n + i] = uv(rng); s[2 * n + i] = ut(rng); s[3 * n + i] = uv(rng); }
+        std::vector<int32_t> a((size_t)n);
+        for (auto &v : a) v = (int32_t)(rng() & 1u);
+        env.SetState(s);
+        gymnet::BatchStep out = env.Step(a);
+        auto got = env.GetState();
+        double worst = 0; int mism = 0, ndone = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const double in[4] = {s[i], s[n + i], s[2 * n + i], s[3 * n + i]};
+            double want[4]; bool d;
+            ref_step(in, a[i], want, d);
+            for (int k = 0; k < 4; ++k) worst = std::fmax(worst, std::fabs((double)got[k * n + i] - want[k]));
+            const bool near = std::fabs(std::fabs(want[0]) - (double)2.4f) < 1e-6 || std::fabs(std::fabs(want[2]) - (double)(float)(24.0 * M_PI / 360.0)) < 1e-6;
+            if (!near && d != (out.Done[i] != 0)) ++mism;
+            ndone += d;
+            for (int k = 0; k < 4; ++k) CHECK(out.Observation[i * 4 + k] == got[k * n + i], "observation is the new state, row-major [N,4]");
+            CHECK(out.Reward[i] == 1.0f, "first done still pays 1");
+        }
+        CHECK(worst <= 1e-5, "state within 1e-5 of the float64 reference arithmetic");
+        CHECK(mism == 0 && ndone > 0 && ndone < n, "done flags exact");
+    }
+    {   // steps_beyond_done reward stream (CartPoleEnv.cs:168-183) through IVecEnv.Step(int)
+        gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 3, 0, 1);
+        env.Reset();
+        env.SetState({0, 0, 0, 0, 0, 0, 0.05f, 0.05f, 0.05f, 0, 0, 0});
+        int after = 0; bool seen = false;
+        for (int t = 0; t < 40 && after < 3; ++t) {
+            auto out = env.Step(1);
+            if (out.Done[0]) { CHECK(out.Reward[0] == (seen ? 0.0f : 1.0f), "1 on the falling step, 0 afterwards"); if (seen) ++after; seen = true; }
+            else CHECK(out.Reward[0] == 1.0f && !seen, "1 while alive");
+        }
+        CHECK(seen && after == 3, "pole fell and was stepped past done");
+        CHECK(env.GetStepsBeyondDone()[0] == 3 && env.Counters().stepped_after_done == 9, "sbd counts; warning counted, not printed");
+    }
+    {   // error behaviour
+        gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_VALIDATE_ACTIONS);
+        env.Reset();
+        CHECK(throws<gymnet::InvalidActionError>([&] { env.Step(2); }), "InvalidActionError (LunarLanderEnv.cs:604-607 convention)");
+        CHECK(throws<std::invalid_argument>([&] { env.Seed(std::vector<int>{1, 2, 3}); }), "seed count mismatch -> ArgumentException (VecEnv.cs:49)");
+        CHECK(throws<std::invalid_argument>([&] { env.Step(std::vector<int32_t>{1, 0}); }), "action count mismatch");
+        CHECK(throws<gymnet::NotSteppingError>([&] { env.StepWait(); }), "NotSteppingError");
+        env.StepAsync(std::vector<int32_t>(8, 1));
+        CHECK(throws<gymnet::AlreadySteppingError>([&] { env.StepAsync(std::vector<int32_t>(8, 0)); }), "AlreadySteppingError");
+        auto out = env.StepWait();
+        CHECK(out.size() == 8 && out[0].Observation.size() == 4, "StepWait returns the batch");
+        CHECK(throws<std::invalid_argument>([] { gymnet::VectorEnv bad(GYMNET_ENV_CARTPOLE, 0); }), "num_envs 0 -> ArgumentException");
+    }
+}
+
+int main(int argc, char **argv) {
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
+    try {
+        cpu_tests();
+        if (gpu) gpu_tests();
+    } catch (const std::exception &e) {
+        std::printf("FAIL unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf("%s: %d failed check(s)\n", gpu ? "cpu+gpu" : "cpu", g_failed);
+    return g_failed ? 1 : 0;
+}
