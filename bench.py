@@ -143,6 +143,23 @@ def main():
     c = local.Counters()
     assert c["lane_steps"] == (K + W) * n, c
 
+    # Secondary figure, NOT the headline: the same K steps fused into one launch per `ring` steps (state stays in
+    # registers, gymnet_vecenv_rollout_fused_device) — open-loop rollouts only, so it is reported beside, not as, `value`.
+    fused = None
+    if not args.allgather:
+        fsteps = max(ring, (min(K, 2048) // ring) * ring)
+        local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
+        torch.cuda.synchronize(dev)
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for _ in range(fsteps // ring):
+            local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
+        f1.record(stream)
+        torch.cuda.synchronize(dev)
+        fused_us = f0.elapsed_time(f1) * 1e3 / fsteps
+        fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
+                 "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
+
     if rank == 0:
         bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
         launch_us = ev_ms * 1e3 / K                                          # HIP events over the timed region / launches
@@ -168,6 +185,8 @@ def main():
                          "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us},
         }
+        if fused:
+            out["fused_rollout"] = fused
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -63,6 +63,10 @@ class DeviceView(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+class RolloutBuffers(C.Structure):
+    _fields_ = [("d_obs", C.c_void_p), ("d_reward", C.c_void_p), ("d_done", C.c_void_p)]
+
+
 class Counters(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("tick", C.c_uint64),
                 ("lane_steps", C.c_uint64), ("stepped_after_done", C.c_uint64),
@@ -94,6 +98,7 @@ PROTOTYPES = {
     "gymnet_vecenv_reset_where_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_step_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_rollout_device": (C.c_int, [_H, _P, C.c_int64, C.c_int64, C.c_int64]),
+    "gymnet_vecenv_rollout_fused_device": (C.c_int, [_H, _P, C.c_int64, C.c_int64, C.c_int64, C.POINTER(RolloutBuffers)]),
     "gymnet_vecenv_pack_obs_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_sync": (C.c_int, [_H]),
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),

@@ -86,6 +86,7 @@ struct gymnet_vecenv {
     unsigned long long *d_after_done = nullptr;
     uint32_t *d_bad = nullptr;
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
+    int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
     int last_cparity = -1;
     bool async_pending = false;
     std::atomic<bool> busy{false};
@@ -174,7 +175,7 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.n = h->n; a.state_stride = h->sstride; a.obs_stride = h->ostride;
     a.lane_offset = (uint64_t)h->cfg.lane_offset;
     a.seed = h->seed;
-    a.parity = (int32_t)(h->tick & 1u);
+    a.parity = (int32_t)h->tslot;
     a.cparity = (int32_t)(h->step_launches & 1u);
     a.max_episode_steps = h->cfg.max_episode_steps;
     return a;
@@ -186,6 +187,7 @@ int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
     HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
     h->last_cparity = a.cparity;
     h->tick += 1;
+    h->tslot ^= 1;
     h->step_launches += 1;
     h->lane_steps += (uint64_t)h->n;
     return GYMNET_OK;
@@ -199,9 +201,10 @@ int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
     r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
     r.n = h->n; r.state_stride = h->sstride; r.obs_stride = h->ostride;
     r.lane_offset = (uint64_t)h->cfg.lane_offset; r.seed = h->seed;
-    r.parity = (int32_t)(h->tick & 1u);
+    r.parity = (int32_t)h->tslot;
     HIP_TRY(h, launch_reset(h->cfg.env_id, r, h->stream));
     h->tick += 1;
+    h->tslot ^= 1;
     return GYMNET_OK;
 }
 
@@ -566,19 +569,20 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
     const char *force = std::getenv("GYMNET_GRAPH");
     const bool use_graph = force ? std::atoi(force) != 0 : launch_bound;
     if (use_graph && glen <= 4096 && steps >= glen) {
-        const int parity = (int)(h->tick & 1u), cparity = (int)(h->step_launches & 1u);
+        const int parity = h->tslot, cparity = (int)(h->step_launches & 1u);
         GraphEntry *ge = nullptr;
         for (auto &g : h->graphs)
             if (g.actions == d_actions && g.len == glen && g.stride == action_stride && g.ring == ring && g.parity == parity && g.cparity == cparity)
                 ge = &g;
         if (!ge) {
             const uint64_t tick0 = h->tick, sl0 = h->step_launches, ls0 = h->lane_steps;
+            const int slot0 = h->tslot;
             HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
             int s = GYMNET_OK;
             for (int64_t k = 0; k < glen && s == GYMNET_OK; ++k) s = launch_one_step(h, slice(k));
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamEndCapture(h->stream, &graph);
-            h->tick = tick0; h->step_launches = sl0; h->lane_steps = ls0;   // capturing launched nothing
+            h->tick = tick0; h->step_launches = sl0; h->lane_steps = ls0; h->tslot = slot0;   // capturing launched nothing
             if (s != GYMNET_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
             if (e != hipSuccess) return fail(h, GYMNET_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
             hipGraphExec_t exec = nullptr;
@@ -596,6 +600,30 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
         }
     }
     for (; t < steps; ++t) ST_TRY(launch_one_step(h, slice(t)));
+    return GYMNET_OK;
+}
+
+int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
+                                       int64_t ring, const gymnet_rollout_buffers *rec) {
+    ENTER(h);
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
+    if (h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no DONE_LIST / EPISODE_STATS / FINAL_OBS / per-lane-seed variant");
+    if (h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device");
+    if (steps == 0) return GYMNET_OK;
+    LaunchCfg cfg = h->lcfg;
+    const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned16(rec->d_reward)) &&
+                                 (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 3u) == 0));
+    if (cfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0 || (h->n % 4) != 0 || !rec_ok)) cfg.vec = 1;
+    StepArgs a = make_step_args(h, d_actions);
+    RolloutArgs r{};
+    r.steps = steps; r.action_stride = action_stride; r.ring = ring;
+    if (rec) { r.rec_obs = rec->d_obs; r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
+    HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
+    h->tick += (uint64_t)steps;
+    h->tslot ^= 1;                       // one launch: it read one half of d_tick2 and wrote the other
+    h->step_launches += 1;
+    h->lane_steps += (uint64_t)steps * (uint64_t)h->n;
     return GYMNET_OK;
 }
 
@@ -689,7 +717,7 @@ int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     uint64_t dtick[2] = {0, 0};
     HIP_TRY(h, hipMemcpy(dtick, h->d_tick2, sizeof dtick, hipMemcpyDeviceToHost));
-    out->tick = dtick[h->tick & 1u];   // the device's own count (== host mirror h->tick)
+    out->tick = dtick[h->tslot];   // the device's own count (== host mirror h->tick)
     out->lane_steps = h->lane_steps;
     out->stepped_after_done = ad;
     out->last_done_count = (h->d_done_count2 && h->last_cparity >= 0) ? (int64_t)cnt[h->last_cparity] : -1;

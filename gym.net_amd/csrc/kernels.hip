@@ -304,6 +304,120 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused rollout (the example's replay memory batched: ReplayMemory.cs:25-67): T vector steps in
+// ONE launch.  Each thread keeps its VEC envs in registers for all T steps, so per env-step only the action is
+// read (4 B) and — when recording — obs / reward / done are written (O*4 + 5 B): 25 B instead of 41 B for
+// CartPole, and the load-phase / store-phase serialisation of the one-step kernel disappears.  The next step's
+// action is loaded before the current step's math.  Results are bit-identical to T one-step launches.
+// ---------------------------------------------------------------------------------------------
+template <class Env, int VEC, bool AUTORESET>
+__global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const RolloutArgs ro) {
+    constexpr int S = Env::S, O = Env::O;
+    using Act = typename Env::Action;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const int64_t n = a.n;
+    const uint64_t tick0 = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
+    if (i0 >= n) return;
+
+    float s[S][VEC];
+#pragma unroll
+    for (int k = 0; k < S; ++k) load_f32<VEC, true, true>(a.state + k * a.state_stride, i0, n, s[k]);
+    int32_t sbd[VEC];
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, true, true>(a.sbd, i0, n, sbd);
+
+    auto load_action = [&](int64_t slice, Act (&dst)[VEC]) {
+        const char *base = static_cast<const char *>(a.action) + (size_t)(slice * ro.action_stride) * 4;
+        if constexpr (Env::BOX_ACTION) load_f32<VEC, true, true>(reinterpret_cast<const float *>(base), i0, n, dst);
+        else load_i32<VEC, true, true>(reinterpret_cast<const int32_t *>(base), i0, n, dst);
+    };
+
+    Act act[VEC], act_next[VEC];
+    load_action(0, act);
+    int64_t slice = 0;
+    float reward[VEC];
+    uint8_t done[VEC];
+    float o[O][VEC];
+
+    for (int64_t t = 0; t < ro.steps; ++t) {
+        int64_t nslice = slice + 1;
+        if (nslice == ro.ring) nslice = 0;
+        if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math
+        uint32_t pending = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float sj[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+            bool dn;
+            float rw;
+            Env::step(sj, act[j], rw, dn);
+            if constexpr (!AUTORESET && Env::HAS_SBD) {
+                if (dn) {
+                    if (sbd[j] == -1) { sbd[j] = 0; }
+                    else { if (i0 + j < n) atomicAdd(a.after_done, 1ull); sbd[j] += 1; rw = 0.0f; }
+                }
+            }
+            done[j] = dn ? 1 : 0;
+            reward[j] = rw;
+            if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+            if constexpr (!Env::OBS_ALIASES_STATE) {
+                float oj[O];
+                Env::observe(sj, oj);
+#pragma unroll
+                for (int k = 0; k < O; ++k) o[k][j] = oj[k];
+            }
+        }
+        if (ro.rec_reward) store_f32<VEC, true, true>(ro.rec_reward + t * n, i0, n, reward);
+        if (ro.rec_done) store_u8<VEC, true, true>(ro.rec_done + t * n, i0, n, done);
+        if constexpr (AUTORESET) {
+            while (pending) {
+                const int j = __ffs(pending) - 1;
+                pending &= pending - 1;
+                const PhiloxWords r = lane_words(a.seed, a.lane_offset + (uint64_t)(i0 + j), tick0 + (uint64_t)t);
+                float sj[S];
+                Env::reset(sj, r);
+                float oj[O];
+                if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
+#pragma unroll
+                for (int jj = 0; jj < VEC; ++jj) {
+                    if (jj == j) {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) s[k][jj] = sj[k];
+                        if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                            for (int k = 0; k < O; ++k) o[k][jj] = oj[k];
+                        }
+                    }
+                }
+            }
+        }
+        if (ro.rec_obs) {
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                if constexpr (Env::OBS_ALIASES_STATE) store_f32<VEC, true, true>(ro.rec_obs + (t * O + k) * n, i0, n, s[k]);
+                else store_f32<VEC, true, true>(ro.rec_obs + (t * O + k) * n, i0, n, o[k]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) act[j] = act_next[j];
+        slice = nslice;
+    }
+
+#pragma unroll
+    for (int k = 0; k < S; ++k) store_f32<VEC, false, true>(a.state + k * a.state_stride, i0, n, s[k]);
+    if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) store_f32<VEC, false, true>(a.obs + k * a.obs_stride, i0, n, o[k]);
+    }
+    store_f32<VEC, false, true>(a.reward, i0, n, reward);
+    store_u8<VEC, false, true>(a.done, i0, n, done);
+    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, false, true>(a.sbd, i0, n, sbd);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Reset: all lanes, or the lanes selected by a byte mask (the caller's `if (done) Reset()`).
 // ---------------------------------------------------------------------------------------------
 template <class Env>
@@ -451,6 +565,31 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
         case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);
         case 2: return launch_step_env<MountainCar>(autoreset, extras, a, cfg, st);
         case 3: return launch_step_env<Acrobot>(autoreset, extras, a, cfg, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <class Env>
+static hipError_t launch_rollout_env(bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st) {
+    const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
+    const dim3 grid(grid_for(threads > 0 ? threads : 1, 256)), blk(256);
+    if (cfg.vec == 4) {
+        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, 4, true>), grid, blk, 0, st, a, r);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 4, false>), grid, blk, 0, st, a, r);
+    } else {
+        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, 1, true>), grid, blk, 0, st, a, r);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 1, false>), grid, blk, 0, st, a, r);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st) {
+    if (cfg.vec != 4) cfg.vec = 1;
+    switch (env_id) {
+        case 0: return launch_rollout_env<CartPole>(autoreset, a, r, cfg, st);
+        case 1: return launch_rollout_env<Pendulum>(autoreset, a, r, cfg, st);
+        case 2: return launch_rollout_env<MountainCar>(autoreset, a, r, cfg, st);
+        case 3: return launch_rollout_env<Acrobot>(autoreset, a, r, cfg, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -35,6 +35,18 @@ struct LaunchCfg { int vec; int block; int nt; };
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);
 
+// Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
+struct RolloutArgs {
+    int64_t steps;           // T
+    int64_t action_stride;   // elements between consecutive action slices
+    int64_t ring;            // step t reads slice t % ring
+    float *rec_obs;          // optional [T][O][n]   (NULL = do not record)
+    float *rec_reward;       // optional [T][n]
+    uint8_t *rec_done;       // optional [T][n]
+};
+// Same results as `steps` launch_step calls (bitwise).  Only the lean variant (no EXTRAS) is fused.
+hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st);
+
 struct ResetArgs {
     float *state; float *obs; int32_t *sbd; uint8_t *done;   // done flags cleared for reset lanes
     const uint8_t *mask;      // NULL = all lanes

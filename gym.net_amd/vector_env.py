@@ -208,6 +208,15 @@ class VectorEnv:
     def RolloutDevice(self, d_actions, steps, action_stride, ring):
         capi.check(self._lib.gymnet_vecenv_rollout_device(self._h, _ptr(d_actions), int(steps), int(action_stride), int(ring)))
 
+    def RolloutFusedDevice(self, d_actions, steps, action_stride, ring, rec_obs=None, rec_reward=None, rec_done=None):
+        """`steps` vector steps in ONE kernel launch (state stays in registers); optional device-side rollout
+        buffers rec_obs [T][D][N], rec_reward [T][N], rec_done [T][N] (ReplayMemory.cs:25-67, batched)."""
+        rec = None
+        if rec_obs is not None or rec_reward is not None or rec_done is not None:
+            rec = capi.RolloutBuffers(_ptr(rec_obs), _ptr(rec_reward), _ptr(rec_done))
+        capi.check(self._lib.gymnet_vecenv_rollout_fused_device(self._h, _ptr(d_actions), int(steps), int(action_stride),
+                                                                int(ring), None if rec is None else C.byref(rec)))
+
     def SampleActionsDevice(self, d_actions, seed=0, tick=0):
         capi.check(self._lib.gymnet_vecenv_sample_actions_device(self._h, _ptr(d_actions), int(seed), int(tick)))
 

@@ -189,6 +189,20 @@ int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions);
  * d_actions + (t % ring) * action_stride elements.  (The caller's hot loop, README.md:34-47, without host hops.) */
 int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_t steps,
                                  int64_t action_stride, int64_t ring);
+/* Device-side rollout buffers (the example's replay memory, batched: examples/ReinforcementLearning/
+ * ReinforcementLearning/MemoryTypes/ReplayMemory.cs:25-67).  Any pointer may be NULL = do not record that stream. */
+typedef struct gymnet_rollout_buffers {
+    float   *d_obs;     /* [steps][obs_dim][num_envs]  observation AFTER step t (after auto-reset, like the step API) */
+    float   *d_reward;  /* [steps][num_envs] */
+    uint8_t *d_done;    /* [steps][num_envs] */
+} gymnet_rollout_buffers;
+/* The same `steps` vector steps as gymnet_vecenv_rollout_device — bit-identical state, reward, done — fused into ONE
+ * kernel launch: every lane keeps its state in registers across the steps, so per env-step only the action is read and
+ * (optionally, rec != NULL) the recorded streams are written.  For open-loop / pre-generated action sequences only: no
+ * policy can look at step t's observation before step t+1.  Not available with DONE_LIST / EPISODE_STATS / FINAL_OBS /
+ * per-lane seeds (GYMNET_ERR_UNSUPPORTED). */
+int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
+                                       int64_t ring, const gymnet_rollout_buffers *rec);
 /* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout). */
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
 int gymnet_vecenv_sync(gymnet_vecenv *h);

@@ -430,3 +430,44 @@ def test_kernel_is_bit_identical_to_the_float32_restatement(gpu_pkg, oracle):
             out = env.Step(a)
             assert np.array_equal(out.Reward, r) and np.array_equal(out.Done, d.astype(bool))
         assert np.array_equal(env.GetState(), cur, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,auto,n", [("CartPole-v1", True, 1 << 16), ("CartPole-v1", False, 5000), ("CartPole-v1", True, 1003),
+                                         ("Pendulum-v1", True, 4096), ("MountainCar-v0", True, 4096), ("Acrobot-v1", True, 4096)])
+def test_fused_rollout_equals_stepwise_and_records(gpu_pkg, name, auto, n):
+    """T steps fused into one launch (state in registers) + device-side rollout buffers must be
+    bit-identical to T one-step launches — final state, every recorded observation / reward / done."""
+    import torch
+    dev = torch.device("cuda", 0)
+    T, ring = 37, 8
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=auto) as f, gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=auto) as e:
+        D = f.ObsDim
+        adt = torch.float32 if name == "Pendulum-v1" else torch.int32
+        stride = (n + 3) // 4 * 4
+        acts = torch.zeros((ring, stride), dtype=adt, device=dev)
+        for t in range(ring):
+            f.SampleActionsDevice(acts[t], seed=SEED + 1, tick=t)
+        f.Sync()
+        rec_obs = torch.zeros((T, D, n), dtype=torch.float32, device=dev)
+        rec_rew = torch.zeros((T, n), dtype=torch.float32, device=dev)
+        rec_done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+        f.ResetDevice(); e.ResetDevice()
+        f.RolloutFusedDevice(acts, T, stride, ring, rec_obs, rec_rew, rec_done)
+        f.Sync()
+        a_host = acts.cpu().numpy()
+        for t in range(T):
+            out = e.Step(a_host[t % ring, :n])
+            assert np.array_equal(rec_obs[t].cpu().numpy().T, out.Observation), t
+            assert np.array_equal(rec_rew[t].cpu().numpy(), out.Reward), t
+            assert np.array_equal(rec_done[t].cpu().numpy().astype(bool), out.Done), t
+        assert np.array_equal(f.GetState(), e.GetState(), equal_nan=True)
+        assert f.Tick == e.Tick == T + 1
+        last = f.Read()
+        assert np.array_equal(last.Reward, out.Reward) and np.array_equal(last.Done, out.Done)
+        assert f.Counters()["lane_steps"] == T * n and f.Counters()["tick"] == T + 1
+        # a following ordinary step continues from the same tick on both
+        f.Step(a_host[0, :n]); e.Step(a_host[0, :n])
+        assert np.array_equal(f.GetState(), e.GetState(), equal_nan=True)
+    with gpu_pkg.VectorEnv(name, 64, seed=SEED, auto_reset=True, done_list=True) as x:
+        with pytest.raises(NotImplementedError):
+            x.RolloutFusedDevice(acts, 2, stride, ring)

@@ -366,6 +366,39 @@ int main(int argc, char **argv) {
         }
     }
     CK(hipGetLastError());
+    // ---- experiment: the batch split in K parts, each part on its own stream (load phase of one part can overlap
+    //      the store phase of another); time per FULL vector step
+    for (int parts : {1, 2, 4}) {
+        std::vector<hipStream_t> ss(parts);
+        for (auto &s : ss) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        std::vector<float> us;
+        for (int r = 0; r < rounds; ++r) {
+            reinit();
+            CK(hipStreamSynchronize(st));
+            hipEvent_t b0, b1; CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+            CK(hipEventRecord(b0, ss[0]));
+            for (int p = 1; p < parts; ++p) CK(hipStreamWaitEvent(ss[p], b0, 0));
+            const int64_t np = n / parts;
+            for (int t = 0; t < steps; ++t)
+                for (int p = 0; p < parts; ++p) {
+                    StepArgs s{};
+                    s.state = a.s0 + p * np; s.obs = s.state; s.action = acts + (size_t)(t % ring) * n + p * np;
+                    s.reward = a.reward + p * np; s.done = a.done + p * np;
+                    s.tick2 = g_tick2; s.n = np; s.state_stride = n; s.obs_stride = n; s.lane_offset = (uint64_t)(p * np);
+                    s.seed = a.seed; s.parity = 0; s.cparity = 0;
+                    launch_step(0, true, false, s, LaunchCfg{4, 256, 15}, ss[p]);
+                }
+            std::vector<hipEvent_t> ends(parts);
+            for (int p = 0; p < parts; ++p) { CK(hipEventCreate(&ends[p])); CK(hipEventRecord(ends[p], ss[p])); }
+            for (int p = 1; p < parts; ++p) CK(hipStreamWaitEvent(ss[0], ends[p], 0));
+            CK(hipEventRecord(b1, ss[0]));
+            CK(hipEventSynchronize(b1));
+            float ms; CK(hipEventElapsedTime(&ms, b0, b1));
+            us.push_back(ms * 1e3f / steps);
+        }
+        std::sort(us.begin(), us.end());
+        printf("SHIPPED split over %d stream(s): median %8.3f us per full step  %8.1f GB/s\n", parts, us[us.size() / 2], 41.0 * n / (us[us.size() / 2] * 1e-6) / 1e9);
+    }
     printf("lanes=2^%d rounds=%d steps/round=%d   (us per launch; GB/s = 41 B x lanes / median)\n", lg, rounds, steps);
     for (auto &v : V) {
         std::sort(v.us.begin(), v.us.end());
