@@ -419,16 +419,19 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
     const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0);
-    // Launch policy, measured with tools/probe_step.hip on MI355X (profiles/probe_r01.txt):
-    //  - state <= 8 MiB: scalar lanes (4x the waves hide latency better than dwordx4 when the grid is small);
-    //  - state <= 16 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
-    //  - state <= 256 MiB (fits the Infinity Cache): dwordx4, keep the state cacheable and stream only the
-    //    action / reward / done arrays past it, so the next launch re-reads the state from the cache;
-    //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal.
-    const size_t state_bytes = (size_t)h->n * d.state_dim * 4;
-    if (state_bytes <= ((size_t)8 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
-    else if (state_bytes <= ((size_t)16 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
-    else if (state_bytes <= ((size_t)256 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
+    // Launch policy, measured on MI355X with tools/probe_step.hip and bench.py (profiles/probe_r01.txt),
+    // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
+    //  - <= 24 MiB (2^19 CartPole lanes): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
+    //  - <= 48 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
+    //  - <= 768 MiB (state fits the 256 MiB Infinity Cache): dwordx4, state cacheable, action / reward / done streamed
+    //    past it, so the next launch re-reads the state from the cache;
+    //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal;
+    //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
+    const size_t step_bytes = (size_t)h->n * (size_t)d.algorithmic_bytes;
+    const bool alu_bound = cfg->env_id == GYMNET_ENV_ACROBOT;
+    if (alu_bound || step_bytes <= ((size_t)24 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
+    else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
     else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
     if (!can_vec4) h->lcfg.vec = 1;
     if (const char *e = std::getenv("GYMNET_VEC")) { int v = std::atoi(e); if (v == 1 || (v == 4 && can_vec4)) h->lcfg.vec = v; }

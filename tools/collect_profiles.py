@@ -74,14 +74,15 @@ if "TCC_HIT_sum" in vals:
 open(os.path.join(P, f"rocprof_pmc_{tag}.txt"), "w").write("".join(pm))
 
 misc = []
-for f in ("bench.log", "bench_2p27.log", "bench_eager.log", "hbm_copy.log", "rocminfo.log"):
+for f in ("bench.log", "bench_2p27.log", "bench_Pendulum-v1.log", "bench_MountainCar-v0.log", "bench_Acrobot-v1.log",
+          "fused_probe.log", "host_path.log", "hbm_copy.log", "rocminfo.log"):
     fp = os.path.join(G, f)
     if os.path.exists(fp):
         misc.append(f"## {f}\n" + "".join(l for l in open(fp, errors="replace") if not l.startswith("/opt/amdgpu")) + "\n")
 open(os.path.join(P, f"bench_runs_{tag}.txt"), "w").write("".join(misc))
 probe = []
 for f in sorted(os.listdir(G)):
-    if f.startswith("probe3_") and f.endswith(".log"):
+    if f.startswith("probe10_") and f.endswith(".log"):
         probe.append(open(os.path.join(G, f)).read() + "\n")
 if probe:
     open(os.path.join(P, f"probe_{tag}.txt"), "w").write(

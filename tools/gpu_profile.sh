@@ -12,6 +12,10 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
   timeout 600 rocprofv3 --pmc $C -d $O/pmc_$tag -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 200 --warmup 20 > $O/pmc_$tag.log 2>&1
 done
 timeout 300 python3 $R/bench.py --no-cpu-baseline --num-envs 134217728 --ring 4 --steps 64 --warmup 8 > $O/bench_2p27.log 2>&1
-timeout 300 python3 $R/bench.py --no-cpu-baseline --no-graph > $O/bench_eager.log 2>&1
+for E in Pendulum-v1 MountainCar-v0 Acrobot-v1; do
+  timeout 300 python3 $R/bench.py --no-cpu-baseline --env $E --steps 1024 --warmup 128 > $O/bench_$E.log 2>&1
+done
+timeout 300 python3 $R/tools/fused_probe.py > $O/fused_probe.log 2>&1
+timeout 300 python3 $R/tools/host_path_probe.py > $O/host_path.log 2>&1
 timeout 300 python3 $R/tools/hbm_copy_probe.py > $O/hbm_copy.log 2>&1
 find $O -name "*.csv" | head -50 > $O/files.txt
