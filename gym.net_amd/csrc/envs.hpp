@@ -207,17 +207,25 @@ struct Acrobot {
     using Action = int32_t;                  // Discrete(3): torque = a - 1
     static constexpr float PI = 3.14159265358979323846f;
 
-    // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals
+    // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals.
+    // Acrobot is the one ALU-bound kernel of the four (RK4 = 4 x dsdt), so dsdt is written for instruction count:
+    //  - upstream's cos(th1 + th2 - pi/2) and cos(th1 - pi/2) are sin(th1 + th2) and sin(th1); with sin/cos of th1 and
+    //    th2 in hand, sin(th1 + th2) = s1*c2 + c1*s2: two sincos per stage instead of one sincos + two cos;
+    //  - the two divisions by d1 share one reciprocal.
+    // Mathematically identical to upstream; in float32 it differs from the literal transcription by rounding only
+    // (<= 1e-6 on accelerations of O(10)); the float64 oracle keeps upstream's literal formula.
     __device__ __forceinline__ static void dsdt(const float (&s)[4], float torque, float (&d)[4]) {
         const float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
-        float s2, c2;
+        float s1, c1, s2, c2;
+        sincos_f32(th1, s1, c1);
         sincos_f32(th2, s2, c2);
         const float d1 = 0.25f + (1.25f + c2) + 2.0f;
         const float d2 = (0.25f + 0.5f * c2) + 1.0f;
-        const float phi2 = 4.9f * cos_f32(th1 + th2 - PI / 2.0f);
-        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * cos_f32(th1 - PI / 2.0f) + phi2;
-        const float ddth2 = (torque + d2 / d1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 / d1);
-        const float ddth1 = -(d2 * ddth2 + phi1) / d1;
+        const float r1 = 1.0f / d1;
+        const float phi2 = 4.9f * (s1 * c2 + c1 * s2);
+        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * s1 + phi2;
+        const float ddth2 = (torque + d2 * r1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 * r1);
+        const float ddth1 = -(d2 * ddth2 + phi1) * r1;
         d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
     }
 
@@ -251,7 +259,12 @@ struct Acrobot {
         y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = y[i];
-        done = (-cos_f32(y[0]) - cos_f32(y[1] + y[0])) > 1.0f;
+        // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2 (the kernel's observe() recomputes
+        // the same sincos pair; the compiler merges them after inlining)
+        float s1, c1, s2, c2;
+        sincos_f32(y[0], s1, c1);
+        sincos_f32(y[1], s2, c2);
+        done = (-c1 - (c1 * c2 - s1 * s2)) > 1.0f;
         reward = done ? 0.0f : -1.0f;
     }
 

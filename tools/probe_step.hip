@@ -279,6 +279,14 @@ struct Variant {
     std::vector<float> us;
 };
 
+// occupancy-limited launch: LDSKB KiB of (unused) dynamic LDS per workgroup caps the resident workgroups per CU, so
+// the grid runs in several GENERATIONS and one generation's store phase can overlap the next one's load phase
+template <int VEC, int BLOCK, int MODE, int RESET, int NT, int LDSKB>
+void LOCC(const Args &a, hipStream_t st) {
+    const int64_t threads = a.n / VEC;
+    hipLaunchKernelGGL((k_step<VEC, BLOCK, MODE, RESET, NT>), dim3((unsigned)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), LDSKB * 1024, st, a);
+}
+
 template <int VEC, int BLOCK, int MODE, int RESET, int NT>
 void L(const Args &a, hipStream_t st) {
     const int64_t threads = a.n / VEC;
@@ -325,6 +333,20 @@ int main(int argc, char **argv) {
     ADD("base    vec4 b256 reset=divergent ", (L<4, 256, 0, 0, 0>));
     ADD("loop    vec4 b256                 ", (L<4, 256, 0, 1, 0>));
     ADD("SHIPPED vec4 nt=all               ", (LPROD<4, 15>));
+    ADD("loop vec4 b256 nt=all lds 40K (4/CU)", (LOCC<4, 256, 0, 1, 15, 40>));
+    ADD("loop vec4 b256 nt=all lds 53K (3/CU)", (LOCC<4, 256, 0, 1, 15, 53>));
+    ADD("loop vec4 b256 nt=all lds 80K (2/CU)", (LOCC<4, 256, 0, 1, 15, 80>));
+    ADD("loop vec4 b256 nt=all lds 100K(1/CU)", (LOCC<4, 256, 0, 1, 15, 100>));
+    ADD("loop vec4 b128 nt=all lds 40K (4/CU)", (LOCC<4, 128, 0, 1, 15, 40>));
+    ADD("loop vec4 b128 nt=all lds 26K (6/CU)", (LOCC<4, 128, 0, 1, 15, 26>));
+    ADD("loop vec4 b64  nt=all lds 20K (8/CU)", (LOCC<4, 64, 0, 1, 15, 20>));
+    ADD("loop vec4 b64  nt=all lds 13K (12/CU)", (LOCC<4, 64, 0, 1, 15, 13>));
+    ADD("loop vec2 b256 nt=all lds 40K (4/CU)", (LOCC<2, 256, 0, 1, 15, 40>));
+    ADD("loop vec2 b256 nt=all lds 26K (6/CU)", (LOCC<2, 256, 0, 1, 15, 26>));
+    ADD("loop vec1 b256 nt=all lds 26K (6/CU)", (LOCC<1, 256, 0, 1, 15, 26>));
+    ADD("loop vec1 b256 nt=all lds 40K (4/CU)", (LOCC<1, 256, 0, 1, 15, 40>));
+    ADD("copy vec4 b256 lds 80K (2/CU)       ", (LOCC<4, 256, 1, 0, 0, 80>));
+    ADD("copy vec4 b128 lds 40K (4/CU)       ", (LOCC<4, 128, 1, 0, 0, 40>));
     ADD("noreset vec4 b256 nt=all 2x phys  ", (L<4, 256, 3, 0, 15>));
     ADD("noreset vec4 b256 nt=all 3x phys  ", (L<4, 256, 4, 0, 15>));
     ADD("spec    vec4 b256 nt=all          ", (L<4, 256, 0, 3, 15>));
