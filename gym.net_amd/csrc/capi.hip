@@ -560,6 +560,16 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
         return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be 16-byte aligned");
     const char *base = static_cast<const char *>(d_actions);
     auto slice = [&](int64_t t) -> const void * { return base + (size_t)((t % ring) * action_stride) * 4; };
+    if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && !h->desc->box_action && steps > 0) {
+        // Discrete.Contains over every slice the rollout will read, before any state changes (one readback)
+        HIP_TRY(h, hipMemsetAsync(h->d_bad, 0, sizeof(uint32_t), h->stream));
+        for (int64_t k = 0; k < (steps < ring ? steps : ring); ++k)
+            HIP_TRY(h, launch_validate_discrete(static_cast<const int32_t *>(slice(k)), h->n, h->desc->action_n, h->d_bad, h->stream));
+        uint32_t bad = 0;
+        HIP_TRY(h, hipMemcpyAsync(&bad, h->d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (bad) return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%u lane-steps, Discrete(%d))", bad, h->desc->action_n);
+    }
 
     // graph length: a multiple of `ring` (so every replay starts at slice 0) and even (so the
     // double-buffered device tick / done-count parities are the same at every replay)

@@ -316,6 +316,15 @@ def test_invalid_actions(gpu_pkg, oracle):
             env.Step(2)
         assert np.array_equal(env.GetState(), s)
         env.Step(np.ones(n, np.int32))
+        import torch                                                      # device rollouts validate every slice up front
+        acts_dev = torch.ones((4, n), dtype=torch.int32, device="cuda")
+        acts_dev[2, 5] = 7
+        before = env.GetState()
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            env.RolloutDevice(acts_dev, 8, n, 4)
+        assert np.array_equal(env.GetState(), before)
+        env.RolloutDevice(acts_dev, 2, n, 4)                              # slices 0 and 1 only: valid
+        env.Sync()
     cp = gpu_pkg.CartPoleEnv()
     with pytest.raises(TypeError):                                       # (int)action InvalidCastException, CartPoleEnv.cs:138
         cp.Step(0.5)
