@@ -480,3 +480,25 @@ def test_fused_rollout_equals_stepwise_and_records(gpu_pkg, name, auto, n):
     with gpu_pkg.VectorEnv(name, 64, seed=SEED, auto_reset=True, done_list=True) as x:
         with pytest.raises(NotImplementedError):
             x.RolloutFusedDevice(acts, 2, stride, ring)
+
+
+def test_maximum_size_batch_properties(gpu_pkg, oracle):
+    """2^25 lanes (the largest size the CPU side of this test can afford; the bench goes to 2^27): reset draws are
+    U(-0.05, 0.05) with the oracle's exact values at both ends of the lane range, a rollout keeps every lane inside
+    the thresholds it resets at, and the step count adds up."""
+    n = 1 << 25
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as env:
+        obs = env.Reset()
+        assert obs.shape == (n, 4) and obs.min() >= -0.05 and obs.max() < 0.05
+        assert abs(float(obs.mean())) < 1e-4 and abs(float(obs.std()) - 0.1 / np.sqrt(12)) < 1e-4
+        assert np.array_equal(obs[:64].T, oracle.cartpole_reset(SEED, 0, 0, 64))
+        assert np.array_equal(obs[-64:].T, oracle.cartpole_reset(SEED, n - 64, 0, 64))
+        del obs
+        dones = 0
+        for t in range(12):
+            out = env.Step(1)                                         # IVecEnv.Step(int): scalar broadcast, always push right
+            dones += int(out.Done.sum())
+        st = env.GetState()
+        assert np.isfinite(st).all() and np.abs(st[0]).max() <= 2.5 and np.abs(st[2]).max() <= 0.3
+        c = env.Counters()
+        assert c["lane_steps"] == 12 * n and c["tick"] == 13 and dones > 0
