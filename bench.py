@@ -143,6 +143,22 @@ def main():
     c = local.Counters()
     assert c["lane_steps"] == (K + W) * n, c
 
+    # Cross-check of the per-launch figure: 200 single launches, each bracketed by its own HIP-event pair on the
+    # engine's stream (isolated launches: no back-to-back overlap with a neighbour's ramp / drain).
+    single_us = None
+    if not args.allgather:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        for t, (a0, a1) in enumerate(evs):
+            a0.record(stream)
+            local.StepDevice(actions[t % ring].data_ptr())
+            a1.record(stream)
+        torch.cuda.synchronize(dev)
+        ds = sorted(a0.elapsed_time(a1) * 1e3 for a0, a1 in evs)
+        single_us = ds[len(ds) // 2]
+        K_extra = len(evs)
+    else:
+        K_extra = 0
+
     # Secondary figure, NOT the headline: the same K steps fused into one launch per `ring` steps (state stays in
     # registers, gymnet_vecenv_rollout_fused_device) — open-loop rollouts only, so it is reported beside, not as, `value`.
     fused = None
@@ -183,7 +199,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
-                         "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us},
+                         "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
+                         "isolated_launch_us_median": single_us},
         }
         if fused:
             out["fused_rollout"] = fused
