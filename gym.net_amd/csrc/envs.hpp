@@ -26,7 +26,7 @@ namespace gymnet {
 // |x| <= 1e5, <= 1.5 ulp for |x| <= 10.  sin(-0) returns +0.  |x| > 65536 (or inf) falls back to OCML.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) {
-    if (fabsf(x) > 65536.0f) {            // never taken by a sane rollout; keeps huge / infinite angles defined
+    if (__builtin_expect(fabsf(x) > 65536.0f, 0)) {   // never taken by a sane rollout; keeps huge / infinite angles defined
         sincosf(x, &s_out, &c_out);
         return;
     }

@@ -4,6 +4,8 @@ Single samples are drawn on the host with numpy's RandomState (the reference use
 np.random, Box.cs:33, Discrete.cs:16).  Batched sampling for a whole VectorEnv runs on the GPU:
 VectorEnv.SampleActions() -> gymnet_vecenv_sample_actions (Philox, see csrc/kernels.hip).
 """
+import enum
+
 import numpy as np
 
 
@@ -37,7 +39,9 @@ class Discrete(Space):                                          # Discrete.cs:5-
             return self.Start
         return self.Start + int(self.RandomState.randint(0, self.N))
 
-    def Contains(self, x):                                      # Discrete.cs:30-40: 0 <= x < N (ignores Start)
+    def Contains(self, x):                                      # Discrete.cs:30-44: 0 <= x < N (ignores Start)
+        if isinstance(x, enum.Enum):                            # Contains(Enum x), Discrete.cs:42-44
+            x = int(x.value)
         if isinstance(x, (bool, np.bool_)) or not isinstance(x, (int, np.integer)):
             raise NotImplementedError(str(x))                   # NotSupportedException
         return 0 <= int(x) < self.N

@@ -16,6 +16,7 @@ Everything here is a thin shim over libgymnet_amd.so: all compute happens in HIP
 is numpy.ndarray on this side of the boundary.
 """
 import ctypes as C
+import enum
 
 import numpy as np
 
@@ -328,6 +329,8 @@ class GpuEnv:
         return self._v.Reset()[0]
 
     def Step(self, action):                                                          # CartPoleEnv.cs:137-186
+        if isinstance(action, enum.Enum):                                            # Env<TAction> where TAction : Enum (Env.cs:43-53)
+            action = int(action.value)
         if isinstance(action, (bool, np.bool_)) or not isinstance(action, (int, np.integer)):
             if isinstance(self.ActionSpace, Discrete):
                 raise TypeError(f"Specified cast is not valid: {type(action).__name__} -> int")   # InvalidCastException, :138

@@ -107,6 +107,13 @@ def test_discrete(gymnet):
     with pytest.raises(NotImplementedError):
         d.Contains("x")
     assert repr(d) == "Discrete(2)" and d.Shape == (2,)
+    import enum
+
+    class Push(enum.Enum):                                          # Contains(Enum), Discrete.cs:42-44
+        Left = 0
+        Right = 1
+        Up = 2
+    assert d.Contains(Push.Left) and d.Contains(Push.Right) and not d.Contains(Push.Up)
 
 
 def test_step_record(gymnet):
