@@ -54,11 +54,13 @@ def cpu_baseline(num_envs, target_seconds):
     rate = probe["steps_per_sec"]
     t_steps = int(max(8, min(4096, target_seconds * rate / num_envs)))
     r = oracle.cpu_baseline(num_envs, t_steps, cores, alloc_faithful=True)
+    r0 = oracle.cpu_baseline(num_envs, max(8, t_steps // 4), cores, alloc_faithful=False)   # variant (B): no heap traffic
     r1 = oracle.cpu_baseline(1, 100_000, 1, alloc_faithful=True)     # BASELINE.json configs[0]
     return {"value": r["steps_per_sec"], "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{num_envs} per-instance float64 CartPole envs x {t_steps} steps, reset-on-done, "
                       f"split over {cores} threads, 2 heap allocations per step like the C# path "
                       f"({r['seconds']:.1f} s)",
+            "no_alloc_variant_value": r0["steps_per_sec"],
             "single_instance_100k_steps_per_sec": r1["steps_per_sec"]}
 
 

@@ -282,3 +282,37 @@ def test_kernel_sincos_accuracy(oracle):
     assert np.array_equal(s1, -s2) and np.array_equal(c1, c2)
     s, c = oracle.sincos_kernel(np.array([np.nan, np.inf], dtype=f32))
     assert np.isnan(s).all() and np.isnan(c).all()
+
+
+def test_restatement_against_exact_rational_arithmetic(oracle):
+    """Third, evaluation-order-independent anchor: the CartPoleEnv.Step formulas (CartPoleEnv.cs:146-157) evaluated
+    in EXACT rational arithmetic (sin/cos by Taylor series on Fractions, 40 terms) with the float32-valued
+    constants.  The float64 restatement must sit within a few float64 ulps of the exact real-number result."""
+    from fractions import Fraction as F
+
+    def sincos(x):
+        s = c = F(0)
+        term_s, term_c = x, F(1)
+        for k in range(40):
+            s += term_s; c += term_c
+            term_s = -term_s * x * x / ((2 * k + 2) * (2 * k + 3))
+            term_c = -term_c * x * x / ((2 * k + 1) * (2 * k + 2))
+        return s, c
+
+    cst = oracle.cartpole_constants()
+    g, mp, M, L, pml, tau = (F(cst[k]) for k in ("gravity", "masspole", "total_mass", "length", "polemass_length", "tau"))
+    rng = np.random.default_rng(17)
+    for _ in range(12):
+        st = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-0.25, 0.25), rng.uniform(-3, 3)]).astype(f32)
+        a = int(rng.integers(0, 2))
+        x, xd, th, thd = (F(float(v)) for v in st)
+        force = F(10) if a == 1 else F(-10)
+        s, c = sincos(th)
+        temp = (force + pml * thd * thd * s) / M
+        thetaacc = (g * s - c * temp) / (L * (F(4, 3) - mp * c * c / M))
+        xacc = temp - pml * thetaacc * c / M
+        exact = [x + tau * xd, xd + tau * xacc, th + tau * thd, thd + tau * thetaacc]
+        got = oracle.cartpole_step(st.astype(np.float64).reshape(4, 1), np.array([a], dtype=np.int32))[0][:, 0]
+        for e, v in zip(exact, got):
+            # 4.0/3.0 as a double literal and ~15 roundings: allow 64 ulp of slack around the exact value
+            assert abs(float(e) - v) <= 64 * np.spacing(abs(v)) + 1e-300
