@@ -1,13 +1,16 @@
 // kernels.hip — HIP kernels of the batched classic-control engine, written for gfx950 (CDNA4, wave64).
 //
-// The hot path is HBM-bound streaming (CartPole: 41 algorithmic bytes per env-step against ~40 flop +
-// one sincos), so the design rules are the memory ones: structure-of-arrays, one env per lane, 16-byte
-// (dwordx4) accesses per lane on every stream, a static block->lane map (block b always owns the same
-// lanes and the dispatcher places block b on XCD b % 8, so a batch that fits the 8 x 4 MiB L2s is
-// re-read from its own XCD's L2 on the next step), no LDS (there is no reuse to stage: each state
-// word is read once and written once), no MFMA (no dense contraction exists on this path).
-// Auto-reset is a divergent Philox4x32-10 call executed only by waves that contain a finished lane
-// (exec-mask skip); done-lane compaction is one wave ballot + one atomic per wave.
+// The hot path is HBM-bound streaming (CartPole: 41 algorithmic bytes per env-step against ~105 VALU), so the
+// design rules are the memory ones: structure-of-arrays, one env per lane, 16-byte (dwordx4) accesses per lane
+// on every stream, a static block->lane map, no LDS (there is no reuse to stage: each state word is read once
+// and written once per launch), no MFMA (no dense contraction exists on this path).
+// What the counters say (profiles/rocprof_pmc_r01.txt): every launch fetches all of its input bytes through the
+// fabric again — the per-XCD L2s keep nothing across a kernel boundary — so the only cross-launch reuse level
+// is the 256 MiB Infinity Cache, and an XCD-aware block remap would buy nothing here; what matters instead is
+// which streams are marked non-temporal (the NT template parameter, chosen from the batch size in capi.hip).
+// At 2^20 lanes all waves are resident at once and run load -> math -> store in lock-step, so beyond the memory
+// floor every VALU instruction is exposed: hence the in-house sincos, the fma-pair constant division and the
+// loop-compacted Philox reset (envs.hpp, below).  Done-lane compaction is one wave ballot + one atomic per wave.
 //
 // Compiled with -ffp-contract=off (see envs.hpp).
 #include "kernels.hpp"
