@@ -117,3 +117,46 @@ def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name):
         assert np.array_equal(env.GetState(), ws)
         assert np.array_equal(out.Observation, wo.T)
         assert np.array_equal(out.Reward, wr.astype(np.float32)) and np.array_equal(out.Done, wd.astype(bool))
+
+
+@pytest.mark.parametrize("name", ["Pendulum-v1", "MountainCar-v0", "Acrobot-v1"])
+def test_episode_bookkeeping_on_every_env(gpu_pkg, name):
+    # done-list compaction, episode statistics and the time-limit extension are env-agnostic kernel features
+    n, steps, limit = 6000, 45, 20
+    rng = np.random.default_rng(41)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True, done_list=True, episode_stats=True, final_obs=True,
+                           max_episode_steps=limit) as env:
+        env.Reset()
+        ln = np.zeros(n, np.int32); ret = np.zeros(n, np.float64)
+        fin_len = np.zeros(n, np.int32); fin_ret = np.zeros(n, np.float64)
+        for t in range(steps):
+            a = rng.uniform(-2, 2, n).astype(np.float32) if name == "Pendulum-v1" else rng.integers(0, 3, n).astype(np.int32)
+            out = env.Step(a)
+            ln += 1; ret += out.Reward
+            d = out.Done
+            assert sorted(env.DoneLanes().tolist()) == np.nonzero(d)[0].tolist()
+            fin_len[d] = ln[d]; fin_ret[d] = ret[d]; ln[d] = 0; ret[d] = 0
+        got_ret, got_len = env.EpisodeStats()
+        assert np.array_equal(got_len, fin_len) and got_len.max() == limit       # truncation at the limit
+        assert np.abs(got_ret - fin_ret).max() <= 1e-3 * max(1.0, np.abs(fin_ret).max())
+        if name == "Pendulum-v1":
+            assert set(np.unique(got_len)) == {limit}                                # Pendulum only ever ends by truncation
+        assert np.isfinite(env.FinalObs()).all()
+
+
+def test_long_fused_rollout_stays_deterministic_and_in_bounds(gpu_pkg):
+    import torch
+    n, T, ring = 1 << 14, 6000, 16
+    dev = torch.device("cuda", 0)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as f, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as e:
+        acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+        for t in range(ring):
+            f.SampleActionsDevice(acts[t], seed=5, tick=t)
+        f.ResetDevice(); e.ResetDevice()
+        f.RolloutFusedDevice(acts, T, n, ring)
+        e.RolloutDevice(acts, T, n, ring)                # graph replay at this size
+        f.Sync(); e.Sync()
+        a, b = f.GetState(), e.GetState()
+        assert np.array_equal(a, b) and np.isfinite(a).all()
+        assert np.abs(a[0]).max() <= 2.5 and np.abs(a[2]).max() <= 0.3
+        assert f.Tick == e.Tick == T + 1 and f.Counters()["tick"] == T + 1 == e.Counters()["tick"]
