@@ -134,9 +134,9 @@ struct BusyGuard {
 };
 
 #define ENTER(h)                                                                                         \
-    if (!(h)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "%s: null handle", __func__);                 \
+    if (!(h)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");                               \
     BusyGuard guard_(h);                                                                                 \
-    if (!guard_.ok) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "%s: handle is in use by another call", __func__); \
+    if (!guard_.ok) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "handle is in use by another call");     \
     HIP_TRY(h, hipSetDevice((h)->device))
 
 template <class T>
@@ -254,6 +254,18 @@ void recompute_extras(gymnet_vecenv *h) {
                 h->d_lane_seed != nullptr;
 }
 
+// Nothing may throw across the C ABI: every entry point body runs inside this guard.
+template <class F>
+int guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return GYMNET_ERR_OOM;
+    } catch (...) {
+        return GYMNET_ERR_HIP;
+    }
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -280,6 +292,7 @@ const char *gymnet_status_string(int status) {
 const char *gymnet_last_error(void) { return g_last_error.c_str(); }
 
 int gymnet_device_count(int *count) {
+    return guarded([&]() -> int {
     if (!count) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "count is null");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -290,9 +303,11 @@ int gymnet_device_count(int *count) {
     }
     *count = c;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_env_describe(int env_id, gymnet_env_info *out) {
+    return guarded([&]() -> int {
     if (!out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "out is null");
     if (env_id < 0 || env_id > 3) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "unknown env_id %d", env_id);
     const EnvDesc &d = kEnvs[env_id];
@@ -307,9 +322,11 @@ int gymnet_env_describe(int env_id, gymnet_env_info *out) {
     out->reward_low = d.reward_low; out->reward_high = d.reward_high;
     out->algorithmic_bytes_per_step = d.algorithmic_bytes;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_destroy(gymnet_vecenv *h) {
+    return guarded([&]() -> int {
     if (!h) return GYMNET_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -318,9 +335,11 @@ int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
+    return guarded([&]() -> int {
     if (!out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
     if (!cfg) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "cfg is null");
@@ -441,9 +460,11 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 #undef CREATE_HIP
     *out = h;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed) {
+    return guarded([&]() -> int {
     ENTER(h);
     h->seed = seed;
     h->tick = 0;
@@ -451,9 +472,11 @@ int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed) {
     h->d_lane_seed = nullptr;   // back to one key for all lanes (the old array stays owned until destroy)
     recompute_extras(h);
     return write_tick(h);
+    });
 }
 
 int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t count) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!seeds) return fail(h, GYMNET_ERR_INVALID_ARG, "seeds is null");
     if (count != h->n)   // VecEnv.cs:49
@@ -467,45 +490,57 @@ int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t co
     h->tick = 0;
     drop_graphs(h);
     return write_tick(h);
+    });
 }
 
 int gymnet_vecenv_reset_device(gymnet_vecenv *h) {
+    return guarded([&]() -> int {
     ENTER(h);
     return launch_reset_lanes(h, nullptr);
+    });
 }
 
 int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_mask) {   // own done flags: snapshot them, because the reset kernel clears done for reset lanes
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
         d_mask = h->d_mask;
     }
     return launch_reset_lanes(h, d_mask);
+    });
 }
 
 int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     ST_TRY(launch_reset_lanes(h, nullptr));
     return copy_out(h, obs_out, nullptr, nullptr);
+    });
 }
 
 int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (mask) HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     else HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     ST_TRY(launch_reset_lanes(h, h->d_mask));
     return copy_out(h, obs_out, nullptr, nullptr);
+    });
 }
 
 int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     ST_TRY(stage_host_actions(h, actions));
     ST_TRY(launch_one_step(h, h->d_actions));
     return copy_out(h, obs_out, reward_out, done_out);
+    });
 }
 
 int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_out, float *reward_out, uint8_t *done_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     const EnvDesc &d = *h->desc;
@@ -521,38 +556,48 @@ int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_ou
     }
     ST_TRY(launch_one_step(h, h->d_actions));
     return copy_out(h, obs_out, reward_out, done_out);
+    });
 }
 
 int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     ST_TRY(stage_host_actions(h, actions));
     ST_TRY(launch_one_step(h, h->d_actions));
     h->async_pending = true;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->async_pending) return fail(h, GYMNET_ERR_NOT_STEPPING, "not running an async step");
     h->async_pending = false;
     return copy_out(h, obs_out, reward_out, done_out);
+    });
 }
 
 int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     return copy_out(h, obs_out, reward_out, done_out);
+    });
 }
 
 int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (h->lcfg.vec == 4 && !aligned16(d_actions)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions must be 16-byte aligned");
     ST_TRY(validate_staged_actions(h, d_actions));
     return launch_one_step(h, d_actions);
+    });
 }
 
 int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
@@ -614,10 +659,12 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
     }
     for (; t < steps; ++t) ST_TRY(launch_one_step(h, slice(t)));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
                                        int64_t ring, const gymnet_rollout_buffers *rec) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
@@ -638,23 +685,29 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     h->step_launches += 1;
     h->lane_steps += (uint64_t)steps * (uint64_t)h->n;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_obs_rowmajor) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor is null");
     if (!aligned16(d_obs_rowmajor)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor must be 16-byte aligned");
     HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_obs, h->ostride, d_obs_rowmajor, h->n, h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_sync(gymnet_vecenv *h) {
+    return guarded([&]() -> int {
     ENTER(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
+    return guarded([&]() -> int {
     if (!h || !out) return fail(h, GYMNET_ERR_INVALID_ARG, "null argument");
     std::memset(out, 0, sizeof *out);
     out->struct_size = sizeof *out;
@@ -666,18 +719,22 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     out->d_finished_return = h->d_fin_ret; out->d_finished_length = h->d_fin_len;
     out->stream = h->stream;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
     HIP_TRY(h, hipMemcpy2DAsync(state_soa, (size_t)h->n * 4, h->d_state, (size_t)h->sstride * 4, (size_t)h->n * 4,
                                 (size_t)h->desc->state_dim, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
     HIP_TRY(h, hipMemcpy2DAsync(h->d_state, (size_t)h->sstride * 4, state_soa, (size_t)h->n * 4, (size_t)h->n * 4,
@@ -686,39 +743,49 @@ int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa) {
         HIP_TRY(h, launch_observe(h->cfg.env_id, h->d_state, h->sstride, h->d_obs, h->ostride, h->n, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_get_steps_beyond_done(gymnet_vecenv *h, int32_t *out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_sbd) return fail(h, GYMNET_ERR_UNSUPPORTED, "steps_beyond_done exists only for CartPole without GYMNET_FLAG_AUTORESET");
     if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
     HIP_TRY(h, hipMemcpyAsync(out, h->d_sbd, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_set_steps_beyond_done(gymnet_vecenv *h, const int32_t *in) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_sbd) return fail(h, GYMNET_ERR_UNSUPPORTED, "steps_beyond_done exists only for CartPole without GYMNET_FLAG_AUTORESET");
     if (!in) return fail(h, GYMNET_ERR_INVALID_ARG, "in is null");
     HIP_TRY(h, hipMemcpyAsync(h->d_sbd, in, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_get_tick(gymnet_vecenv *h, uint64_t *tick) {
+    return guarded([&]() -> int {
     if (!h || !tick) return fail(h, GYMNET_ERR_INVALID_ARG, "null argument");
     *tick = h->tick;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_set_tick(gymnet_vecenv *h, uint64_t tick) {
+    return guarded([&]() -> int {
     ENTER(h);
     h->tick = tick;
     return write_tick(h);
+    });
 }
 
 int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
     std::memset(out, 0, sizeof *out);
@@ -735,9 +802,11 @@ int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out) {
     out->stepped_after_done = ad;
     out->last_done_count = (h->d_done_count2 && h->last_cparity >= 0) ? (int64_t)cnt[h->last_cparity] : -1;
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capacity, int64_t *count) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
     if (!count || capacity < 0 || (capacity > 0 && !lanes_out)) return fail(h, GYMNET_ERR_INVALID_ARG, "bad count/capacity/lanes_out");
@@ -749,18 +818,22 @@ int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capac
     const int64_t m = c < capacity ? c : capacity;
     if (m > 0) HIP_TRY(h, hipMemcpy(lanes_out, h->d_done_list, (size_t)m * 4, hipMemcpyDeviceToHost));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_fin_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_EPISODE_STATS");
     if (finished_return) HIP_TRY(h, hipMemcpyAsync(finished_return, h->d_fin_ret, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     if (finished_length) HIP_TRY(h, hipMemcpyAsync(finished_length, h->d_fin_len, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
     if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
@@ -768,25 +841,31 @@ int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
     HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
                                   uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    return guarded([&]() -> int {
     if (!d_out || count < 0 || n <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/n");
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, launch_sample_discrete(d_out, count, n, start, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t count, float low, float high,
                              uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    return guarded([&]() -> int {
     if (!d_out || count < 0 || !(low <= high)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/bounds");
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, launch_sample_box(d_out, count, low, high, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick) {
+    return guarded([&]() -> int {
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     const EnvDesc &d = *h->desc;
@@ -797,9 +876,11 @@ int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint6
         HIP_TRY(h, launch_sample_discrete(static_cast<int32_t *>(d_actions), h->n, d.action_n, 0, seed,
                                           (uint64_t)h->cfg.lane_offset, tick, h->stream));
     return GYMNET_OK;
+    });
 }
 
 int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick) {
+    return guarded([&]() -> int {
     if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
     if (!actions_out) return fail(h, GYMNET_ERR_INVALID_ARG, "actions_out is null");
     ST_TRY(gymnet_vecenv_sample_actions_device(h, h->d_actions, seed, tick));
@@ -807,6 +888,7 @@ int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t s
     HIP_TRY(h, hipMemcpyAsync(actions_out, h->d_actions, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
+    });
 }
 
 }  // extern "C"
