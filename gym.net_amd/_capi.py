@@ -110,6 +110,7 @@ PROTOTYPES = {
     "gymnet_vecenv_set_tick": (C.c_int, [_H, C.c_uint64]),
     "gymnet_vecenv_counters": (C.c_int, [_H, C.POINTER(Counters)]),
     "gymnet_vecenv_done_lanes": (C.c_int, [_H, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "gymnet_vecenv_done_lanes_device": (C.c_int, [_H, _P, _P]),
     "gymnet_vecenv_episode_stats": (C.c_int, [_H, _P, _P]),
     "gymnet_vecenv_final_obs": (C.c_int, [_H, _P]),
     "gymnet_sample_discrete_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32,

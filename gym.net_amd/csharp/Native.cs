@@ -76,6 +76,8 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_set_tick(IntPtr h, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_counters(IntPtr h, out GymnetCounters counters);
         [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes(IntPtr h, int* lanes_out, long capacity, out long count);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes_device(IntPtr h, IntPtr d_lanes_out, IntPtr d_count_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_fused_device(IntPtr h, IntPtr d_actions, long steps, long action_stride, long ring, IntPtr rec);
         [DllImport(Lib)] public static extern int gymnet_vecenv_episode_stats(IntPtr h, float* finished_return, int* finished_length);
         [DllImport(Lib)] public static extern int gymnet_vecenv_final_obs(IntPtr h, float* final_obs_out);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions(IntPtr h, void* actions_out, ulong seed, ulong tick);

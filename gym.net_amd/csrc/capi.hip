@@ -78,8 +78,9 @@ struct gymnet_vecenv {
     void *d_actions = nullptr;     // staging for host-path / broadcast actions
     float *d_pack = nullptr;       // row-major obs staging
     float *d_final_obs = nullptr;
-    int32_t *d_done_list = nullptr;
-    uint32_t *d_done_count2 = nullptr;
+    int32_t *d_done_list = nullptr, *d_done_compact = nullptr;    // sharded segments / compact list (on demand)
+    uint32_t *d_done_count2 = nullptr, *d_done_total = nullptr;
+    int64_t done_cap = 0;
     float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
     int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
     uint64_t *d_lane_seed = nullptr;
@@ -169,6 +170,7 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.final_obs = h->d_final_obs;
     a.done_list = h->d_done_list;
     a.done_count2 = h->d_done_count2;
+    a.done_cap = h->done_cap;
     a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
     a.lane_seed = h->d_lane_seed;
     a.after_done = h->d_after_done;
@@ -247,6 +249,13 @@ int stage_host_actions(gymnet_vecenv *h, const void *actions) {
     if (!actions) return fail(h, GYMNET_ERR_INVALID_ARG, "actions is null");
     HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
     return validate_staged_actions(h, h->d_actions);
+}
+
+// gathers the sharded done list of the most recent step into one compact list (stream-ordered, non-blocking)
+int compact_done(gymnet_vecenv *h, int32_t *d_out, uint32_t *d_count) {
+    const uint32_t *counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
+    HIP_TRY(h, launch_compact_done(counts, h->d_done_list, h->done_cap, d_out, d_count, h->stream));
+    return GYMNET_OK;
 }
 
 void recompute_extras(gymnet_vecenv *h) {
@@ -408,14 +417,21 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     CREATE_TRY(dalloc(h, &h->d_tick2, 2));
     CREATE_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)padded));
     CREATE_TRY(dalloc(h, &h->d_pack, (size_t)padded * d.obs_dim));
-    CREATE_TRY(dalloc(h, &h->d_after_done, 1));
+    CREATE_TRY(dalloc(h, &h->d_after_done, (size_t)kShards * kAfterStride));
     CREATE_TRY(dalloc(h, &h->d_bad, 1));
     if (d.has_sbd && !h->autoreset) CREATE_TRY(dalloc(h, &h->d_sbd, (size_t)padded));
     if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, &h->d_final_obs, (size_t)h->n * d.obs_dim));
     if (cfg->flags & GYMNET_FLAG_DONE_LIST) {
-        CREATE_TRY(dalloc(h, &h->d_done_list, (size_t)padded));
-        CREATE_TRY(dalloc(h, &h->d_done_count2, 2));
-        CREATE_HIP(hipMemsetAsync(h->d_done_count2, 0, 2 * sizeof(uint32_t), h->stream));
+        // segment capacity: the most lanes the waves of one shard can own, for either lane width (dwordx4 / scalar)
+        const int64_t w4 = (h->n + 255) / 256, w1 = (h->n + 63) / 64;
+        const int64_t cap4 = (w4 + kShards - 1) / kShards * 256, cap1 = (w1 + kShards - 1) / kShards * 64;
+        h->done_cap = cap4 > cap1 ? cap4 : cap1;
+        CREATE_TRY(dalloc(h, &h->d_done_list, (size_t)kShards * (size_t)h->done_cap));
+        CREATE_TRY(dalloc(h, &h->d_done_compact, (size_t)padded));
+        CREATE_TRY(dalloc(h, &h->d_done_count2, (size_t)2 * kShards * kCountStride));
+        CREATE_TRY(dalloc(h, &h->d_done_total, 1));
+        CREATE_HIP(hipMemsetAsync(h->d_done_count2, 0, (size_t)2 * kShards * kCountStride * sizeof(uint32_t), h->stream));
+        CREATE_HIP(hipMemsetAsync(h->d_done_total, 0, sizeof(uint32_t), h->stream));
     }
     if (cfg->flags & GYMNET_FLAG_EPISODE_STATS) {
         CREATE_TRY(dalloc(h, &h->d_ep_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_ep_len, (size_t)padded));
@@ -431,7 +447,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_reward, 0, (size_t)padded * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_done, 0, (size_t)padded, h->stream));
-    CREATE_HIP(hipMemsetAsync(h->d_after_done, 0, sizeof(unsigned long long), h->stream));
+    CREATE_HIP(hipMemsetAsync(h->d_after_done, 0, (size_t)kShards * kAfterStride * sizeof(unsigned long long), h->stream));
     if (h->d_final_obs) CREATE_HIP(hipMemsetAsync(h->d_final_obs, 0, (size_t)h->n * d.obs_dim * 4, h->stream));
     if (h->d_sbd) CREATE_HIP(launch_fill_i32(h->d_sbd, -1, h->n, h->stream));
     CREATE_TRY(write_tick(h));
@@ -714,7 +730,7 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     out->state_dim = h->desc->state_dim; out->obs_dim = h->desc->obs_dim; out->obs_aliases_state = h->desc->alias;
     out->num_envs = h->n; out->state_stride = h->sstride; out->obs_stride = h->ostride;
     out->d_state = h->d_state; out->d_obs = h->d_obs; out->d_reward = h->d_reward; out->d_done = h->d_done;
-    out->d_steps_beyond_done = h->d_sbd; out->d_final_obs = h->d_final_obs; out->d_done_list = h->d_done_list;
+    out->d_steps_beyond_done = h->d_sbd; out->d_final_obs = h->d_final_obs; out->d_done_list = h->d_done_compact;
     out->d_episode_return = h->d_ep_ret; out->d_episode_length = h->d_ep_len;
     out->d_finished_return = h->d_fin_ret; out->d_finished_length = h->d_fin_len;
     out->stream = h->stream;
@@ -790,17 +806,25 @@ int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out) {
     if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
     std::memset(out, 0, sizeof *out);
     out->struct_size = sizeof *out;
-    unsigned long long ad = 0;
-    HIP_TRY(h, hipMemcpyAsync(&ad, h->d_after_done, sizeof ad, hipMemcpyDeviceToHost, h->stream));
-    uint32_t cnt[2] = {0, 0};
-    if (h->d_done_count2) HIP_TRY(h, hipMemcpyAsync(cnt, h->d_done_count2, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    std::vector<unsigned long long> adv((size_t)kShards * kAfterStride);
+    HIP_TRY(h, hipMemcpyAsync(adv.data(), h->d_after_done, adv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint32_t> cntv;
+    if (h->d_done_count2 && h->last_cparity >= 0) {
+        cntv.resize((size_t)kShards * kCountStride);
+        HIP_TRY(h, hipMemcpyAsync(cntv.data(), h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride,
+                                  cntv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned long long ad = 0;
+    for (int s = 0; s < kShards; ++s) ad += adv[(size_t)s * kAfterStride];
+    int64_t last_done = -1;
+    if (!cntv.empty()) { last_done = 0; for (int s = 0; s < kShards; ++s) last_done += cntv[(size_t)s * kCountStride]; }
     uint64_t dtick[2] = {0, 0};
     HIP_TRY(h, hipMemcpy(dtick, h->d_tick2, sizeof dtick, hipMemcpyDeviceToHost));
     out->tick = dtick[h->tslot];   // the device's own count (== host mirror h->tick)
     out->lane_steps = h->lane_steps;
     out->stepped_after_done = ad;
-    out->last_done_count = (h->d_done_count2 && h->last_cparity >= 0) ? (int64_t)cnt[h->last_cparity] : -1;
+    out->last_done_count = last_done;
     return GYMNET_OK;
     });
 }
@@ -810,14 +834,26 @@ int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capac
     ENTER(h);
     if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
     if (!count || capacity < 0 || (capacity > 0 && !lanes_out)) return fail(h, GYMNET_ERR_INVALID_ARG, "bad count/capacity/lanes_out");
-    uint32_t cnt[2] = {0, 0};
-    HIP_TRY(h, hipMemcpyAsync(cnt, h->d_done_count2, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    if (h->last_cparity < 0) { *count = 0; return GYMNET_OK; }
+    ST_TRY(compact_done(h, h->d_done_compact, h->d_done_total));
+    uint32_t c32 = 0;
+    HIP_TRY(h, hipMemcpyAsync(&c32, h->d_done_total, sizeof c32, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const int64_t c = h->last_cparity >= 0 ? (int64_t)cnt[h->last_cparity] : 0;
+    const int64_t c = (int64_t)c32;
     *count = c;
     const int64_t m = c < capacity ? c : capacity;
-    if (m > 0) HIP_TRY(h, hipMemcpy(lanes_out, h->d_done_list, (size_t)m * 4, hipMemcpyDeviceToHost));
+    if (m > 0) HIP_TRY(h, hipMemcpy(lanes_out, h->d_done_compact, (size_t)m * 4, hipMemcpyDeviceToHost));
     return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint32_t *d_count_out) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
+    if (!d_count_out) return fail(h, GYMNET_ERR_INVALID_ARG, "d_count_out is null");
+    if (h->last_cparity < 0) { HIP_TRY(h, hipMemsetAsync(d_count_out, 0, sizeof(uint32_t), h->stream)); return GYMNET_OK; }
+    return compact_done(h, d_lanes_out ? d_lanes_out : h->d_done_compact, d_count_out);
     });
 }
 

@@ -114,6 +114,21 @@ __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// shard of the calling wave for the sharded counters / done list (StepArgs)
+__device__ __forceinline__ uint32_t wave_shard() {
+    return (uint32_t)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kShards - 1));
+}
+
+// one 64-bit atomic per WAVE (and only if the wave has something to report) into the wave's shard
+template <int VEC>
+__device__ __forceinline__ void count_after_done(const StepArgs &a, const bool (&after)[VEC]) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) total += (uint32_t)__popcll(__ballot(after[j]));
+    if (total && lane_id() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1))
+        atomicAdd(&a.after_done[wave_shard() * kAfterStride], (unsigned long long)total);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The vector step: ONE launch advances every lane by one env-step.
 //   Env       dynamics (envs.hpp)
@@ -151,6 +166,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     float reward[VEC];
     uint8_t done[VEC];
     bool finished[VEC];
+    bool after[VEC];          // sub-lane was stepped although it had already returned done (no auto-reset only)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) after[j] = false;
     float o[O][VEC];
     uint32_t pending = 0;     // sub-lanes of this thread that finished and await their reset draw
 
@@ -168,7 +186,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
             if (dn) {
                 if (sbd[j] == -1) { sbd[j] = 0; }
                 else {
-                    if (!GUARD || i0 + j < n) atomicAdd(a.after_done, 1ull);   // the reference's console warning, counted
+                    after[j] = !GUARD || i0 + j < n;   // the reference's console warning (:176-179), counted below
                     sbd[j] += 1;
                     rw = 0.0f;
                 }
@@ -213,6 +231,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
             for (int k = 0; k < O; ++k) o[k][j] = oj[k];
         }
     }
+
+    if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
 
     // reward / done do not depend on the reset draw: get them on their way before the Philox rounds
     store_f32<VEC, NT_O, GUARD>(a.reward, i0, n, reward);
@@ -274,12 +294,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
             }
             if (total) {   // wave-uniform
                 const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+                const uint32_t shard = wave_shard();
                 uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&a.done_count2[a.cparity], total);
+                if ((int)lane == leader)
+                    base = atomicAdd(&a.done_count2[a.cparity * (kShards * kCountStride) + shard * kCountStride], total);
                 base = __shfl(base, leader);
+                int32_t *seg = a.done_list + (int64_t)shard * a.done_cap;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    if (finished[j]) a.done_list[base + off[j]] = (int32_t)(i0 + j);
+                    if (finished[j]) seg[base + off[j]] = (int32_t)(i0 + j);
             }
         }
     }
@@ -293,9 +316,10 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const uint64_t tick = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.tick2[a.parity ^ 1] = tick + 1;
-        if constexpr (EXTRAS) {
-            if (a.done_count2) a.done_count2[a.cparity ^ 1] = 0u;   // the NEXT step launch's counter
-        }
+    }
+    if constexpr (EXTRAS) {
+        if (blockIdx.x == 0 && a.done_count2)     // zero the NEXT step launch's half of the shard counters
+            for (int sh = threadIdx.x; sh < kShards; sh += blockDim.x) a.done_count2[(a.cparity ^ 1) * (kShards * kCountStride) + sh * kCountStride] = 0u;
     }
     // workgroup-uniform: every workgroup but (at most) the last runs the unguarded body
     if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {
@@ -347,6 +371,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
         if (nslice == ro.ring) nslice = 0;
         if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math
         uint32_t pending = 0;
+        bool after[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) after[j] = false;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float sj[S];
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
             if constexpr (!AUTORESET && Env::HAS_SBD) {
                 if (dn) {
                     if (sbd[j] == -1) { sbd[j] = 0; }
-                    else { if (i0 + j < n) atomicAdd(a.after_done, 1ull); sbd[j] += 1; rw = 0.0f; }
+                    else { after[j] = i0 + j < n; sbd[j] += 1; rw = 0.0f; }
                 }
             }
             done[j] = dn ? 1 : 0;
@@ -373,6 +400,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
                 for (int k = 0; k < O; ++k) o[k][j] = oj[k];
             }
         }
+        if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
         if (ro.rec_reward) store_f32<VEC, true, true>(ro.rec_reward + t * n, i0, n, reward);
         if (ro.rec_done) store_u8<VEC, true, true>(ro.rec_done + t * n, i0, n, done);
         if constexpr (AUTORESET) {
@@ -482,6 +510,29 @@ __global__ __launch_bounds__(256) void pack_obs_kernel(const float *__restrict__
     }
 }
 
+// Gathers the kShards segments of one step's done list into one compact list.  One workgroup per shard; every
+// workgroup recomputes the (tiny) exclusive scan of the 256 shard counts in LDS, then copies its segment coalesced.
+__global__ __launch_bounds__(256) void compact_done_kernel(const uint32_t *__restrict__ counts, const int32_t *__restrict__ list,
+                                                           int64_t cap, int32_t *__restrict__ out, uint32_t *out_count) {
+    __shared__ uint32_t scan[kShards];
+    const int t = threadIdx.x;
+    const uint32_t mine = counts[t * kCountStride];
+    scan[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < kShards; d <<= 1) {            // Hillis-Steele inclusive scan, 8 rounds
+        const uint32_t v = t >= d ? scan[t - d] : 0u;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const int shard = blockIdx.x;
+    const uint32_t cnt = counts[shard * kCountStride];
+    const uint32_t start = scan[shard] - cnt;
+    if (shard == 0 && t == 0) *out_count = scan[kShards - 1];
+    const int32_t *seg = list + (int64_t)shard * cap;
+    for (uint32_t k = t; k < cnt; k += 256) out[start + k] = seg[k];
+}
+
 __global__ __launch_bounds__(256) void fill_i32_kernel(int32_t *p, int32_t v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -546,9 +597,9 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
         else if (cfg.nt == 12) GYMNET_LAUNCH(V, AR, EX, 12);          \
         else GYMNET_LAUNCH(V, AR, EX, 0);                             \
     } while (0)
-    if (extras) {   // bookkeeping variants: not the measured hot path, one NT policy (none) is enough
-        if (cfg.vec == 4) { if (autoreset) GYMNET_LAUNCH(4, true, true, 0); else GYMNET_LAUNCH(4, false, true, 0); }
-        else              { if (autoreset) GYMNET_LAUNCH(1, true, true, 0); else GYMNET_LAUNCH(1, false, true, 0); }
+    if (extras) {   // bookkeeping variants follow the same stream policy (their own arrays stay cacheable)
+        if (cfg.vec == 4) { if (autoreset) GYMNET_LAUNCH_NT(4, true, true); else GYMNET_LAUNCH_NT(4, false, true); }
+        else              { if (autoreset) GYMNET_LAUNCH_NT(1, true, true); else GYMNET_LAUNCH_NT(1, false, true); }
     } else if (cfg.vec == 4) {
         if (autoreset) GYMNET_LAUNCH_NT(4, true, false); else GYMNET_LAUNCH_NT(4, false, false);
     } else {
@@ -637,6 +688,11 @@ hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float 
 hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int64_t cap, int32_t *out, uint32_t *out_count, hipStream_t st) {
+    hipLaunchKernelGGL(compact_done_kernel, dim3(kShards), dim3(256), 0, st, counts, list, cap, out, out_count);
     return hipGetLastError();
 }
 

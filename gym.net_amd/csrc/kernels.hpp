@@ -16,11 +16,15 @@ struct StepArgs {
     uint64_t *tick2;         // device tick, double-buffered: launch with tick t reads tick2[t&1], writes tick2[(t+1)&1]=t+1
     // extras (all NULL / 0 in the lean hot-path variant)
     float *final_obs;        // [O][n]
-    int32_t *done_list;      // [n]
-    uint32_t *done_count2;   // [2] double-buffered: this launch fills [cparity] and zeroes [cparity^1] for the next
+    // Done-lane compaction is SHARDED: 4096 waves hammering one counter word serialise at ~88 atomics/us (46 us per
+    // step at 2^20 lanes, measured); wave w appends to shard w % kShards, each shard has its own counter (64-byte
+    // stride) and its own segment of the list.  compact_done gathers the segments into one list on demand.
+    int32_t *done_list;      // [kShards][done_cap] segmented
+    uint32_t *done_count2;   // [2][kShards * kCountStride]: this launch fills half [cparity] and zeroes half [cparity^1]
+    int64_t done_cap;        // entries per shard segment
     float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;
     const uint64_t *lane_seed;       // [n] per-lane Philox keys (VecEnv.Seed(int[])) or NULL
-    unsigned long long *after_done;  // counter: steps taken on already-done lanes (CartPoleEnv.cs:176-179)
+    unsigned long long *after_done;  // [kShards * kAfterStride] sharded counter: steps taken on already-done lanes (CartPoleEnv.cs:176-179)
     int64_t n, state_stride, obs_stride;
     uint64_t lane_offset, seed;
     int32_t parity;          // tick & 1 of this launch
@@ -30,6 +34,10 @@ struct StepArgs {
 
 // vec: envs per thread (4 = dwordx4 streams, 1 = scalar); block: threads per workgroup;
 // nt: non-temporal mask (0 none, 12 action + reward/done streams, 15 every stream)
+constexpr int kShards = 256;        // power of two
+constexpr int kCountStride = 16;    // uint32 words between shard counters (64 bytes: one counter per cache line)
+constexpr int kAfterStride = 8;     // uint64 words between after_done shards (64 bytes)
+
 struct LaunchCfg { int vec; int block; int nt; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
@@ -64,6 +72,8 @@ hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float 
 hipError_t launch_observe(int env_id, const float *state, int64_t state_stride, float *obs, int64_t obs_stride,
                           int64_t n, hipStream_t st);
 hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st);
+// gathers the sharded done list of one step (counter half `counts`) into out[0 .. *out_count)
+hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int64_t cap, int32_t *out, uint32_t *out_count, hipStream_t st);
 // counts actions outside [0, nvals) into *bad
 hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,

@@ -278,6 +278,10 @@ class VectorEnv:
         capi.check(self._lib.gymnet_vecenv_done_lanes(self._h, _host(lanes), n, C.byref(cnt)))
         return lanes[:cnt.value].copy()
 
+    def DoneLanesDevice(self, d_lanes_out, d_count_out):
+        """Compact list of the lanes that finished in the last step, left on the device (stream-ordered)."""
+        capi.check(self._lib.gymnet_vecenv_done_lanes_device(self._h, _ptr(d_lanes_out), _ptr(d_count_out)))
+
     def EpisodeStats(self):
         n = self.NumberOfEnvironments
         ret, ln = np.empty(n, np.float32), np.empty(n, np.int32)

@@ -121,7 +121,7 @@ typedef struct gymnet_device_view {
     uint8_t *d_done;           /* [num_envs] */
     int32_t *d_steps_beyond_done; /* CartPole without AUTORESET: CartPoleEnv.cs:41 per lane; else NULL */
     float   *d_final_obs;      /* [obs_dim][num_envs], FINAL_OBS only */
-    int32_t *d_done_list;      /* [num_envs], DONE_LIST only */
+    int32_t *d_done_list;      /* [num_envs] compact list, valid after gymnet_vecenv_done_lanes(_device); DONE_LIST only */
     float   *d_episode_return; int32_t *d_episode_length;     /* running, EPISODE_STATS only */
     float   *d_finished_return; int32_t *d_finished_length;   /* last finished episode per lane */
     void    *stream;           /* hipStream_t all of the handle's work is ordered on */
@@ -222,6 +222,11 @@ int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out);
 /* ---- episode bookkeeping (the step AFTER the path: BasePlaySession.cs:58-69) ------------------ */
 /* Lanes that finished in the most recent step (unordered). Needs GYMNET_FLAG_DONE_LIST. */
 int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capacity, int64_t *count);
+/* Device-side form: writes the compact list to d_lanes_out (capacity num_envs int32; NULL = the handle's own buffer,
+ * gymnet_device_view.d_done_list) and the count to *d_count_out.  Stream-ordered, does not block.  (Inside the step
+ * kernel the list is built per wave with ballot + one atomic into one of 256 shard counters; this call gathers the
+ * shards.) */
+int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint32_t *d_count_out);
 /* Last finished episode's return and length per lane (0 length = none finished yet). Needs EPISODE_STATS. */
 int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length);
 /* Terminal observations, host [num_envs, obs_dim]; rows of lanes that never finished are 0. Needs FINAL_OBS. */

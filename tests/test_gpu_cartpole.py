@@ -255,6 +255,12 @@ def test_done_list_episode_stats_final_obs(gpu_pkg, oracle):
             out = env.Step(a)
             lanes = env.DoneLanes()
             assert sorted(lanes.tolist()) == np.nonzero(out.Done)[0].tolist()       # wave-ballot compaction == mask
+            if t % 20 == 0:                                                         # device-side gather of the 256 shards
+                import torch
+                d_l = torch.full((n,), -1, dtype=torch.int32, device="cuda"); d_c = torch.zeros(1, dtype=torch.int32, device="cuda")
+                env.DoneLanesDevice(d_l, d_c); env.Sync()
+                c = int(d_c.item())
+                assert c == len(lanes) and sorted(d_l[:c].cpu().tolist()) == sorted(lanes.tolist())
             assert env.Counters()["last_done_count"] == int(out.Done.sum())
             term = oracle.cartpole_step(s, a, dtype=np.float32)[0]                  # terminal obs, kernel semantics
             ret += out.Reward; ln += 1

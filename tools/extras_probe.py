@@ -1,0 +1,24 @@
+"""Times the bookkeeping (EXTRAS) variants of the step kernel at 2^20 CartPole lanes."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+dev = torch.device("cuda", 0)
+st = torch.cuda.Stream(dev); torch.cuda.set_stream(st)
+n, ring, T = 1 << 20, 64, 1024
+out = {}
+for label, kw in (("lean", {}), ("done_list", dict(done_list=True)), ("episode_stats", dict(episode_stats=True)),
+                  ("done_list+stats", dict(done_list=True, episode_stats=True)),
+                  ("all", dict(done_list=True, episode_stats=True, final_obs=True)), ("no_autoreset(sbd)", dict(auto_reset=False))):
+    a = dict(auto_reset=True); a.update(kw)
+    env = pkg.VectorEnv("CartPole-v1", n, seed=1, stream=st.cuda_stream, **a)
+    acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+    for t in range(ring):
+        env.SampleActionsDevice(acts[t], seed=2, tick=t)
+    env.ResetDevice(); env.RolloutDevice(acts, 128, n, ring); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st); env.RolloutDevice(acts, T, n, ring); e1.record(st); torch.cuda.synchronize()
+    out[label] = e0.elapsed_time(e1) * 1e3 / T
+    env.Close()
+print(json.dumps(out))
