@@ -519,11 +519,9 @@ int gymnet_vecenv_reset_device(gymnet_vecenv *h) {
 int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (!d_mask) {   // own done flags: snapshot them, because the reset kernel clears done for reset lanes
-        HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
-        d_mask = h->d_mask;
-    }
-    return launch_reset_lanes(h, d_mask);
+    // own done flags: the reset kernel may read its mask from the very array it clears (each lane's flag is read
+    // before the same thread clears it), so no snapshot copy is needed
+    return launch_reset_lanes(h, d_mask ? d_mask : h->d_done);
     });
 }
 
@@ -539,8 +537,7 @@ int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_
     return guarded([&]() -> int {
     ENTER(h);
     if (mask) HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
-    else HIP_TRY(h, hipMemcpyAsync(h->d_mask, h->d_done, (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
-    ST_TRY(launch_reset_lanes(h, h->d_mask));
+    ST_TRY(launch_reset_lanes(h, mask ? h->d_mask : h->d_done));
     return copy_out(h, obs_out, nullptr, nullptr);
     });
 }

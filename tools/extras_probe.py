@@ -22,3 +22,20 @@ for label, kw in (("lean", {}), ("done_list", dict(done_list=True)), ("episode_s
     out[label] = e0.elapsed_time(e1) * 1e3 / T
     env.Close()
 print(json.dumps(out))
+
+# the reference-faithful loop on the device: Step (no auto-reset) followed by the caller's `if (done) Reset()`
+env = pkg.VectorEnv("CartPole-v1", n, seed=1, stream=st.cuda_stream, auto_reset=False)
+acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+for t in range(ring):
+    env.SampleActionsDevice(acts[t], seed=2, tick=t)
+env.ResetDevice()
+for t in range(64):
+    env.StepDevice(acts[t % ring]); env.ResetWhereDevice()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for t in range(T):
+    env.StepDevice(acts[t % ring]); env.ResetWhereDevice()
+e1.record(st); torch.cuda.synchronize()
+print(json.dumps({"step + reset_where (reference loop shape), us per iteration": e0.elapsed_time(e1) * 1e3 / T}))
+env.Close()
