@@ -148,3 +148,19 @@ def test_shard_plan(gymnet):
         assert q.offset(r) + i == lane and 0 <= i < q.count(r)
     with pytest.raises(ValueError):
         gymnet.ShardPlan(2, 3)
+
+
+def test_missing_extension_raises_instead_of_falling_back(tmp_path):
+    # a fresh interpreter whose package copy has no lib/: loading must raise, and nothing CPU-side may take over
+    import shutil
+    import subprocess
+    import sys
+    pkg_copy = tmp_path / "gym.net_amd"
+    shutil.copytree(os.path.join(ROOT, "gym.net_amd"), pkg_copy, ignore=shutil.ignore_patterns("lib", "__pycache__", "csrc", "csharp"))
+    code = (
+        "import importlib.util, sys\n"
+        f"spec = importlib.util.spec_from_file_location('gymnet_amd', r'{pkg_copy}/__init__.py', submodule_search_locations=[r'{pkg_copy}'])\n"
+        "m = importlib.util.module_from_spec(spec); sys.modules['gymnet_amd'] = m; spec.loader.exec_module(m)\n"
+        "try:\n    m.VectorEnv('CartPole-v1', 4)\nexcept m.GymNetError as e:\n    print('RAISED', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED" in r.stdout and "has not been built" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
