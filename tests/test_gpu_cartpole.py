@@ -197,6 +197,7 @@ def test_graph_rollout_equals_eager_steps_bitwise(gpu_pkg, monkeypatch, force_gr
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as g, \
             gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as e:
         acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         for t in range(ring):
             g.SampleActionsDevice(acts[t], seed=SEED + 1, tick=t)
         g.Sync()
@@ -258,6 +259,7 @@ def test_done_list_episode_stats_final_obs(gpu_pkg, oracle):
             if t % 20 == 0:                                                         # device-side gather of the 256 shards
                 import torch
                 d_l = torch.full((n,), -1, dtype=torch.int32, device="cuda"); d_c = torch.zeros(1, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
                 env.DoneLanesDevice(d_l, d_c); env.Sync()
                 c = int(d_c.item())
                 assert c == len(lanes) and sorted(d_l[:c].cpu().tolist()) == sorted(lanes.tolist())
@@ -325,6 +327,7 @@ def test_invalid_actions(gpu_pkg, oracle):
         import torch                                                      # device rollouts validate every slice up front
         acts_dev = torch.ones((4, n), dtype=torch.int32, device="cuda")
         acts_dev[2, 5] = 7
+        torch.cuda.synchronize()                                          # torch's stream is not the engine's stream
         before = env.GetState()
         with pytest.raises(gpu_pkg.InvalidActionError):
             env.RolloutDevice(acts_dev, 8, n, 4)
@@ -374,6 +377,7 @@ def test_external_obs_buffer_and_unaligned_fallback(gpu_pkg):
     for shift in (0, 1):
         buf = torch.zeros(4 * n + 8, dtype=torch.float32, device=dev)
         view = buf[shift:shift + 4 * n]
+        torch.cuda.synchronize()                                          # torch's fill must land before the engine owns the buffer
         with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, ext_obs=view.data_ptr(), ext_obs_stride=n) as env:
             env.Reset()
             for t in range(steps):
@@ -460,12 +464,14 @@ def test_fused_rollout_equals_stepwise_and_records(gpu_pkg, name, auto, n):
         adt = torch.float32 if name == "Pendulum-v1" else torch.int32
         stride = (n + 3) // 4 * 4
         acts = torch.zeros((ring, stride), dtype=adt, device=dev)
+        torch.cuda.synchronize()
         for t in range(ring):
             f.SampleActionsDevice(acts[t], seed=SEED + 1, tick=t)
         f.Sync()
         rec_obs = torch.zeros((T, D, n), dtype=torch.float32, device=dev)
         rec_rew = torch.zeros((T, n), dtype=torch.float32, device=dev)
         rec_done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         f.ResetDevice(); e.ResetDevice()
         f.RolloutFusedDevice(acts, T, stride, ring, rec_obs, rec_rew, rec_done)
         f.Sync()

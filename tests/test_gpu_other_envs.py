@@ -150,8 +150,10 @@ def test_long_fused_rollout_stays_deterministic_and_in_bounds(gpu_pkg):
     dev = torch.device("cuda", 0)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as f, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as e:
         acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         for t in range(ring):
             f.SampleActionsDevice(acts[t], seed=5, tick=t)
+        f.Sync()
         f.ResetDevice(); e.ResetDevice()
         f.RolloutFusedDevice(acts, T, n, ring)
         e.RolloutDevice(acts, T, n, ring)                # graph replay at this size
