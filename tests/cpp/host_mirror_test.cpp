@@ -91,6 +91,18 @@ static void gpu_tests() {
         CHECK(episodes > 10 && episodes < 80 && steps + episodes == 1000, "alternating-action episodes average ~37 steps");
         cp.CloseEnvironment();
     }
+    {   // README.md:32-52 — the 100 000-iteration variant of the same loop (without Render / Thread.Sleep)
+        gymnet::CartPoleEnv cp(0, 99);
+        bool done = true;
+        long episodes = 0, steps = 0;
+        for (int i = 0; i < 100000; ++i) {
+            if (done) { cp.Reset(); done = false; ++episodes; }
+            else { auto st = cp.Step(i % 2); done = st.Done; ++steps; }
+        }
+        const double mean_len = (double)steps / (double)episodes;
+        CHECK(mean_len > 25.0 && mean_len < 50.0, "alternating-action episodes average ~37.5 steps (SURVEY App. C)");
+        cp.CloseEnvironment();
+    }
     {   // teacher-forced single steps vs the double closed form: |err| <= 1e-5, done exact (north_star bar)
         const int64_t n = 4096;
         gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, n, 0, 7);
