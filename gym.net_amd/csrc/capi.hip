@@ -23,6 +23,7 @@ using namespace gymnet;
 namespace {
 
 thread_local std::string g_last_error;
+constexpr int64_t kSmallHostPath = 4096;
 
 struct EnvDesc {
     const char *name;
@@ -85,6 +86,11 @@ struct gymnet_vecenv {
     int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
     uint64_t *d_lane_seed = nullptr;
     unsigned long long *d_after_done = nullptr;
+    // small batches (n <= kSmallHostPath): host-mapped staging, so a host-boundary step is 2 kernel launches + 1 sync
+    void *hm_actions = nullptr;    // pinned + mapped: the step kernel reads the actions straight from it
+    float *hm_obs = nullptr, *hm_reward = nullptr;
+    uint8_t *hm_done = nullptr;
+    void *hm_block = nullptr;
     uint32_t *d_bad = nullptr;
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
     int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
@@ -220,6 +226,16 @@ int write_tick(gymnet_vecenv *h) {
 // copy the current results to host buffers (any may be NULL); blocks
 int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
+    if (h->hm_block) {   // latency path for small batches: one export kernel into host-mapped memory, one sync, host memcpy
+        if (obs_out || reward_out || done_out)
+            HIP_TRY(h, launch_export_small(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, h->hm_obs,
+                                           reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr, h->n, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (obs_out) std::memcpy(obs_out, h->hm_obs, (size_t)h->n * d.obs_dim * sizeof(float));
+        if (reward_out) std::memcpy(reward_out, h->hm_reward, (size_t)h->n * sizeof(float));
+        if (done_out) std::memcpy(done_out, h->hm_done, (size_t)h->n);
+        return GYMNET_OK;
+    }
     if (obs_out) {
         HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
         HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -245,10 +261,17 @@ int validate_staged_actions(gymnet_vecenv *h, const void *d_actions) {
     return GYMNET_OK;
 }
 
-int stage_host_actions(gymnet_vecenv *h, const void *actions) {
+// stages host actions; *d_use receives the device-visible pointer the step kernel should read
+int stage_host_actions(gymnet_vecenv *h, const void *actions, const void **d_use) {
     if (!actions) return fail(h, GYMNET_ERR_INVALID_ARG, "actions is null");
-    HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
-    return validate_staged_actions(h, h->d_actions);
+    if (h->hm_block) {   // the previous step's kernel has completed (every host-boundary call ends with a sync)
+        std::memcpy(h->hm_actions, actions, (size_t)h->n * 4);
+        *d_use = h->hm_actions;
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
+        *d_use = h->d_actions;
+    }
+    return validate_staged_actions(h, *d_use);
 }
 
 // gathers the sharded done list of the most recent step into one compact list (stream-ordered, non-blocking)
@@ -341,6 +364,7 @@ int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     for (void *p : h->owned) (void)hipFree(p);
+    if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GYMNET_OK;
@@ -419,6 +443,17 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     CREATE_TRY(dalloc(h, &h->d_pack, (size_t)padded * d.obs_dim));
     CREATE_TRY(dalloc(h, &h->d_after_done, (size_t)kShards * kAfterStride));
     CREATE_TRY(dalloc(h, &h->d_bad, 1));
+    if (h->n <= kSmallHostPath) {
+        const size_t a_bytes = (size_t)padded * 4, o_bytes = (size_t)padded * d.obs_dim * 4, r_bytes = (size_t)padded * 4, d_bytes = (size_t)padded;
+        if (hipHostMalloc(&h->hm_block, a_bytes + o_bytes + r_bytes + d_bytes, hipHostMallocMapped) == hipSuccess) {
+            char *b = static_cast<char *>(h->hm_block);
+            h->hm_actions = b; h->hm_obs = reinterpret_cast<float *>(b + a_bytes);
+            h->hm_reward = reinterpret_cast<float *>(b + a_bytes + o_bytes); h->hm_done = reinterpret_cast<uint8_t *>(b + a_bytes + o_bytes + r_bytes);
+        } else {
+            (void)hipGetLastError();
+            h->hm_block = nullptr;             // fall back to the memcpy path
+        }
+    }
     if (d.has_sbd && !h->autoreset) CREATE_TRY(dalloc(h, &h->d_sbd, (size_t)padded));
     if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, &h->d_final_obs, (size_t)h->n * d.obs_dim));
     if (cfg->flags & GYMNET_FLAG_DONE_LIST) {
@@ -546,8 +581,9 @@ int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, fl
     return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
-    ST_TRY(stage_host_actions(h, actions));
-    ST_TRY(launch_one_step(h, h->d_actions));
+    const void *d_act = nullptr;
+    ST_TRY(stage_host_actions(h, actions, &d_act));
+    ST_TRY(launch_one_step(h, d_act));
     return copy_out(h, obs_out, reward_out, done_out);
     });
 }
@@ -576,8 +612,9 @@ int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions) {
     return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
-    ST_TRY(stage_host_actions(h, actions));
-    ST_TRY(launch_one_step(h, h->d_actions));
+    const void *d_act = nullptr;
+    ST_TRY(stage_host_actions(h, actions, &d_act));
+    ST_TRY(launch_one_step(h, d_act));
     h->async_pending = true;
     return GYMNET_OK;
     });

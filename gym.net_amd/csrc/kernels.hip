@@ -548,6 +548,18 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const uint32_t *__res
     for (uint32_t k = t; k < cnt; k += 256) out[start + k] = seg[k];
 }
 
+template <int O>
+__global__ __launch_bounds__(256) void export_small_kernel(const float *__restrict__ obs, int64_t stride, const float *__restrict__ reward,
+                                                           const uint8_t *__restrict__ done, float *out_obs, float *out_reward,
+                                                           uint8_t *out_done, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < O; ++k) out_obs[i * O + k] = obs[k * stride + i];
+    if (out_reward) out_reward[i] = reward[i];
+    if (out_done) out_done[i] = done[i];
+}
+
 __global__ __launch_bounds__(256) void fill_i32_kernel(int32_t *p, int32_t v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -695,6 +707,20 @@ hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float 
         case 3: hipLaunchKernelGGL(pack_obs_kernel<3>, grid, blk, 0, st, obs, stride, out, n); break;
         case 4: hipLaunchKernelGGL(pack_obs_kernel<4>, grid, blk, 0, st, obs, stride, out, n); break;
         case 6: hipLaunchKernelGGL(pack_obs_kernel<6>, grid, blk, 0, st, obs, stride, out, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_export_small(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
+                               float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid(grid_for(n, 256)), blk(256);
+    switch (obs_dim) {
+        case 2: hipLaunchKernelGGL(export_small_kernel<2>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
+        case 3: hipLaunchKernelGGL(export_small_kernel<3>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
+        case 4: hipLaunchKernelGGL(export_small_kernel<4>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
+        case 6: hipLaunchKernelGGL(export_small_kernel<6>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
