@@ -12,8 +12,9 @@ Weak scaling: every GPU owns 2^20 lanes of one global batch of N * 2^20 lanes (c
 lanes are independent, so the data path has no collective (`--allgather` adds the per-step RCCL
 observation all-gather north_star mentions, for measuring what it costs).
 
-The timed region is K steps, replayed from a hipGraph of one-launch-per-step kernels, bracketed by
-barrier + synchronize; inputs are resident in HBM before it starts.  Prints ONE JSON line.
+The timed region is K steps, one kernel launch per step (gymnet_vecenv_rollout_device: back-to-back stream
+launches at this size, hipGraph replay for batches that are launch-bound), bracketed by barrier + synchronize;
+inputs are resident in HBM before it starts.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -196,7 +197,9 @@ def main():
             "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), float32 SoA state, "
                                    "fused auto-reset, iid random actions pre-generated in HBM",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
-                       "launch": "eager" if (args.no_graph or args.allgather) else "hipGraph replay, one kernel launch per step",
+                       "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or args.allgather) else
+                                  "one kernel launch per step; gymnet_vecenv_rollout_device: " +
+                                  ("hipGraph replay" if n * local.AlgorithmicBytesPerStep < (24 << 20) else "back-to-back stream launches")),
                        "allgather_obs": bool(args.allgather and use_dist), "parallelism": f"lane-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
