@@ -98,7 +98,7 @@ def main():
 
     # this rank's shard of the global batch; observations live inside the (optional) gather buffer
     env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=local_rank, seed=seed,
-                               auto_reset=True, gather_obs=args.allgather, tensor_device=dev,
+                               auto_reset=True, gather_obs=use_dist, tensor_device=dev,
                                force_gather=args.force_dist)
     local = env.local
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
@@ -179,6 +179,32 @@ def main():
         fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
                  "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
 
+    # Secondary figure for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
+    # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
+    # collective; this shows what a consumer that wants every rank to see all observations pays over xGMI.
+    gathered = None
+    if use_dist and not args.allgather:
+        try:
+            gs = 128
+            for t in range(16):
+                env.StepDevice(actions[t % ring].data_ptr()); env.AllGatherObs()
+            torch.cuda.synchronize(dev); barrier()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tg0 = time.perf_counter()
+            g0.record(stream)
+            for t in range(gs):
+                env.StepDevice(actions[t % ring].data_ptr()); env.AllGatherObs()
+            g1.record(stream)
+            torch.cuda.synchronize(dev); barrier()
+            gwall = time.perf_counter() - tg0
+            tg = torch.tensor([gwall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            ok = bool(torch.isfinite(env.GlobalObs()).all()) and all(float(env.GlobalObs()[r].abs().sum()) > 0 for r in range(world))
+            gathered = {"value": n * world * gs / float(tg[0]), "unit": "env-steps/s", "ms_per_step": float(tg[0]) * 1e3 / gs,
+                        "steps": gs, "allgather_bytes_per_rank_per_step": env.obs_dim * n * 4, "gathered_obs_finite_and_nonzero": ok}
+        except Exception as e:                      # never lose the headline over the optional collective
+            gathered = {"error": repr(e)[:200]}
+
     if rank == 0:
         bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
         launch_us = ev_ms * 1e3 / K                                          # HIP events over the timed region / launches
@@ -209,6 +235,8 @@ def main():
         }
         if fused:
             out["fused_rollout"] = fused
+        if gathered:
+            out["with_obs_allgather"] = gathered
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
