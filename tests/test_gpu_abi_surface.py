@@ -1,0 +1,97 @@
+"""GPU tests for the C-ABI entry points the parity suites do not reach: stand-alone space sampling (all four
+Box regimes of src/Gym/Spaces/Box.cs:69-90), device-side observation packing, the device view, per-lane seeds
+with fused auto-reset, external observation buffers for envs whose observation is derived."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def test_standalone_sampling_regimes(gpu_pkg, oracle):
+    import torch
+    lib, capi = gpu_pkg.load_library(), gpu_pkg._capi
+    n = 400_000
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    iout = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    inf = float("inf")
+
+    def box(low, high, tick):
+        capi.check(lib.gymnet_sample_box_device(0, None, C.c_void_p(out.data_ptr()), n, low, high, 7, 11, tick))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().astype(np.float64)
+
+    u = box(-5.0, 5.0, 1)                                               # bounded: uniform(low, high)   (BoxTest.cs:36-41)
+    assert u.min() >= -5.0 and u.max() <= 5.0 and abs(u.mean()) < 0.03 and abs(u.std() - 10 / np.sqrt(12)) < 0.03
+    assert np.array_equal(u.astype(np.float32), oracle.box_uniform_sample(7, 11, 1, -5.0, 5.0, n))
+    e = box(2.0, inf, 2)                                                # low-bounded: low + Exp(1)     (Box.cs:83)
+    assert e.min() >= 2.0 and abs(e.mean() - 3.0) < 0.02 and abs(e.std() - 1.0) < 0.03
+    h = box(-inf, 7.0, 3)                                               # high-bounded: high + Exp(1)   (Box.cs:84, sic)
+    assert h.min() >= 7.0 and abs(h.mean() - 8.0) < 0.02
+    g = box(-inf, inf, 4)                                               # unbounded: Normal(0.5, 1)     (Box.cs:82, sic)
+    assert abs(g.mean() - 0.5) < 0.01 and abs(g.std() - 1.0) < 0.01 and abs(((g - 0.5) ** 3).mean()) < 0.03
+    capi.check(lib.gymnet_sample_discrete_device(0, None, C.c_void_p(iout.data_ptr()), n, 3, 10, 7, 11, 5))
+    torch.cuda.synchronize()
+    d = iout.cpu().numpy()
+    assert np.array_equal(d, oracle.discrete_sample(7, 11, 5, 3, 10, n))     # Start + randint(0, N) (Discrete.cs:27)
+    assert set(np.unique(d)) == {10, 11, 12} and abs(np.bincount(d - 10) / n - 1 / 3).max() < 0.005
+    with pytest.raises(ValueError):
+        capi.check(lib.gymnet_sample_box_device(0, None, C.c_void_p(out.data_ptr()), n, 3.0, 1.0, 0, 0, 0))
+
+
+@pytest.mark.parametrize("name", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1"])
+def test_pack_obs_device_and_device_view(gpu_pkg, name):
+    import torch
+    n = 3000
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as env:
+        obs = env.Reset()
+        D = env.ObsDim
+        packed = torch.zeros((n, D), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        env.PackObsDevice(packed); env.Sync()
+        assert np.array_equal(packed.cpu().numpy(), obs)                 # row-major [N, D] == the NDArray the host API returns
+        v = env.DeviceView()
+        assert v.num_envs == n and v.obs_dim == D and v.state_dim == env.StateDim
+        assert bool(v.obs_aliases_state) == (name == "CartPole-v1") and (v.d_obs == v.d_state) == (name == "CartPole-v1")
+        assert v.d_reward and v.d_done and v.stream and v.state_stride >= n and v.state_stride % 64 == 0
+        out = env.Step(env.SampleActions(seed=1, tick=0))
+        again = env.Read()                                               # gymnet_vecenv_read: the same Step results again
+        assert np.array_equal(again.Observation, out.Observation) and np.array_equal(again.Reward, out.Reward)
+
+
+def test_per_lane_seeds_with_fused_autoreset(gpu_pkg, oracle):
+    # VecEnv.Seed(int[]) (VecEnv.cs:48-53): lane i resets from Philox(key = seeds[i], counter = (global lane, tick))
+    n, off = 2048, 100
+    seeds = (np.arange(n) * 7919 + 13).astype(np.int64)
+    rng = np.random.default_rng(3)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=1, auto_reset=True, lane_offset=off) as env:
+        env.Seed(seeds.tolist())
+        first = env.Reset()
+        want = np.stack([oracle.cartpole_reset(int(seeds[i]), off + i, 0, 1)[:, 0] for i in range(0, n, 37)])
+        assert np.array_equal(first[::37], want)
+        for t in range(30):
+            tick = env.Tick
+            out = env.Step(rng.integers(0, 2, n).astype(np.int32))
+            for i in np.nonzero(out.Done)[0][:5]:
+                assert np.array_equal(out.Observation[i], oracle.cartpole_reset(int(seeds[i]), off + int(i), tick, 1)[:, 0])
+
+
+def test_external_obs_buffer_for_derived_observations(gpu_pkg):
+    # Pendulum's observation (cos, sin, thdot) is derived: with d_ext_obs the OBSERVATION arrays live in the caller's
+    # buffer (the all-gather layout) while the state stays internal
+    import torch
+    n = 5000
+    buf = torch.zeros((3, n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED, auto_reset=True, ext_obs=buf.data_ptr(), ext_obs_stride=n) as env, \
+            gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED, auto_reset=True) as ref:
+        env.Reset(); ref.Reset()
+        a = np.linspace(-2, 2, n).astype(np.float32)
+        for t in range(5):
+            o1 = env.Step(a); o2 = ref.Step(a)
+            assert np.array_equal(o1.Observation, o2.Observation)
+        env.Sync()
+        assert np.array_equal(buf.cpu().numpy().T, o1.Observation)
