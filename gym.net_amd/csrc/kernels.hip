@@ -129,6 +129,56 @@ __device__ __forceinline__ void count_after_done(const StepArgs &a, const bool (
         atomicAdd(&a.after_done[wave_shard() * kAfterStride], (unsigned long long)total);
 }
 
+// One env-step of ONE sub-lane: the dynamics, then — without auto-reset, for envs that carry it — the reference's
+// steps_beyond_done rule (CartPoleEnv.cs:168-183): reward 1 until and including the step the pole falls, 0 afterwards.
+// `after` reports a step taken on a lane that had already returned done (the reference's console warning, :176-179).
+template <class Env, bool AUTORESET>
+__device__ __forceinline__ void advance_sublane(float (&sj)[Env::S], typename Env::Action act, int32_t &sbd, float &rw,
+                                                bool &dn, bool &after, bool in_range) {
+    Env::step(sj, act, rw, dn);
+    if constexpr (!AUTORESET && Env::HAS_SBD) {
+        if (dn) {
+            if (sbd == -1) { sbd = 0; }
+            else { after = in_range; sbd += 1; rw = 0.0f; }
+        }
+    }
+}
+
+// Fused auto-reset of the sub-lanes flagged in `pending`.  ~4.5 % of CartPole lanes finish per step, so ~95 % of
+// 64-lane waves hold a finished lane in EVERY sub-lane position: a per-sub-lane `if (done) philox()` would make every
+// wave pay VEC Philox passes.  Instead each thread drains its finished sub-lanes one per loop trip; the trips a wave
+// pays are max over its lanes of #finished sub-lanes (1.6 on average instead of 3.8), and waves with no finished lane
+// skip the loop through the exec mask.
+template <class Env, int VEC, bool LANE_SEEDS>
+__device__ __forceinline__ void reset_pending(uint32_t pending, float (&s)[Env::S][VEC], float (&o)[Env::O][VEC], const StepArgs &a,
+                                              int64_t i0, int64_t n, uint64_t tick) {
+    constexpr int S = Env::S, O = Env::O;
+    while (pending) {
+        const int j = __ffs(pending) - 1;
+        pending &= pending - 1;
+        uint64_t key = a.seed;
+        if constexpr (LANE_SEEDS) {
+            if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
+        }
+        const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
+        float sj[S];
+        Env::reset(sj, r);
+        float oj[O];
+        if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) {
+            if (jj == j) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) s[k][jj] = sj[k];
+                if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                    for (int k = 0; k < O; ++k) o[k][jj] = oj[k];
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The vector step: ONE launch advances every lane by one env-step.
 //   Env       dynamics (envs.hpp)
@@ -152,7 +202,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A, GUARD>(static_cast<const float *>(a.action), i0, n, act);
     else load_i32<VEC, NT_A, GUARD>(static_cast<const int32_t *>(a.action), i0, n, act);
 
-    int32_t sbd[VEC];
+    int32_t sbd[VEC] = {};
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, sbd);
 
     float ep_ret[VEC];
@@ -179,19 +229,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
         for (int k = 0; k < S; ++k) sj[k] = s[k][j];
         bool dn;
         float rw;
-        Env::step(sj, act[j], rw, dn);
-
-        if constexpr (!AUTORESET && Env::HAS_SBD) {
-            // CartPoleEnv.cs:168-183 — reward 1 until and including the step the pole falls, 0 afterwards
-            if (dn) {
-                if (sbd[j] == -1) { sbd[j] = 0; }
-                else {
-                    after[j] = !GUARD || i0 + j < n;   // the reference's console warning (:176-179), counted below
-                    sbd[j] += 1;
-                    rw = 0.0f;
-                }
-            }
-        }
+        advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n);
 
         uint8_t db = dn ? 1 : 0;
         if constexpr (EXTRAS) {
@@ -238,37 +276,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     store_f32<VEC, NT_O, GUARD>(a.reward, i0, n, reward);
     store_u8<VEC, NT_O, GUARD>(a.done, i0, n, done);
 
-    if constexpr (AUTORESET) {
-        // Fused auto-reset.  ~4.5 % of CartPole lanes finish per step, so ~95 % of 64-lane waves hold a finished
-        // lane in EVERY sub-lane position: a per-sub-lane `if (done) philox()` would make every wave pay VEC
-        // Philox passes.  Instead each thread drains its finished sub-lanes one per loop trip; the trips a wave
-        // pays are max over its lanes of #finished sub-lanes (1.6 on average instead of 3.8), and waves with no
-        // finished lane skip the loop through the exec mask.
-        while (pending) {
-            const int j = __ffs(pending) - 1;
-            pending &= pending - 1;
-            uint64_t key = a.seed;
-            if constexpr (EXTRAS) {
-                if (a.lane_seed && (!GUARD || i0 + j < n)) key = a.lane_seed[i0 + j];
-            }
-            const PhiloxWords r = lane_words(key, a.lane_offset + (uint64_t)(i0 + j), tick);
-            float sj[S];
-            Env::reset(sj, r);
-            float oj[O];
-            if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
-#pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) {
-                if (jj == j) {
-#pragma unroll
-                    for (int k = 0; k < S; ++k) s[k][jj] = sj[k];
-                    if constexpr (!Env::OBS_ALIASES_STATE) {
-#pragma unroll
-                        for (int k = 0; k < O; ++k) o[k][jj] = oj[k];
-                    }
-                }
-            }
-        }
-    }
+    if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick);
 
 #pragma unroll
     for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
     float s[S][VEC];
 #pragma unroll
     for (int k = 0; k < S; ++k) load_f32<VEC, true, true>(a.state + k * a.state_stride, i0, n, s[k]);
-    int32_t sbd[VEC];
+    int32_t sbd[VEC] = {};
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, true, true>(a.sbd, i0, n, sbd);
 
     auto load_action = [&](int64_t slice, Act (&dst)[VEC]) {
@@ -381,13 +389,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
             for (int k = 0; k < S; ++k) sj[k] = s[k][j];
             bool dn;
             float rw;
-            Env::step(sj, act[j], rw, dn);
-            if constexpr (!AUTORESET && Env::HAS_SBD) {
-                if (dn) {
-                    if (sbd[j] == -1) { sbd[j] = 0; }
-                    else { after[j] = i0 + j < n; sbd[j] += 1; rw = 0.0f; }
-                }
-            }
+            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], i0 + j < n);
             done[j] = dn ? 1 : 0;
             reward[j] = rw;
             if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
@@ -403,28 +405,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
         if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
         if (ro.rec_reward) store_f32<VEC, true, true>(ro.rec_reward + t * n, i0, n, reward);
         if (ro.rec_done) store_u8<VEC, true, true>(ro.rec_done + t * n, i0, n, done);
-        if constexpr (AUTORESET) {
-            while (pending) {
-                const int j = __ffs(pending) - 1;
-                pending &= pending - 1;
-                const PhiloxWords r = lane_words(a.seed, a.lane_offset + (uint64_t)(i0 + j), tick0 + (uint64_t)t);
-                float sj[S];
-                Env::reset(sj, r);
-                float oj[O];
-                if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
-#pragma unroll
-                for (int jj = 0; jj < VEC; ++jj) {
-                    if (jj == j) {
-#pragma unroll
-                        for (int k = 0; k < S; ++k) s[k][jj] = sj[k];
-                        if constexpr (!Env::OBS_ALIASES_STATE) {
-#pragma unroll
-                            for (int k = 0; k < O; ++k) o[k][jj] = oj[k];
-                        }
-                    }
-                }
-            }
-        }
+        if constexpr (AUTORESET) reset_pending<Env, VEC, false>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
         if (ro.rec_obs) {
 #pragma unroll
             for (int k = 0; k < O; ++k) {
