@@ -514,3 +514,39 @@ def test_maximum_size_batch_properties(gpu_pkg, oracle):
         assert np.isfinite(st).all() and np.abs(st[0]).max() <= 2.5 and np.abs(st[2]).max() <= 0.3
         c = env.Counters()
         assert c["lane_steps"] == 12 * n and c["tick"] == 13 and dones > 0
+
+
+def test_free_running_autoreset_rollout_is_bit_identical_to_the_cpu_restatement(gpu_pkg, oracle):
+    """300 free-running steps with fused auto-reset on 2^16 lanes — device-sampled actions, Philox resets keyed by
+    (global lane, tick), one-launch steps and the fused T-step kernel mixed — replayed on the CPU with the oracle's
+    float32 kernel-semantics step + its Philox reset: every state bit, every done flag must agree."""
+    import torch
+    n, ring, off = 1 << 16, 16, 7_000_000
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=off) as env:
+        acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(ring):
+            env.SampleActionsDevice(acts[t], seed=77, tick=t)
+        env.Sync()
+        a_host = acts.cpu().numpy()
+        for t in range(ring):                                             # the device sampler == the oracle's sampler
+            assert np.array_equal(a_host[t], oracle.discrete_sample(77, off, t, 2, 0, n))
+        env.ResetDevice()
+        env.RolloutDevice(acts, 100, n, ring)                             # ticks 1..100
+        env.RolloutFusedDevice(acts, 150, n, ring)                        # ticks 101..250 (slices restart at 0)
+        env.RolloutDevice(acts, 50, n, ring)                              # ticks 251..300
+        env.Sync()
+        got, last = env.GetState(), env.Read()
+
+    s = oracle.cartpole_reset(SEED, off, 0, n)
+    tick, total_done = 1, 0
+    for seg in (100, 150, 50):
+        for t in range(seg):
+            s, r, d, _ = oracle.cartpole_step(s, a_host[t % ring], dtype=np.float32)
+            fin = d.astype(bool)
+            fresh = oracle.cartpole_reset(SEED, off, tick, n)
+            s[:, fin] = fresh[:, fin]
+            tick += 1; total_done += int(fin.sum())
+    assert np.array_equal(got, s)
+    assert np.array_equal(last.Done, fin) and np.array_equal(last.Reward, r)
+    assert total_done > 10 * n                                            # ~13 episodes per lane on average
