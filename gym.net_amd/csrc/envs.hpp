@@ -118,6 +118,11 @@ struct CartPole {
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = s[k];
     }
+    // dynamics + observation of the new state in one call (Acrobot shares its trigonometry between the two)
+    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
+        step(s, a, reward, done);
+        observe(s, o);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -162,6 +167,10 @@ struct Pendulum {
         sincos_f32(s[0], sn, cs);
         o[0] = cs; o[1] = sn; o[2] = s[1];
     }
+    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
+        step(s, a, reward, done);
+        observe(s, o);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -193,6 +202,10 @@ struct MountainCar {
     }
 
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) { o[0] = s[0]; o[1] = s[1]; }
+    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
+        step(s, a, reward, done);
+        observe(s, o);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -237,7 +250,8 @@ struct Acrobot {
         return x;
     }
 
-    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+    // One RK4 step; the sin/cos of the new angles serve both the termination test and the observation.
+    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
         const float dt = 0.2f, mv1 = 4.0f * PI, mv2 = 9.0f * PI;
         const float torque = (float)(a - 1);
         float k1[4], k2[4], k3[4], k4[4], y[4];
@@ -259,13 +273,18 @@ struct Acrobot {
         y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = y[i];
-        // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2 (the kernel's observe() recomputes
-        // the same sincos pair; the compiler merges them after inlining)
+        // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2
         float s1, c1, s2, c2;
         sincos_f32(y[0], s1, c1);
         sincos_f32(y[1], s2, c2);
         done = (-c1 - (c1 * c2 - s1 * s2)) > 1.0f;
         reward = done ? 0.0f : -1.0f;
+        o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = y[2]; o[5] = y[3];
+    }
+
+    __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
+        float o[O];
+        step_observe(s, a, reward, done, o);
     }
 
     __device__ __forceinline__ static void reset(float (&s)[S], const PhiloxWords &r) {

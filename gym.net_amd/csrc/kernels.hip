@@ -134,8 +134,9 @@ __device__ __forceinline__ void count_after_done(const StepArgs &a, const bool (
 // `after` reports a step taken on a lane that had already returned done (the reference's console warning, :176-179).
 template <class Env, bool AUTORESET>
 __device__ __forceinline__ void advance_sublane(float (&sj)[Env::S], typename Env::Action act, int32_t &sbd, float &rw,
-                                                bool &dn, bool &after, bool in_range) {
-    Env::step(sj, act, rw, dn);
+                                                bool &dn, bool &after, bool in_range, float (&oj)[Env::O]) {
+    if constexpr (Env::OBS_ALIASES_STATE) Env::step(sj, act, rw, dn);
+    else Env::step_observe(sj, act, rw, dn, oj);          // observation of the new (pre-reset) state
     if constexpr (!AUTORESET && Env::HAS_SBD) {
         if (dn) {
             if (sbd == -1) { sbd = 0; }
@@ -229,7 +230,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
         for (int k = 0; k < S; ++k) sj[k] = s[k][j];
         bool dn;
         float rw;
-        advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n);
+        float oj[O];
+        advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n, oj);
 
         uint8_t db = dn ? 1 : 0;
         if constexpr (EXTRAS) {
@@ -246,10 +248,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
 
         if constexpr (EXTRAS) {
             if (fin && a.final_obs && (!GUARD || i0 + j < n)) {
-                float fo[O];
-                Env::observe(sj, fo);
 #pragma unroll
-                for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = fo[k];
+                for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? sj[k < S ? k : 0] : oj[k];
             }
             if (stats && fin && (!GUARD || i0 + j < n)) {
                 a.fin_ret[i0 + j] = ep_ret[j];
@@ -263,8 +263,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k][j] = sj[k];
         if constexpr (!Env::OBS_ALIASES_STATE) {
-            float oj[O];
-            Env::observe(sj, oj);
 #pragma unroll
             for (int k = 0; k < O; ++k) o[k][j] = oj[k];
         }
@@ -389,15 +387,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
             for (int k = 0; k < S; ++k) sj[k] = s[k][j];
             bool dn;
             float rw;
-            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], i0 + j < n);
+            float oj[O];
+            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], i0 + j < n, oj);
             done[j] = dn ? 1 : 0;
             reward[j] = rw;
             if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
 #pragma unroll
             for (int k = 0; k < S; ++k) s[k][j] = sj[k];
             if constexpr (!Env::OBS_ALIASES_STATE) {
-                float oj[O];
-                Env::observe(sj, oj);
 #pragma unroll
                 for (int k = 0; k < O; ++k) o[k][j] = oj[k];
             }
