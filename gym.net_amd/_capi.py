@@ -13,7 +13,8 @@ from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDe
                      NotSteppingError)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgymnet_amd.so")
+# GYMNET_LIB_PATH points the binding at another build of the same library (A/B timing of two builds, packaged installs)
+LIB_PATH = os.environ.get("GYMNET_LIB_PATH") or os.path.join(HERE, "lib", "libgymnet_amd.so")
 
 OK = 0
 ERR_INVALID_ARG = -1

@@ -343,26 +343,22 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
 // CartPole, and the load-phase / store-phase serialisation of the one-step kernel disappears.  The next step's
 // action is loaded before the current step's math.  Results are bit-identical to T one-step launches.
 // ---------------------------------------------------------------------------------------------
-template <class Env, int VEC, bool AUTORESET>
-__global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const RolloutArgs ro) {
+template <class Env, int VEC, bool AUTORESET, bool GUARD>
+__device__ __forceinline__ void rollout_body(const StepArgs &a, const RolloutArgs &ro, const int64_t i0, const uint64_t tick0) {
     constexpr int S = Env::S, O = Env::O;
     using Act = typename Env::Action;
-    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     const int64_t n = a.n;
-    const uint64_t tick0 = a.tick2[a.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
-    if (i0 >= n) return;
 
     float s[S][VEC];
 #pragma unroll
-    for (int k = 0; k < S; ++k) load_f32<VEC, true, true>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) load_f32<VEC, true, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
     int32_t sbd[VEC] = {};
-    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, true, true>(a.sbd, i0, n, sbd);
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, true, GUARD>(a.sbd, i0, n, sbd);
 
     auto load_action = [&](int64_t slice, Act (&dst)[VEC]) {
         const char *base = static_cast<const char *>(a.action) + (size_t)(slice * ro.action_stride) * 4;
-        if constexpr (Env::BOX_ACTION) load_f32<VEC, true, true>(reinterpret_cast<const float *>(base), i0, n, dst);
-        else load_i32<VEC, true, true>(reinterpret_cast<const int32_t *>(base), i0, n, dst);
+        if constexpr (Env::BOX_ACTION) load_f32<VEC, true, GUARD>(reinterpret_cast<const float *>(base), i0, n, dst);
+        else load_i32<VEC, true, GUARD>(reinterpret_cast<const int32_t *>(base), i0, n, dst);
     };
 
     Act act[VEC], act_next[VEC];
@@ -388,7 +384,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
             bool dn;
             float rw;
             float oj[O];
-            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], i0 + j < n, oj);
+            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n, oj);
             done[j] = dn ? 1 : 0;
             reward[j] = rw;
             if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
@@ -400,14 +396,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
             }
         }
         if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
-        if (ro.rec_reward) store_f32<VEC, true, true>(ro.rec_reward + t * n, i0, n, reward);
-        if (ro.rec_done) store_u8<VEC, true, true>(ro.rec_done + t * n, i0, n, done);
+        if (ro.rec_reward) store_f32<VEC, true, GUARD>(ro.rec_reward + t * n, i0, n, reward);
+        if (ro.rec_done) store_u8<VEC, true, GUARD>(ro.rec_done + t * n, i0, n, done);
         if constexpr (AUTORESET) reset_pending<Env, VEC, false>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
         if (ro.rec_obs) {
 #pragma unroll
             for (int k = 0; k < O; ++k) {
-                if constexpr (Env::OBS_ALIASES_STATE) store_f32<VEC, true, true>(ro.rec_obs + (t * O + k) * n, i0, n, s[k]);
-                else store_f32<VEC, true, true>(ro.rec_obs + (t * O + k) * n, i0, n, o[k]);
+                if constexpr (Env::OBS_ALIASES_STATE) store_f32<VEC, true, GUARD>(ro.rec_obs + (t * O + k) * n, i0, n, s[k]);
+                else store_f32<VEC, true, GUARD>(ro.rec_obs + (t * O + k) * n, i0, n, o[k]);
             }
         }
 #pragma unroll
@@ -416,14 +412,27 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const Ro
     }
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, false, true>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) store_f32<VEC, false, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
-        for (int k = 0; k < O; ++k) store_f32<VEC, false, true>(a.obs + k * a.obs_stride, i0, n, o[k]);
+        for (int k = 0; k < O; ++k) store_f32<VEC, false, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
     }
-    store_f32<VEC, false, true>(a.reward, i0, n, reward);
-    store_u8<VEC, false, true>(a.done, i0, n, done);
-    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, false, true>(a.sbd, i0, n, sbd);
+    store_f32<VEC, false, GUARD>(a.reward, i0, n, reward);
+    store_u8<VEC, false, GUARD>(a.done, i0, n, done);
+    if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, false, GUARD>(a.sbd, i0, n, sbd);
+}
+
+template <class Env, int VEC, bool AUTORESET>
+__global__ __launch_bounds__(256) void rollout_kernel(const StepArgs a, const RolloutArgs ro) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const uint64_t tick0 = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
+    if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {     // full workgroup: no bounds checks inside the T-step loop
+        rollout_body<Env, VEC, AUTORESET, false>(a, ro, i0, tick0);
+    } else {
+        if (i0 >= a.n) return;
+        rollout_body<Env, VEC, AUTORESET, true>(a, ro, i0, tick0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
