@@ -95,3 +95,21 @@ def test_external_obs_buffer_for_derived_observations(gpu_pkg):
             assert np.array_equal(o1.Observation, o2.Observation)
         env.Sync()
         assert np.array_equal(buf.cpu().numpy().T, o1.Observation)
+
+
+def test_create_destroy_does_not_leak_device_memory(gpu_pkg):
+    import torch
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        with gpu_pkg.VectorEnv("CartPole-v1", 1 << 18, seed=1, auto_reset=True, done_list=True, episode_stats=True, final_obs=True) as env:
+            env.Reset()
+            env.Step(1)
+            env.Seed(list(range(1 << 18)))
+            env.Step(0)
+            env.DoneLanes()
+        with gpu_pkg.VectorEnv("Acrobot-v1", 1000, seed=1) as env:                   # small batch: host-mapped staging too
+            env.Reset(); env.Step(2)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)      # allocator slack only; 40 leaked handles would be > 1 GiB
