@@ -122,3 +122,50 @@ def test_create_destroy_does_not_leak_device_memory(gpu_pkg):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (32 << 20), (free0, free1)      # 30 leaked handles would be ~ 1 GiB
+
+
+def test_handles_are_independent_across_threads(gpu_pkg):
+    """Different handles from different threads at the same time (the reference runs two env instances concurrently in
+    tests/Gym.Tests/Envs/Aether/LunarLanderEnvironment.cs:185-190); one handle from two threads is refused, not raced."""
+    import threading
+    n, steps = 1 << 15, 60
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 2, (steps, n)).astype(np.int32)
+
+    def rollout(seed, out, k):
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=seed, auto_reset=True) as env:
+            env.Reset()
+            for t in range(steps):
+                env.Step(acts[t])
+            out[k] = env.GetState()
+
+    solo = {}
+    for k in range(4):
+        rollout(100 + k, solo, k)
+    conc = {}
+    threads = [threading.Thread(target=rollout, args=(100 + k, conc, k)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for k in range(4):
+        assert np.array_equal(solo[k], conc[k])
+
+    # one handle, two threads: the second caller gets AlreadySteppingError (the guard the reference only declared)
+    with gpu_pkg.VectorEnv("CartPole-v1", 1 << 22, seed=1, auto_reset=True) as env:
+        env.Reset()
+        errors, big = [], np.ones(1 << 22, np.int32)
+
+        def hammer():
+            for _ in range(15):
+                try:
+                    env.Step(big)
+                except gpu_pkg.AlreadySteppingError:
+                    errors.append(1)
+
+        ts = [threading.Thread(target=hammer) for _ in range(3)]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        assert env.Counters()["lane_steps"] == (45 - len(errors)) * (1 << 22)    # every accepted call ran exactly once
