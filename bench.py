@@ -205,6 +205,27 @@ def main():
         except Exception as e:                      # never lose the headline over the optional collective
             gathered = {"error": repr(e)[:200]}
 
+    # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
+    # beside the 8 TB/s spec peak the roofline fraction uses: cache-resident (32 MiB) and HBM-resident (2 GiB).
+    copy_bw = None
+    if rank == 0 and world == 1:
+        copy_bw = {}
+        for label, mib in (("32MiB", 32), ("2GiB", 2048)):
+            src = torch.empty(mib * (1 << 18), dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50 if mib <= 64 else 10
+            c0.record(stream)
+            for _ in range(reps):
+                dst.copy_(src)
+            c1.record(stream)
+            torch.cuda.synchronize(dev)
+            copy_bw[label] = 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9
+            del src, dst
+
     if rank == 0:
         bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
         launch_us = ev_ms * 1e3 / K                                          # HIP events over the timed region / launches
@@ -231,7 +252,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
-                         "isolated_launch_us_median": single_us},
+                         "isolated_launch_us_median": single_us, "measured_copy_GBps": copy_bw},
         }
         if fused:
             out["fused_rollout"] = fused
