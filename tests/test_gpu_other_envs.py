@@ -192,3 +192,16 @@ def test_full_size_long_rollout_checksum(gpu_pkg, name):
         env.Sync()
         assert env.Tick == 2001
         assert hashlib.sha256(env.GetState().tobytes()).hexdigest()[:24] == LONG_ROLLOUT_SHA256[name]
+
+
+def test_scalar_broadcast_on_a_box_action_space(gpu_pkg):
+    # IVecEnv.Step(int) (IVecEnv.cs:15) on Pendulum: the int is the (scalar) torque for every lane
+    n = 2000
+    with gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED) as a, gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED) as b:
+        a.Reset(); b.Reset()
+        for u in (1, -2, 0, 5):                               # 5 is clipped to max_torque = 2 like np.clip(u, -2, 2)
+            oa = a.Step(u)
+            ob = b.Step(np.full(n, float(u), dtype=np.float32))
+            assert np.array_equal(oa.Observation, ob.Observation) and np.array_equal(oa.Reward, ob.Reward)
+        oc = a.StepAsync(1).Result(); od = b.Step(np.ones(n, np.float32))
+        assert np.array_equal(oc.Observation, od.Observation)
