@@ -169,3 +169,25 @@ def test_handles_are_independent_across_threads(gpu_pkg):
         for th in ts:
             th.join()
         assert env.Counters()["lane_steps"] == (45 - len(errors)) * (1 << 22)    # every accepted call ran exactly once
+
+
+def test_instance_properties_match_the_reference_constructor(gpu_pkg):
+    # what `new CartPoleEnv()` sets up (CartPoleEnv.cs:43-52) and what VecEnv carries (VecEnv.cs:13-27)
+    with gpu_pkg.VectorEnv("CartPole-v1", 8) as env:
+        assert env.NumberOfEnvironments == 8 and env.Environments == []
+        assert isinstance(env.ActionSpace, gpu_pkg.Discrete) and env.ActionSpace.N == 2
+        assert isinstance(env.ObservationSpace, gpu_pkg.Box) and env.ObservationSpace.Shape == (4,)
+        assert env.ObservationSpace.DType == np.float32
+        high = env.ObservationSpace.High
+        assert high[0] == np.float32(2.4) * 2 and high[1] == np.finfo(np.float32).max and np.array_equal(env.ObservationSpace.Low, -high)
+        assert env.Metadata == {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 50}
+        obs = env.Reset()
+        assert all(env.ObservationSpace.Contains(o) for o in obs)                    # every reset observation is inside the Box
+        assert env.get_attr("state").shape == (8, 4) and np.array_equal(env.get_attr("steps_beyond_done"), np.full(8, -1))
+        env.set_attr("state", np.zeros((8, 4), np.float32))
+        assert not env.GetState().any()
+        with pytest.raises(ValueError):
+            env.set_attr("state", None)                                             # ArgumentNullException, VecEnv.cs:88
+    cp = gpu_pkg.CartPoleEnv()
+    assert cp.ActionSpace.Contains(cp.ActionSpace.Sample()) and cp.Render() is None
+    cp.Dispose()

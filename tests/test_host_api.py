@@ -189,3 +189,14 @@ def test_csharp_binding_sources_lex_cleanly_and_cover_the_header():
     # device-side sampling helpers are not needed by the managed wrapper; everything else must be importable
     assert missing <= {"gymnet_sample_discrete_device", "gymnet_sample_box_device", "gymnet_vecenv_sample_actions_device",
                        "gymnet_vecenv_device_view"}, missing
+
+
+def test_mirror_exposes_the_reference_member_names(gymnet):
+    # IVecEnv / VecEnv (src/Gym/Envs/IVecEnv.cs:8-19, VecEnv.cs:12-93) and IEnv / Env (IEnv.cs:11-22, Env.cs:13-41)
+    for m in ("Reset", "Step", "Close", "Seed", "StepAsync", "get_attr", "set_attr"):
+        assert callable(getattr(gymnet.VectorEnv, m)), m
+    for m in ("Reset", "Step", "StepAsync", "Render", "CloseEnvironment", "Seed", "Dispose"):
+        assert callable(getattr(gymnet.CartPoleEnv, m)), m
+    for m in ("Sample", "Contains", "Seed"):                       # Space.cs:15-17
+        assert callable(getattr(gymnet.Box, m)) and callable(getattr(gymnet.Discrete, m)), m
+    assert set(gymnet.Step.__slots__) == {"Observation", "Reward", "Done", "Information"}      # Step.cs:8-11
