@@ -316,3 +316,22 @@ def test_restatement_against_exact_rational_arithmetic(oracle):
         for e, v in zip(exact, got):
             # 4.0/3.0 as a double literal and ~15 roundings: allow 64 ulp of slack around the exact value
             assert abs(float(e) - v) <= 64 * np.spacing(abs(v)) + 1e-300
+
+
+def test_reset_stream_is_uniform_across_lanes_and_across_ticks(oracle):
+    """Philox(key = seed, counter = (lane, tick)): the reset draws must look iid uniform whether one walks along the lanes
+    at a fixed tick or along the ticks at a fixed lane (the two directions a rollout consumes them in)."""
+    from scipy import stats
+    seed, bins = 0xC0FFEE, 32
+    lanes = oracle.cartpole_reset(seed, 12345, 9, 200_000)                      # [4, n] at one tick
+    ticks = np.concatenate([oracle.cartpole_reset(seed, 777, t, 1) for t in range(20_000)], axis=1)   # one lane, many ticks
+    for sample in (lanes, ticks):
+        for comp in sample:
+            u = (comp.astype(np.float64) + 0.05) / 0.1
+            counts = np.histogram(u, bins=bins, range=(0.0, 1.0))[0]
+            p = stats.chisquare(counts).pvalue
+            assert p > 1e-4, p
+        # neighbours (adjacent lanes / consecutive ticks) are uncorrelated, and so are the four components of one draw
+        x = sample[0].astype(np.float64)
+        assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 4.0 / np.sqrt(x.size)
+        assert np.abs(np.corrcoef(sample.astype(np.float64))[np.triu_indices(4, 1)]).max() < 4.0 / np.sqrt(x.size)
