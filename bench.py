@@ -79,13 +79,21 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an AMD GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; GYMNET_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist (a 1-GPU box can then
+    # exercise the N > 1 plumbing: lane offsets, shard buffers, barrier, max-over-ranks) — RCCL needs one GPU per rank
+    backend = os.environ.get("GYMNET_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")      # where the timing reduction tensors live
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.num_envs
     ring = max(2, args.ring + (args.ring % 2))
@@ -97,7 +105,7 @@ def main():
     torch.cuda.set_stream(stream)
 
     # this rank's shard of the global batch; observations live inside the (optional) gather buffer
-    env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=local_rank, seed=seed,
+    env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
                                auto_reset=True, gather_obs=use_dist, tensor_device=dev,
                                force_gather=args.force_dist)
     local = env.local
@@ -138,7 +146,7 @@ def main():
     wall = t1 - t0
     ev_ms = e0.elapsed_time(e1)
     if use_dist:
-        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tw[0]), float(tw[1])
 
@@ -183,7 +191,7 @@ def main():
     # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
     # collective; this shows what a consumer that wants every rank to see all observations pays over xGMI.
     gathered = None
-    if use_dist and not args.allgather:
+    if use_dist and not args.allgather and backend == "nccl":
         try:
             gs = 128
             for t in range(16):
@@ -197,7 +205,7 @@ def main():
             g1.record(stream)
             torch.cuda.synchronize(dev); barrier()
             gwall = time.perf_counter() - tg0
-            tg = torch.tensor([gwall], dtype=torch.float64, device=dev)
+            tg = torch.tensor([gwall], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
             ok = bool(torch.isfinite(env.GlobalObs()).all()) and all(float(env.GlobalObs()[r].abs().sum()) > 0 for r in range(world))
             gathered = {"value": n * world * gs / float(tg[0]), "unit": "env-steps/s", "ms_per_step": float(tg[0]) * 1e3 / gs,
