@@ -14,10 +14,10 @@ from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDe
 from .sharding import ShardPlan, ShardedVectorEnv
 from .spaces import Box, Discrete, Space
 from .step import Step
-from .vector_env import (AcrobotEnv, BatchStep, CartPoleEnv, GpuEnv, MountainCarEnv, PendingStep,
+from .vector_env import (AcrobotEnv, BatchStep, CartPoleEnv, DummyVecEnv, GpuEnv, MountainCarEnv, PendingStep,
                          PendulumEnv, VectorEnv)
 
-__all__ = ["VectorEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
+__all__ = ["VectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
            "AcrobotEnv", "Space", "Box", "Discrete", "Step", "InvalidActionError", "AlreadySteppingError",
            "NotSteppingError", "GymNetError", "NoDeviceError", "ShardPlan", "ShardedVectorEnv", "device_count",
            "env_describe", "load_library", "LIB_PATH", "ENV_IDS"]

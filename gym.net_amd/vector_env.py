@@ -317,6 +317,13 @@ class VectorEnv:
     reset, step, seed, close = Reset, Step, Seed, Close
 
 
+class DummyVecEnv(VectorEnv):
+    """DummyVecEnv (src/Gym/Envs/DummyVecEnv.cs:2-4): a VecEnv around ONE environment — here a 1-lane batch."""
+
+    def __init__(self, env="CartPole-v1", **kw):
+        super().__init__(env, 1, **kw)
+
+
 class GpuEnv:
     """Single-instance `Env` façade (Env.cs:13-41) over a 1-lane VectorEnv: Reset() -> NDArray[D],
     Step(object action) -> Step.  Exists so an existing per-instance loop (README.md:32-52,
@@ -384,5 +391,5 @@ class AcrobotEnv(GpuEnv):
     ENV = "Acrobot-v1"
 
 
-__all__ = ["VectorEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
+__all__ = ["VectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
            "AcrobotEnv", "AlreadySteppingError", "NotSteppingError"]

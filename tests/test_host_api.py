@@ -195,6 +195,7 @@ def test_mirror_exposes_the_reference_member_names(gymnet):
     # IVecEnv / VecEnv (src/Gym/Envs/IVecEnv.cs:8-19, VecEnv.cs:12-93) and IEnv / Env (IEnv.cs:11-22, Env.cs:13-41)
     for m in ("Reset", "Step", "Close", "Seed", "StepAsync", "get_attr", "set_attr"):
         assert callable(getattr(gymnet.VectorEnv, m)), m
+    assert issubclass(gymnet.DummyVecEnv, gymnet.VectorEnv)           # DummyVecEnv.cs:2-4
     for m in ("Reset", "Step", "StepAsync", "Render", "CloseEnvironment", "Seed", "Dispose"):
         assert callable(getattr(gymnet.CartPoleEnv, m)), m
     for m in ("Sample", "Contains", "Seed"):                       # Space.cs:15-17
