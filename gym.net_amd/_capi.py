@@ -120,6 +120,7 @@ PROTOTYPES = {
                                            C.c_uint64, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions_device": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
+    "gymnet_vecenv_compose_actions_device": (C.c_int, [_H, _P, C.c_float, _P, C.c_uint64, C.c_uint64]),
 }
 
 _lib = None

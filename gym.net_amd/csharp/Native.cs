@@ -81,6 +81,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_episode_stats(IntPtr h, float* finished_return, int* finished_length);
         [DllImport(Lib)] public static extern int gymnet_vecenv_final_obs(IntPtr h, float* final_obs_out);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions(IntPtr h, void* actions_out, ulong seed, ulong tick);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_compose_actions_device(IntPtr h, IntPtr d_policy_actions, float epsilon, IntPtr d_actions_out, ulong seed, ulong tick);
 
         /// Maps a status to the exception the reference throws for the same condition.
         public static void Check(int status) {

@@ -949,6 +949,19 @@ int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint6
     });
 }
 
+int gymnet_vecenv_compose_actions_device(gymnet_vecenv *h, const int32_t *d_policy_actions, float epsilon, int32_t *d_actions_out,
+                                         uint64_t seed, uint64_t tick) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!d_policy_actions || !d_actions_out) return fail(h, GYMNET_ERR_INVALID_ARG, "null action buffer");
+    if (h->desc->box_action) return fail(h, GYMNET_ERR_UNSUPPORTED, "epsilon-greedy composition is defined for Discrete action spaces");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail(h, GYMNET_ERR_INVALID_ARG, "epsilon must be in [0, 1]");
+    HIP_TRY(h, launch_compose_discrete(d_policy_actions, d_actions_out, h->n, h->desc->action_n, epsilon, seed,
+                                       (uint64_t)h->cfg.lane_offset, tick, h->stream));
+    return GYMNET_OK;
+    });
+}
+
 int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick) {
     return guarded([&]() -> int {
     if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");

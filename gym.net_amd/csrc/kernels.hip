@@ -571,6 +571,20 @@ __global__ __launch_bounds__(256) void sample_discrete_kernel(int32_t *__restric
     out[i] = start + (int32_t)__umulhi(r.w[0], (uint32_t)nvals);
 }
 
+// The caller's epsilon-greedy composer (examples/.../PlaySessions/TrainingPlaySession.cs:46-52), batched:
+//   if (Random.NextDouble() <= epsilon) action = ActionSpace.Sample(); else action = policy action
+// Lane i uses Philox(seed, (lane_offset + i, tick)): word 0 is the sampled action (identical to sample_discrete_kernel),
+// word 1 the 24-bit uniform that is compared with epsilon.
+__global__ __launch_bounds__(256) void compose_discrete_kernel(const int32_t *__restrict__ policy, int32_t *__restrict__ out,
+                                                               int64_t n, int32_t nvals, float epsilon, uint64_t seed,
+                                                               uint64_t lane_offset, uint64_t tick) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    const bool explore = u01_24(r.w[1]) <= epsilon;
+    out[i] = explore ? (int32_t)__umulhi(r.w[0], (uint32_t)nvals) : policy[i];
+}
+
 // Box.Sample() (Box.cs:69-90): the reference's four regimes, selected by which bounds are finite
 __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out, int64_t n, float low, float high,
                                                          uint64_t seed, uint64_t lane_offset, uint64_t tick) {
@@ -734,6 +748,14 @@ hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_
                                   uint64_t lane_offset, uint64_t tick, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(sample_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, seed,
+                       lane_offset, tick);
+    return hipGetLastError();
+}
+
+hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t n, int32_t nvals, float epsilon, uint64_t seed,
+                                   uint64_t lane_offset, uint64_t tick, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(compose_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, policy, out, n, nvals, epsilon, seed,
                        lane_offset, tick);
     return hipGetLastError();
 }

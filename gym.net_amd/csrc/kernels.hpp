@@ -82,6 +82,8 @@ hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int6
 hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
                                   uint64_t lane_offset, uint64_t tick, hipStream_t st);
+hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t n, int32_t nvals, float epsilon, uint64_t seed,
+                                   uint64_t lane_offset, uint64_t tick, hipStream_t st);
 hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,
                              uint64_t tick, hipStream_t st);
 

@@ -221,6 +221,12 @@ class VectorEnv:
     def SampleActionsDevice(self, d_actions, seed=0, tick=0):
         capi.check(self._lib.gymnet_vecenv_sample_actions_device(self._h, _ptr(d_actions), int(seed), int(tick)))
 
+    def ComposeActionsDevice(self, d_policy_actions, epsilon, d_actions_out, seed=0, tick=0):
+        """Batched epsilon-greedy ComposeAction (TrainingPlaySession.cs:46-52): with probability epsilon the lane's
+        action is ActionSpace.Sample(), otherwise the policy's."""
+        capi.check(self._lib.gymnet_vecenv_compose_actions_device(self._h, _ptr(d_policy_actions), float(epsilon),
+                                                                  _ptr(d_actions_out), int(seed), int(tick)))
+
     def PackObsDevice(self, d_obs_rowmajor):
         capi.check(self._lib.gymnet_vecenv_pack_obs_device(self._h, _ptr(d_obs_rowmajor)))
 

@@ -245,6 +245,13 @@ int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t cou
 /* ActionSpace.Sample() for every lane of a handle into d_actions (int32 / float32 [num_envs]). */
 int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick);
 int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick);
+/* The caller's epsilon-greedy composer, batched (examples/ReinforcementLearning/ReinforcementLearning/PlaySessions/
+ * TrainingPlaySession.cs:46-52: `if (Random.NextDouble() <= _epsilon) return ActionSpace.Sample(); return policy action`).
+ * Lane i: u = 24-bit uniform from Philox word 1 of (seed, (global lane, tick)); out[i] = (u <= epsilon) ? the
+ * Discrete.Sample() draw of gymnet_vecenv_sample_actions_device for the same (seed, tick) : d_policy_actions[i].
+ * Discrete action spaces only. */
+int gymnet_vecenv_compose_actions_device(gymnet_vecenv *h, const int32_t *d_policy_actions, float epsilon, int32_t *d_actions_out,
+                                         uint64_t seed, uint64_t tick);
 
 #ifdef __cplusplus
 }

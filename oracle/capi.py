@@ -54,6 +54,7 @@ def lib():
     L.ref_reset_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u32p]
     L.ref_cartpole_reset_batch_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p, C.c_int64]
     L.ref_discrete_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _i32p, C.c_int64]
+    L.ref_compose_discrete_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64]
     L.ref_box_uniform_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _f32p, C.c_int64]
     L.ref_pendulum_step_f64.argtypes = [_f64p, C.c_double, _f64p, C.POINTER(C.c_double)]
     L.ref_pendulum_step_f32.argtypes = [_f32p, C.c_float, _f32p, C.POINTER(C.c_float)]
@@ -133,6 +134,13 @@ def cartpole_reset(seed, lane0, tick, n):
 def discrete_sample(seed, lane0, tick, nvals, start, count):
     out = np.zeros(count, dtype=np.int32)
     lib().ref_discrete_sample_batch(seed, lane0, tick, nvals, start, out, count)
+    return out
+
+
+def compose_discrete(seed, lane0, tick, nvals, epsilon, policy):
+    policy = np.ascontiguousarray(np.asarray(policy, dtype=np.int32))
+    out = np.zeros_like(policy)
+    lib().ref_compose_discrete_batch(seed, lane0, tick, nvals, epsilon, policy, out, policy.shape[0])
     return out
 
 

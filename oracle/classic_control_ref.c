@@ -253,6 +253,16 @@ void ref_discrete_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int
     for (int64_t i = 0; i < count; ++i) out[i] = ref_discrete_sample(seed, lane0 + (uint64_t)i, tick, n, start);
 }
 
+/* The engine's batched epsilon-greedy composer (TrainingPlaySession.cs:46-52): explore iff u01_24(word 1) <= epsilon. */
+void ref_compose_discrete_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, float epsilon,
+                                const int32_t *policy, int32_t *out, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) {
+        uint32_t w[4];
+        ref_reset_words(seed, lane0 + (uint64_t)i, tick, w);
+        out[i] = u01_24(w[1]) <= epsilon ? (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32) : policy[i];
+    }
+}
+
 /* Box.Sample() bounded regime — src/Gym/Spaces/Box.cs:69-90: uniform(low, high). Engine
  * semantics (binary32): low + (high-low)*u with u = 24-bit uniform from Philox word 0. */
 void ref_box_uniform_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, float low, float high,

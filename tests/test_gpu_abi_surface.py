@@ -191,3 +191,27 @@ def test_instance_properties_match_the_reference_constructor(gpu_pkg):
     cp = gpu_pkg.CartPoleEnv()
     assert cp.ActionSpace.Contains(cp.ActionSpace.Sample()) and cp.Render() is None
     cp.Dispose()
+
+
+def test_batched_epsilon_greedy_composer(gpu_pkg, oracle):
+    # TrainingPlaySession.ComposeAction (TrainingPlaySession.cs:46-52), one decision per lane
+    import torch
+    n, off = 200_000, 31
+    policy = torch.full((n,), 1, dtype=torch.int32, device="cuda")
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, lane_offset=off) as env:
+        for eps in (0.0, 0.25, 1.0):
+            env.ComposeActionsDevice(policy, eps, out, seed=5, tick=3); env.Sync()
+            got = out.cpu().numpy()
+            assert np.array_equal(got, oracle.compose_discrete(5, off, 3, 2, eps, np.ones(n, np.int32)))
+            if eps == 0.0:
+                assert (got == 1).all()                                           # never explores (u <= 0 has probability 2^-24)
+            if eps == 1.0:
+                assert np.array_equal(got, env.SampleActions(seed=5, tick=3))     # always ActionSpace.Sample()
+            if eps == 0.25:
+                assert abs((got == 0).mean() - 0.125) < 0.005                     # explored (25 %) and drew the other action (50 %)
+        with pytest.raises(ValueError):
+            env.ComposeActionsDevice(policy, 1.5, out)
+    with gpu_pkg.VectorEnv("Pendulum-v1", 8) as env, pytest.raises(NotImplementedError):
+        env.ComposeActionsDevice(policy, 0.1, out)
