@@ -39,3 +39,19 @@ for t in range(T):
 e1.record(st); torch.cuda.synchronize()
 print(json.dumps({"step + reset_where (reference loop shape), us per iteration": e0.elapsed_time(e1) * 1e3 / T}))
 env.Close()
+
+# closed loop on the device: a (random) policy kernel produces the actions of step t from nothing but the tick,
+# then the env steps — two launches per step, no host hop
+env = pkg.VectorEnv("CartPole-v1", n, seed=1, stream=st.cuda_stream, auto_reset=True)
+a = torch.empty(n, dtype=torch.int32, device=dev); torch.cuda.synchronize()
+env.ResetDevice()
+for t in range(64):
+    env.SampleActionsDevice(a, seed=3, tick=t); env.StepDevice(a)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for t in range(T):
+    env.SampleActionsDevice(a, seed=3, tick=t); env.StepDevice(a)
+e1.record(st); torch.cuda.synchronize()
+print(json.dumps({"closed loop: sample_actions kernel + step kernel, us per step": e0.elapsed_time(e1) * 1e3 / T}))
+env.Close()
