@@ -5,20 +5,32 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts the N rank processes itself: the
+parent spawns N fresh children before it makes any GPU call, forwards rank 0's JSON line and exits non-zero
+if any child fails.  When the box has fewer than N GPUs the children share the GPUs that exist over gloo
+(`config.backend` says so; that exercises the N > 1 plumbing, it is NOT a multi-GPU measurement).
+
 A "step" is ONE vector step = ONE launch of the step kernel over this GPU's whole batch
 (2^20 CartPole-v1 lanes, float32 structure-of-arrays state, fused auto-reset, iid random {0,1}
 actions pre-generated on the device by the engine's Philox sampler: BASELINE.json configs[1]).
 Weak scaling: every GPU owns 2^20 lanes of one global batch of N * 2^20 lanes (configs[4] at N = 8);
-lanes are independent, so the data path has no collective (`--allgather` adds the per-step RCCL
-observation all-gather north_star mentions, for measuring what it costs).
+lanes are independent, so the data path has no collective.  `value` is ALWAYS the step-only rate; the
+per-step RCCL observation all-gather north_star mentions is measured beside it at N > 1
+(`with_obs_allgather`: on the critical path, and overlapped with the next step through double-buffered
+observation arrays).
 
-The timed region is K steps, one kernel launch per step (gymnet_vecenv_rollout_device: back-to-back stream
-launches at this size, hipGraph replay for batches that are launch-bound), bracketed by barrier + synchronize;
-inputs are resident in HBM before it starts.  Prints ONE JSON line.
+Timing.  One timed region = EXACTLY K steps, one kernel launch per step, bracketed by barrier +
+synchronize on both sides, MAX over ranks; inputs are resident in HBM before it starts.  A K-step region
+of 7 us kernels can be as short as 0.15 ms, where host launch ramp and synchronize latency are a fifth of
+the time, so the region is REPEATED (same K, fresh bracket each time) until >= 50 ms have been timed and the
+MEDIAN repeat is reported: ms_per_step = median region wall / K, `repeats` says how many regions ran.
+Prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+MIN_TIMED_SECONDS = 0.05   # repeat the K-step region until this much has been timed
+MAX_REPEATS = 2000
 
 
 def parse():
@@ -36,12 +50,16 @@ def parse():
     p.add_argument("--env", default="CartPole-v1")
     p.add_argument("--num-envs", type=int, default=1 << 20, help="lanes per GPU")
     p.add_argument("--ring", type=int, default=256, help="distinct pre-generated action slices (ring * num_envs * 4 B)")
-    p.add_argument("--allgather", action="store_true", help="all-gather observations over RCCL after every step")
-    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--allgather", action="store_true", help="put the per-step RCCL observation all-gather INSIDE the timed "
+                   "region (then `value` is no longer the headline and config.workload says so)")
+    p.add_argument("--no-graph", action="store_true", help="eager launches from a python loop instead of gymnet_vecenv_rollout_device")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fused rollout, 2^27 lanes, copy probe)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 "
                    "(exercises the collective code path on a 1-GPU box)")
+    p.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
+    p.add_argument("--no-overlap", action="store_true", help="N > 1: single observation buffer (no gather/step overlap)")
     return p.parse_args()
 
 
@@ -65,8 +83,59 @@ def cpu_baseline(num_envs, target_seconds):
             "single_instance_100k_steps_per_sec": r1["steps_per_sec"]}
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  Nothing in this
+    function (or before it) touches the GPU; the children are started with subprocess (never exec from a process
+    that has initialised the GPU)."""
+    import torch                                        # device_count() does not initialise the GPU on this image
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(_free_port())
+    env["WORLD_SIZE"] = str(args.gpus)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ngpu < 1:
+        raise SystemExit("bench.py needs an AMD GPU: the engine has no CPU fallback")
+    if ngpu < args.gpus:
+        env.setdefault("GYMNET_BENCH_BACKEND", "gloo")   # ranks share the GPUs that exist; labelled in config.backend
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:                        # one rank died: the others would wait in a barrier forever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
+
+
+def median(xs):
+    s = sorted(xs)
+    m = len(s) // 2
+    return s[m] if len(s) % 2 else 0.5 * (s[m - 1] + s[m])
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    # lower completion latency of the closing synchronize: ROCr polls its signals instead of sleeping on an interrupt
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", os.environ.get("GYMNET_BENCH_HSA_INTERRUPT", "0"))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -75,8 +144,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an AMD GPU: the engine has no CPU fallback")
     # one process per GPU; GYMNET_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist (a 1-GPU box can then
@@ -105,59 +174,83 @@ def main():
     torch.cuda.set_stream(stream)
 
     # this rank's shard of the global batch; observations live inside the (optional) gather buffer
+    can_gather = use_dist and backend == "nccl"
     env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
                                auto_reset=True, gather_obs=use_dist, tensor_device=dev,
-                               force_gather=args.force_dist)
+                               force_gather=args.force_dist, overlap=can_gather and not args.no_overlap)
     local = env.local
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
     actions = torch.empty((ring, n), dtype=adtype, device=dev)
-    for t in range(ring):      # ActionSpace.Sample() per lane per step, on the device (Philox key = seed + 1)
+    for t in range(ring):      # ActionSpace.Sample() per lane per step, on the device (Philox stream "action", key = seed + 1)
         local.SampleActionsDevice(actions[t].data_ptr(), seed=seed + 1, tick=t)
     env.ResetDevice()
     env.Sync()
 
-    def run(steps):
-        if args.allgather and use_dist:
+    gather_in_region = bool(args.allgather and use_dist)
+
+    def run(steps, t0=0):
+        if gather_in_region:
             for t in range(steps):
-                env.StepDevice(actions[t % ring].data_ptr())
+                env.StepDevice(actions[(t0 + t) % ring].data_ptr())
                 env.AllGatherObs()
         elif args.no_graph:
             for t in range(steps):
-                env.StepDevice(actions[t % ring].data_ptr())
-        else:
+                env.StepDevice(actions[(t0 + t) % ring].data_ptr())
+        else:               # the C loop handles the double-buffered observation arrays itself
             local.RolloutDevice(actions.data_ptr(), steps, n, ring)
 
     def barrier():
         if use_dist:
             dist.barrier()
 
+    def timed_region(fn):
+        """One bracketed region: barrier + synchronize, fn(), synchronize + barrier.  Returns (wall s, event ms)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        barrier()
+        t1 = time.perf_counter()
+        return t1 - t0, e0.elapsed_time(e1)
+
+    def repeat_until(fn, min_seconds, max_repeats=MAX_REPEATS):
+        """Repeats the bracketed region until min_seconds have been timed (every rank runs the same count: the count
+        is fixed from rank 0's first region).  Returns per-repeat (wall, event_ms) maxima over ranks."""
+        first = timed_region(fn)
+        reps = max(3, min(max_repeats, int(min_seconds / max(first[0], 1e-7)) + 1))
+        if use_dist:
+            tr = torch.tensor([reps], dtype=torch.int64, device=red_dev)
+            dist.broadcast(tr, 0)
+            reps = int(tr[0])
+        rows = [first] + [timed_region(fn) for _ in range(reps - 1)]
+        if use_dist:
+            tw = torch.tensor(rows, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            rows = [(float(a), float(b)) for a, b in tw.tolist()]
+        return rows
+
     run(W)
     torch.cuda.synchronize(dev)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    run(K)
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    ev_ms = e0.elapsed_time(e1)
-    if use_dist:
-        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tw[0]), float(tw[1])
+    steps_before = local.Counters()["lane_steps"]
+    rows = repeat_until(lambda: run(K), args.min_seconds)
+    walls = [r[0] for r in rows]
+    wall = median(walls)
+    ev_ms = median([r[1] for r in rows])
+    repeats = len(rows)
 
-    # sanity: the engine really ran K + W steps on every lane
+    # sanity: the engine really ran K steps on every lane in every repeat
     c = local.Counters()
-    assert c["lane_steps"] == (K + W) * n, c
+    assert c["lane_steps"] - steps_before == repeats * K * n, (c, steps_before, repeats)
 
+    extras = rank == 0 and world == 1 and not args.no_extras and not gather_in_region
     # Cross-check of the per-launch figure: 200 single launches, each bracketed by its own HIP-event pair on the
     # engine's stream (isolated launches: no back-to-back overlap with a neighbour's ramp / drain).
     single_us = None
-    if not args.allgather:
+    if extras:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
         for t, (a0, a1) in enumerate(evs):
             a0.record(stream)
@@ -166,15 +259,12 @@ def main():
         torch.cuda.synchronize(dev)
         ds = sorted(a0.elapsed_time(a1) * 1e3 for a0, a1 in evs)
         single_us = ds[len(ds) // 2]
-        K_extra = len(evs)
-    else:
-        K_extra = 0
 
-    # Secondary figure, NOT the headline: the same K steps fused into one launch per `ring` steps (state stays in
+    # Secondary figure, NOT the headline: the same steps fused into one launch per `ring` steps (state stays in
     # registers, gymnet_vecenv_rollout_fused_device) — open-loop rollouts only, so it is reported beside, not as, `value`.
     fused = None
-    if not args.allgather:
-        fsteps = max(ring, (min(K, 2048) // ring) * ring)
+    if extras:
+        fsteps = max(ring, (min(max(K, 1024), 2048) // ring) * ring)
         local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
         torch.cuda.synchronize(dev)
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -187,36 +277,37 @@ def main():
         fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
                  "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
 
-    # Secondary figure for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
+    # Secondary figures for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
     # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
-    # collective; this shows what a consumer that wants every rank to see all observations pays over xGMI.
+    # collective; this shows what a consumer that wants every rank to see all observations pays over xGMI —
+    # (a) with the gather on the critical path, (b) overlapped with the next step (double-buffered observation arrays:
+    # step t+1 writes buffer B while the gather of buffer A is in flight on a side stream).
     gathered = None
-    if use_dist and not args.allgather and backend == "nccl":
-        try:
-            gs = 128
-            for t in range(16):
-                env.StepDevice(actions[t % ring].data_ptr()); env.AllGatherObs()
-            torch.cuda.synchronize(dev); barrier()
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            tg0 = time.perf_counter()
-            g0.record(stream)
-            for t in range(gs):
-                env.StepDevice(actions[t % ring].data_ptr()); env.AllGatherObs()
-            g1.record(stream)
-            torch.cuda.synchronize(dev); barrier()
-            gwall = time.perf_counter() - tg0
-            tg = torch.tensor([gwall], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            ok = bool(torch.isfinite(env.GlobalObs()).all()) and all(float(env.GlobalObs()[r].abs().sum()) > 0 for r in range(world))
-            gathered = {"value": n * world * gs / float(tg[0]), "unit": "env-steps/s", "ms_per_step": float(tg[0]) * 1e3 / gs,
-                        "steps": gs, "allgather_bytes_per_rank_per_step": env.obs_dim * n * 4, "gathered_obs_finite_and_nonzero": ok}
-        except Exception as e:                      # never lose the headline over the optional collective
-            gathered = {"error": repr(e)[:200]}
+    if can_gather and not gather_in_region:
+        gathered = {}
+        gs = 128
+        for label, overlapped in (("serial", False), ("overlapped", True)) if env.overlap else (("serial", False),):
+            try:
+                def gloop(steps=gs):
+                    for t in range(steps):
+                        env.StepDevice(actions[t % ring].data_ptr())
+                        env.AllGatherObs(overlap=overlapped)
+                    env.WaitGather()
+                gloop(16)
+                grows = repeat_until(gloop, args.min_seconds, max_repeats=16)
+                gwall = median([r[0] for r in grows])
+                obs = env.LastGatheredObs()
+                ok = bool(torch.isfinite(obs).all()) and all(float(obs[r].abs().sum()) > 0 for r in range(world))
+                gathered[label] = {"value": n * world * gs / gwall, "unit": "env-steps/s", "ms_per_step": gwall * 1e3 / gs,
+                                   "steps": gs, "repeats": len(grows), "gathered_obs_finite_and_nonzero": ok}
+            except Exception as e:                      # never lose the headline over the optional collective
+                gathered[label] = {"error": repr(e)[:200]}
+        gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4
 
     # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
     # beside the 8 TB/s spec peak the roofline fraction uses: cache-resident (32 MiB) and HBM-resident (2 GiB).
     copy_bw = None
-    if rank == 0 and world == 1:
+    if extras:
         copy_bw = {}
         for label, mib in (("32MiB", 32), ("2GiB", 2048)):
             src = torch.empty(mib * (1 << 18), dtype=torch.float32, device=dev).normal_()
@@ -234,34 +325,84 @@ def main():
             copy_bw[label] = 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9
             del src, dst
 
+    bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
+    launch_policy = local.LaunchPolicy()
+    overlap_on = env.overlap
+    env.Close()
+    del actions
+    torch.cuda.empty_cache()
+
+    # Secondary figure, NOT the headline: the same kernel at 2^27 lanes — 5.5 GB per step, 2 GiB of state: nothing
+    # can stay in the 256 MiB Infinity Cache, so this is what the path does against real HBM (at 2^20 lanes the
+    # 43 MB working set is cache-resident and "HBM GB/s" is really fabric / Infinity-Cache bandwidth).
+    big = None
+    if extras and args.env == "CartPole-v1" and n == (1 << 20):
+        try:
+            nb, rb, kb = 1 << 27, 2, 20
+            with pkg.VectorEnv(args.env, nb, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream) as e2:
+                a2 = torch.empty((rb, nb), dtype=adtype, device=dev)
+                for t in range(rb):
+                    e2.SampleActionsDevice(a2[t].data_ptr(), seed=seed + 1, tick=t)
+                e2.ResetDevice()
+                e2.RolloutDevice(a2.data_ptr(), 4, nb, rb)
+                e2.Sync()
+                brows = [timed_region(lambda: e2.RolloutDevice(a2.data_ptr(), kb, nb, rb)) for _ in range(3)]
+                bev = median([r[1] for r in brows])
+                bwall = median([r[0] for r in brows])
+                bgbps = bytes_per_step * nb / (bev * 1e-3 / kb) / 1e9
+                big = {"num_envs": nb, "steps": kb, "repeats": len(brows), "env_steps_per_sec": nb * kb / bwall,
+                       "launch_us": bev * 1e3 / kb, "achieved_GBps": bgbps, "frac_of_peak": bgbps / HBM_PEAK_GBPS,
+                       "launch_policy": e2.LaunchPolicy(),
+                       "note": "working set 5.5 GB per step >> 256 MiB Infinity Cache: real HBM traffic"}
+                del a2
+        except Exception as e:
+            big = {"error": repr(e)[:200]}
+
     if rank == 0:
-        bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
-        launch_us = ev_ms * 1e3 / K                                          # HIP events over the timed region / launches
+        launch_us = ev_ms * 1e3 / K                                          # HIP events over the (median) timed region / launches
         achieved = bytes_per_step * n / (launch_us * 1e-6) / 1e9             # GB/s per GPU, algorithmic bytes
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")               # rocprofv3 --pmc result, per launch
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.env, {}).get(str(n))
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.env, {}).get(str(n))
+                if traffic is not None:
+                    traffic_source = ("NOT measured in this run: constant read from profiles/traffic.json — "
+                                      + str(tj.get("_source", "rocprofv3 --pmc passes")))
             except Exception:
                 traffic = None
+        if gather_in_region:
+            what = "value = step + RCCL observation all-gather after every step (NOT the step-only headline)"
+        elif world > 1:
+            what = "value = step-only rate (no collective on the data path); with_obs_allgather = the same stepping plus the per-step RCCL gather"
+        else:
+            what = "value = step-only rate"
         out = {
             "metric": "env-steps/sec", "value": n * world * K / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": repeats, "region_ms_median": wall * 1e3, "region_ms_min": min(walls) * 1e3, "region_ms_max": max(walls) * 1e3,
             "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), float32 SoA state, "
-                                   "fused auto-reset, iid random actions pre-generated in HBM",
+                                   f"fused auto-reset, iid random actions pre-generated in HBM; {what}",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
-                       "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or args.allgather) else
+                       "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or gather_in_region) else
                                   "one kernel launch per step; gymnet_vecenv_rollout_device: " +
-                                  ("hipGraph replay" if n * local.AlgorithmicBytesPerStep < (24 << 20) else "back-to-back stream launches")),
-                       "allgather_obs": bool(args.allgather and use_dist), "parallelism": f"lane-sharded x{world}"},
+                                  ("hipGraph replay" if n * bytes_per_step < (24 << 20) else "back-to-back stream launches")),
+                       "launch_policy": launch_policy,
+                       "timing": f"median of {repeats} bracketed {K}-step regions (>= {args.min_seconds * 1e3:.0f} ms timed in total)",
+                       "backend": ("rccl" if backend == "nccl" else backend + " (ranks SHARE the GPUs that exist: plumbing check, not a multi-GPU measurement)") if use_dist else "single process",
+                       "allgather_obs_in_timed_region": gather_in_region, "double_buffered_obs": bool(overlap_on), "parallelism": f"lane-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
-                         "isolated_launch_us_median": single_us, "measured_copy_GBps": copy_bw},
+                         "frac_by_wall": bytes_per_step * n / (wall / K) / 1e9 / HBM_PEAK_GBPS,
+                         "isolated_launch_us_median": single_us, "measured_copy_GBps": copy_bw,
+                         "note": "at 2^20 lanes the 43 MB working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
         }
+        if big:
+            out["hbm_resident_2p27"] = big
         if fused:
             out["fused_rollout"] = fused
         if gathered:
@@ -269,8 +410,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    env.Close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

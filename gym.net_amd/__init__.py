@@ -7,17 +7,17 @@ Step interface.  The directory name contains a dot, so it is loaded by path
 (`__graft_entry__.load_package()` registers it as module `gymnet_amd`).
 """
 from . import _capi
-from ._capi import (ENV_IDS, FLAG_AUTORESET, FLAG_DONE_LIST, FLAG_EPISODE_STATS, FLAG_FINAL_OBS,
+from ._capi import (ENV_IDS, FLAG_AUTORESET, FLAG_DONE_LIST, FLAG_DOUBLE_BUFFER, FLAG_EPISODE_STATS, FLAG_FINAL_OBS,
                     FLAG_VALIDATE_ACTIONS, LIB_PATH, device_count, env_describe, load_library)
 from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDeviceError,
                      NotSteppingError)
 from .sharding import ShardPlan, ShardedVectorEnv
 from .spaces import Box, Discrete, Space
 from .step import Step
-from .vector_env import (AcrobotEnv, BatchStep, CartPoleEnv, DummyVecEnv, GpuEnv, MountainCarEnv, PendingStep,
+from .vector_env import (AcrobotEnv, BatchStep, CartPoleEnv, DummyVecEnv, GpuEnv, GroupVectorEnv, MountainCarEnv, PendingStep,
                          PendulumEnv, VectorEnv)
 
-__all__ = ["VectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
+__all__ = ["VectorEnv", "GroupVectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
            "AcrobotEnv", "Space", "Box", "Discrete", "Step", "InvalidActionError", "AlreadySteppingError",
            "NotSteppingError", "GymNetError", "NoDeviceError", "ShardPlan", "ShardedVectorEnv", "device_count",
            "env_describe", "load_library", "LIB_PATH", "ENV_IDS"]

@@ -25,6 +25,7 @@ ERR_NO_DEVICE = -5
 ERR_ALREADY_STEPPING = -6
 ERR_NOT_STEPPING = -7
 ERR_UNSUPPORTED = -8
+ERR_RCCL = -9
 
 ENV_CARTPOLE, ENV_PENDULUM, ENV_MOUNTAINCAR, ENV_ACROBOT = 0, 1, 2, 3
 ENV_IDS = {"CartPole-v1": 0, "Pendulum-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3}
@@ -34,13 +35,18 @@ FLAG_VALIDATE_ACTIONS = 0x02
 FLAG_DONE_LIST = 0x04
 FLAG_EPISODE_STATS = 0x08
 FLAG_FINAL_OBS = 0x10
+FLAG_DOUBLE_BUFFER = 0x20
+
+GATHER_NONE, GATHER_DIRECT, GATHER_RCCL = 0, 1, 2
+ABI_VERSION = 2
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("env_id", C.c_int32), ("num_envs", C.c_int64),
                 ("lane_offset", C.c_int64), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("seed", C.c_uint64), ("stream", C.c_void_p), ("d_ext_obs", C.c_void_p),
-                ("ext_obs_stride", C.c_int64), ("max_episode_steps", C.c_int32), ("reserved", C.c_int32)]
+                ("ext_obs_stride", C.c_int64), ("max_episode_steps", C.c_int32), ("reserved", C.c_int32),
+                ("d_ext_obs_alt", C.c_void_p)]
 
 
 class EnvInfo(C.Structure):
@@ -61,7 +67,14 @@ class DeviceView(C.Structure):
                 ("d_final_obs", C.c_void_p), ("d_done_list", C.c_void_p),
                 ("d_episode_return", C.c_void_p), ("d_episode_length", C.c_void_p),
                 ("d_finished_return", C.c_void_p), ("d_finished_length", C.c_void_p),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("obs_buffer", C.c_int32), ("reserved", C.c_int32),
+                ("d_obs_alt", C.c_void_p)]
+
+
+class GroupConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("env_id", C.c_int32), ("global_num_envs", C.c_int64),
+                ("num_members", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64),
+                ("devices", C.POINTER(C.c_int32)), ("gather", C.c_int32), ("max_episode_steps", C.c_int32)]
 
 
 class RolloutBuffers(C.Structure):
@@ -103,6 +116,7 @@ PROTOTYPES = {
     "gymnet_vecenv_pack_obs_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_sync": (C.c_int, [_H]),
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),
+    "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_set_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_get_steps_beyond_done": (C.c_int, [_H, _P]),
@@ -116,11 +130,29 @@ PROTOTYPES = {
     "gymnet_vecenv_final_obs": (C.c_int, [_H, _P]),
     "gymnet_sample_discrete_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32,
                                                 C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gymnet_sample_discrete_masked_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64,
+                                                       C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gymnet_vecenv_sample_actions_masked_device": (C.c_int, [_H, _P, _P, C.c_int64, C.c_uint64, C.c_uint64]),
     "gymnet_sample_box_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_float, C.c_float,
                                            C.c_uint64, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions_device": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_compose_actions_device": (C.c_int, [_H, _P, C.c_float, _P, C.c_uint64, C.c_uint64]),
+    "gymnet_group_create": (C.c_int, [C.POINTER(GroupConfig), C.POINTER(_H)]),
+    "gymnet_group_destroy": (C.c_int, [_H]),
+    "gymnet_group_size": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "gymnet_group_member": (C.c_int, [_H, C.c_int32, C.POINTER(_H)]),
+    "gymnet_group_seed": (C.c_int, [_H, C.c_uint64]),
+    "gymnet_group_reset_device": (C.c_int, [_H]),
+    "gymnet_group_step_device": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "gymnet_group_rollout_device": (C.c_int, [_H, C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int64]),
+    "gymnet_group_allgather_obs": (C.c_int, [_H]),
+    "gymnet_group_wait_gather": (C.c_int, [_H]),
+    "gymnet_group_global_obs": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gymnet_group_read_replica": (C.c_int, [_H, C.c_int32, _P]),
+    "gymnet_group_sync": (C.c_int, [_H]),
+    "gymnet_group_reset": (C.c_int, [_H, _P]),
+    "gymnet_group_step": (C.c_int, [_H, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -159,7 +191,7 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.gymnet_abi_version() != 1:
+    if lib.gymnet_abi_version() != ABI_VERSION:
         raise GymNetError("libgymnet_amd.so ABI version mismatch")
     _lib = lib
     return lib
@@ -178,6 +210,7 @@ _ERRORS = {
     ERR_NOT_STEPPING: NotSteppingError,
     ERR_OOM: MemoryError,
     ERR_UNSUPPORTED: NotImplementedError,        # NotSupportedException
+    ERR_RCCL: RuntimeError,
 }
 
 

@@ -1,6 +1,6 @@
 """Builds gym.net_amd/lib/libgymnet_amd.so: the HIP kernels + the C ABI, for gfx950 only.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared csrc/*.hip -o lib/libgymnet_amd.so
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared csrc/*.hip -ldl -o lib/libgymnet_amd.so
 
 -ffp-contract=off is part of the numerical contract (see csrc/envs.hpp): every float32 operation
 rounds on its own, in the order written.  hipcc cross-compiles without a GPU present.
@@ -12,9 +12,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libgymnet_amd.so")
-SOURCES = ["kernels.hip", "capi.hip"]
-DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
+SOURCES = ["kernels.hip", "capi.hip", "group.hip"]
+DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
 
 
 def hipcc():
@@ -35,7 +36,7 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LIBS + ["-o", OUT + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -1,17 +1,33 @@
 // VectorEnv.cs — a VecEnv (src/Gym/Envs/VecEnv.cs:12-93) whose Step/Reset are ONE HIP kernel launch.
 // UNVERIFIED: never compiled (no .NET toolchain in the build image).  Drop next to VecEnvWrapper.cs.
+//
+// Dispatch through the reference's own types.  VecEnv.Seed(int), Seed(int[]) and StepAsync(int) are NOT virtual
+// (VecEnv.cs:44-65), so a derived class cannot override them, and `public new` members are invisible to callers that hold
+// an IVecEnv or a VecEnv.  Two things make the polymorphic callers work:
+//   1. the class RE-LISTS IVecEnv and implements Seed(int) / Seed(int[]) explicitly: every call through IVecEnv
+//      (IVecEnv.cs:17-18) lands in the native seed functions;
+//   2. `Environments` (VecEnv.cs:25, settable) is a virtual list of N lane proxies.  The non-virtual base Seed — what a
+//      VecEnv-typed variable calls — walks Environments and calls Environments[i].Seed(seed[i]) (VecEnv.cs:50-52); each proxy
+//      records its lane's seed and the last one flushes the batch to gymnet_vecenv_seed_lanes.  So the base path has the
+//      reference's semantics (every env seeded with its own value; Seed(int) = the same value for all, VecEnv.cs:44-46) and
+//      its ArgumentException on a length mismatch, without 2^20 IEnv objects ever being stored.
 using System;
+using System.Collections;
+using System.Collections.Generic;
 using System.Threading.Tasks;
 using Gym.Collections;
 using Gym.Observations;
 using Gym.Spaces;
 using NumSharp;
+using SixLabors.ImageSharp;
 
 namespace Gym.Envs.Amd {
-    public sealed unsafe class VectorEnv : VecEnv, IDisposable {
+    public sealed unsafe class VectorEnv : VecEnv, IVecEnv, IDisposable {
         private IntPtr _h;
         private readonly int _obsDim;
         private readonly bool _boxAction;
+        internal ulong[] PendingLaneSeeds;          // filled by the lane proxies when the base-class Seed runs
+        internal int PendingLaneSeedCount;
 
         public VectorEnv(GymnetEnvId env, int numEnvs, int device = 0, ulong seed = 0, GymnetFlags flags = GymnetFlags.None,
                          long laneOffset = 0)
@@ -23,8 +39,12 @@ namespace Gym.Envs.Amd {
             };
             Native.Check(Native.gymnet_vecenv_create(ref cfg, out _h));
             Metadata = new Dict("render.modes", new[] {"human", "rgb_array"}, "video.frames_per_second", 50);   // CartPoleEnv.cs:51
-            // Environments stays empty: 2^20 IEnv objects are never materialised (SURVEY F7).
+            Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo info));
+            RewardRange = (info.reward_low, info.reward_high);
+            Environments = new LaneList(this);      // virtual: N proxies materialised on demand, never stored (SURVEY F7)
         }
+
+        internal IntPtr Handle => _h;
 
         private static Space MakeObservationSpace(GymnetEnvId env, out int obsDim) {
             Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo i));
@@ -54,21 +74,32 @@ namespace Gym.Envs.Amd {
             return rows;
         }
 
-        /// IVecEnv.Step(int) (IVecEnv.cs:15): ONE scalar action broadcast to every lane; Step[] materialised per lane.
-        public override Step[] Step(int action) {                                                                 // VecEnvWrapper.cs:22-24
-            var (obs, rew, done) = StepBroadcastArrays(action);
+        /// The caller's `if (done) Reset()` (README.md:36-40) for the lanes in mask (null = lanes whose last done flag is set).
+        public NDArray ResetWhere(byte[] mask = null) {
+            if (mask != null && mask.Length != NumberOfEnvironments) throw new ArgumentException("mask length must equal NumberOfEnvironments");
+            var obs = new float[NumberOfEnvironments * _obsDim];
+            fixed (float* p = obs) fixed (byte* m = mask) Native.Check(Native.gymnet_vecenv_reset_where(_h, m, p));
+            return np.array(obs).reshape(NumberOfEnvironments, _obsDim);
+        }
+
+        private Step[] ToSteps(float[] obs, float[] rew, byte[] done) {
+            var all = np.array(obs).reshape(NumberOfEnvironments, _obsDim);
             var steps = new Step[NumberOfEnvironments];
-            for (int i = 0; i < steps.Length; i++) steps[i] = new Step(obs[i], rew.GetSingle(i), done.GetByte(i) != 0, null);
+            for (int i = 0; i < steps.Length; i++) steps[i] = new Step(all[i], rew[i], done[i] != 0, null);       // Step.cs:15-20
             return steps;
         }
 
-        public (NDArray obs, NDArray reward, NDArray done) StepBroadcastArrays(int action) {
+        /// IVecEnv.Step(int) (IVecEnv.cs:15): ONE scalar action broadcast to every lane; Step[] materialised per lane.
+        public override Step[] Step(int action) {                                                                 // VecEnvWrapper.cs:22-24
             int n = NumberOfEnvironments;
             var obs = new float[n * _obsDim]; var rew = new float[n]; var done = new byte[n];
             fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done)
                 Native.Check(Native.gymnet_vecenv_step_broadcast(_h, action, po, pr, pd));
-            return (np.array(obs).reshape(n, _obsDim), np.array(rew), np.array(done));
+            return ToSteps(obs, rew, done);
         }
+
+        /// Env<TAction>.Step(TAction) (Env.cs:43-53) for enum-typed discrete actions: the enum's integer value.
+        public Step[] Step<TAction>(TAction action) where TAction : Enum => Step((int) (object) action);
 
         /// EXTENSION: one action per lane (int32 for Discrete, float32 for Box), array-valued results.
         public (NDArray obs, NDArray reward, NDArray done) Step(NDArray actions) {
@@ -82,12 +113,44 @@ namespace Gym.Envs.Amd {
             return (np.array(obs).reshape(n, _obsDim), np.array(rew), np.array(done));
         }
 
-        public new Task<Step[]> StepAsync(int action) => Task.Run(() => Step(action));                          // VecEnv.cs:63-65
+        /// VecEnv.StepAsync (VecEnv.cs:63-65) on the native queue: gymnet_vecenv_step_async returns once the step is queued on
+        /// the handle's stream; the Task completes in gymnet_vecenv_step_wait.  A second StepAsync before the first finished
+        /// surfaces the reference's AlreadySteppingError (AlreadySteppingError.cs:8-10).
+        public new Task<Step[]> StepAsync(int action) {
+            int n = NumberOfEnvironments;
+            if (_boxAction) { var a = new float[n]; for (int i = 0; i < n; i++) a[i] = action; fixed (float* pa = a) Native.Check(Native.gymnet_vecenv_step_async(_h, pa)); }
+            else { var a = new int[n]; for (int i = 0; i < n; i++) a[i] = action; fixed (int* pa = a) Native.Check(Native.gymnet_vecenv_step_async(_h, pa)); }
+            return Task.Run(() => {
+                var obs = new float[n * _obsDim]; var rew = new float[n]; var done = new byte[n];
+                fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done)
+                    Native.Check(Native.gymnet_vecenv_step_wait(_h, po, pr, pd));
+                return ToSteps(obs, rew, done);
+            });
+        }
 
-        public new void Seed(int seed) => Native.Check(Native.gymnet_vecenv_seed(_h, (ulong) seed));             // VecEnv.cs:44-46 (see DESIGN.md: lanes differ)
-        public new void Seed(int[] seed) {                                                                       // VecEnv.cs:48-53
+        // ---- seeding: explicit IVecEnv implementations (interface callers), `new` members (VectorEnv-typed callers), and the
+        //      lane proxies (VecEnv-typed callers, see the header comment)
+        void IVecEnv.Seed(int seed) => SeedAll(seed);                                                            // IVecEnv.cs:18
+        void IVecEnv.Seed(int[] seed) => SeedLanes(seed);                                                        // IVecEnv.cs:17
+        public new void Seed(int seed) => SeedAll(seed);
+        public new void Seed(int[] seed) => SeedLanes(seed);
+
+        /// VecEnv.Seed(int) (VecEnv.cs:44-46).  DEVIATION (DESIGN.md §1): one Philox key for the batch, lanes differ by counter.
+        private void SeedAll(int seed) => Native.Check(Native.gymnet_vecenv_seed(_h, (ulong) seed));
+
+        private void SeedLanes(int[] seed) {                                                                     // VecEnv.cs:48-53
+            if (seed == null) throw new ArgumentNullException(nameof(seed));
             var s = Array.ConvertAll(seed, x => (ulong) x);
-            Native.Check(Native.gymnet_vecenv_seed_lanes(_h, s, s.Length));
+            Native.Check(Native.gymnet_vecenv_seed_lanes(_h, s, s.Length));     // length mismatch -> ArgumentException (VecEnv.cs:49)
+        }
+
+        internal void SeedLaneFromProxy(int lane, int seed) {
+            if (PendingLaneSeeds == null) { PendingLaneSeeds = new ulong[NumberOfEnvironments]; PendingLaneSeedCount = 0; }
+            PendingLaneSeeds[lane] = (ulong) seed;
+            if (++PendingLaneSeedCount == NumberOfEnvironments) {                // the base Seed loop reached the last env
+                var s = PendingLaneSeeds; PendingLaneSeeds = null; PendingLaneSeedCount = 0;
+                Native.Check(Native.gymnet_vecenv_seed_lanes(_h, s, s.Length));
+            }
         }
 
         public override void Close() {                                                                            // VecEnvWrapper.cs:26-30
@@ -95,5 +158,92 @@ namespace Gym.Envs.Amd {
         }
 
         public void Dispose() => Close();
+    }
+
+    /// `Environments` of a VectorEnv: an IList<IEnv> of N lane proxies created on demand (VecEnv.cs:25 lets it be replaced).
+    internal sealed class LaneList : IList<IEnv> {
+        private readonly VectorEnv _owner;
+        public LaneList(VectorEnv owner) { _owner = owner; }
+        public int Count => _owner.NumberOfEnvironments;
+        public bool IsReadOnly => true;
+        public IEnv this[int index] {
+            get { if (index < 0 || index >= Count) throw new ArgumentOutOfRangeException(nameof(index)); return new LaneEnv(_owner, index); }
+            set => throw new NotSupportedException("the lanes of a VectorEnv are fixed");
+        }
+        public IEnumerator<IEnv> GetEnumerator() { for (int i = 0; i < Count; i++) yield return new LaneEnv(_owner, i); }
+        IEnumerator IEnumerable.GetEnumerator() => GetEnumerator();
+        public bool Contains(IEnv item) => item is LaneEnv l && ReferenceEquals(l.Owner, _owner);
+        public int IndexOf(IEnv item) => item is LaneEnv l && ReferenceEquals(l.Owner, _owner) ? l.Lane : -1;
+        public void CopyTo(IEnv[] array, int arrayIndex) { for (int i = 0; i < Count; i++) array[arrayIndex + i] = new LaneEnv(_owner, i); }
+        public void Add(IEnv item) => throw new NotSupportedException();
+        public void Clear() => throw new NotSupportedException();
+        public void Insert(int index, IEnv item) => throw new NotSupportedException();
+        public bool Remove(IEnv item) => throw new NotSupportedException();
+        public void RemoveAt(int index) => throw new NotSupportedException();
+    }
+
+    /// One lane of a VectorEnv seen as an IEnv (IEnv.cs:11-22).  Seed / Reset act on the lane; a lane cannot be stepped alone.
+    internal sealed class LaneEnv : IEnv {
+        internal readonly VectorEnv Owner;
+        internal readonly int Lane;
+        public LaneEnv(VectorEnv owner, int lane) { Owner = owner; Lane = lane; }
+        public Dict Metadata { get => Owner.Metadata; set => Owner.Metadata = value; }
+        public (float From, float To) RewardRange { get => Owner.RewardRange; set => Owner.RewardRange = value; }
+        public Space ActionSpace { get => Owner.ActionSpace; set => Owner.ActionSpace = value; }
+        public Space ObservationSpace { get => Owner.ObservationSpace; set => Owner.ObservationSpace = value; }
+        public NDArray Reset() { var m = new byte[Owner.NumberOfEnvironments]; m[Lane] = 1; return Owner.ResetWhere(m)[Lane]; }   // CartPoleEnv.cs:63-67
+        public Step Step(object action) => throw new NotSupportedException("step the whole batch: VectorEnv.Step(int) / Step(NDArray)");
+        public Task<Step> StepAsync(object action) => throw new NotSupportedException("step the whole batch: VectorEnv.StepAsync(int)");
+        public Image Render(string mode = "human") => null;                       // rendering is out of scope (NullEnvViewer semantics)
+        public void CloseEnvironment() { }                                        // the batch owns the resources
+        public void Seed(int seed) => Owner.SeedLaneFromProxy(Lane, seed);        // CartPoleEnv.cs:196-198
+    }
+
+    /// ONE process driving G GPUs through gymnet_group_* (include/gymnet_amd.h): member m owns lanes [m*N/G, (m+1)*N/G); every
+    /// member keeps a replica of all observations, completed by AllGatherObs (hand-written direct push over xGMI, or RCCL).
+    public sealed unsafe class GroupVectorEnv : IDisposable {
+        private IntPtr _g;
+        public int NumberOfEnvironments { get; }
+        public int NumMembers { get; }
+        public int ObsDim { get; }
+
+        public GroupVectorEnv(GymnetEnvId env, long globalNumEnvs, int[] devices, ulong seed = 0, GymnetFlags flags = GymnetFlags.AutoReset,
+                              GymnetGatherMode gather = GymnetGatherMode.Direct) {
+            if (devices == null) throw new ArgumentNullException(nameof(devices));
+            Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo info));
+            ObsDim = info.obs_dim; NumMembers = devices.Length; NumberOfEnvironments = (int) globalNumEnvs;
+            fixed (int* pd = devices) {
+                var cfg = new GymnetGroupConfig {
+                    struct_size = (uint) sizeof(GymnetGroupConfig), env_id = (int) env, global_num_envs = globalNumEnvs,
+                    num_members = devices.Length, flags = (uint) flags, seed = seed, devices = (IntPtr) pd, gather = (int) gather
+                };
+                Native.Check(Native.gymnet_group_create(ref cfg, out _g));
+            }
+        }
+
+        public void Seed(int seed) => Native.Check(Native.gymnet_group_seed(_g, (ulong) seed));
+
+        public NDArray Reset() {
+            var obs = new float[NumberOfEnvironments * ObsDim];
+            fixed (float* p = obs) Native.Check(Native.gymnet_group_reset(_g, p));
+            return np.array(obs).reshape(NumberOfEnvironments, ObsDim);
+        }
+
+        public (NDArray obs, NDArray reward, NDArray done) Step(int[] actions) {
+            int n = NumberOfEnvironments;
+            if (actions.Length != n) throw new ArgumentException("Number of actions passed should be equals to number of environments");
+            var obs = new float[n * ObsDim]; var rew = new float[n]; var done = new byte[n];
+            fixed (int* pa = actions) fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done)
+                Native.Check(Native.gymnet_group_step(_g, pa, po, pr, pd));
+            return (np.array(obs).reshape(n, ObsDim), np.array(rew), np.array(done));
+        }
+
+        public void StepDevice(IntPtr[] dActions) => Native.Check(Native.gymnet_group_step_device(_g, dActions));
+        public void AllGatherObs() => Native.Check(Native.gymnet_group_allgather_obs(_g));
+        public void WaitGather() => Native.Check(Native.gymnet_group_wait_gather(_g));
+        public IntPtr GlobalObs(int member) { Native.Check(Native.gymnet_group_global_obs(_g, member, out IntPtr p)); return p; }
+        public void Sync() => Native.Check(Native.gymnet_group_sync(_g));
+
+        public void Dispose() { if (_g != IntPtr.Zero) { Native.gymnet_group_destroy(_g); _g = IntPtr.Zero; } }
     }
 }

@@ -5,39 +5,24 @@
 // and is never linked here.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cmath>
-#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <string>
-#include <vector>
 
-#include "../../include/gymnet_amd.h"
-#include "kernels.hpp"
+#include "handle.hpp"
 
 using namespace gymnet;
 
 namespace {
-
 thread_local std::string g_last_error;
 constexpr int64_t kSmallHostPath = 4096;
-
-struct EnvDesc {
-    const char *name;
-    int state_dim, obs_dim;
-    bool alias, box_action, has_sbd;
-    int action_n;
-    float action_low, action_high;
-    float obs_low[8], obs_high[8];
-    float reward_low, reward_high;
-    int algorithmic_bytes;
-};
-
 constexpr float FMAX = 3.4028234663852886e38f;
 constexpr float PI_F = 3.14159265358979323846f;
+}  // namespace
+
+namespace gymnet {
 
 // Observation bounds: CartPoleEnv.cs:46-48 (high = [x_thr*2, float.MaxValue, theta_thr*2, float.MaxValue]).
 // Algorithmic bytes per env-step: SURVEY.md §8(a)/(d).
@@ -52,58 +37,7 @@ const EnvDesc kEnvs[4] = {
      {-1.f, -1.f, -1.f, -1.f, -4.f * PI_F, -9.f * PI_F}, {1.f, 1.f, 1.f, 1.f, 4.f * PI_F, 9.f * PI_F}, -1.f, 0.f, 65},
 };
 
-struct GraphEntry {
-    const void *actions;
-    int64_t len, stride, ring;
-    int parity, cparity;
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-};
-
-}  // namespace
-
-struct gymnet_vecenv {
-    gymnet_config cfg{};
-    const EnvDesc *desc = nullptr;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t n = 0, sstride = 0, ostride = 0;
-    bool autoreset = false, extras = false;
-    float *d_state = nullptr, *d_obs = nullptr;
-    bool own_state = false, own_obs = false;
-    float *d_reward = nullptr;
-    uint8_t *d_done = nullptr, *d_mask = nullptr;
-    int32_t *d_sbd = nullptr;
-    uint64_t *d_tick2 = nullptr;
-    void *d_actions = nullptr;     // staging for host-path / broadcast actions
-    float *d_pack = nullptr;       // row-major obs staging
-    float *d_final_obs = nullptr;
-    int32_t *d_done_list = nullptr, *d_done_compact = nullptr;    // sharded segments / compact list (on demand)
-    uint32_t *d_done_count2 = nullptr, *d_done_total = nullptr;
-    int64_t done_cap = 0;
-    float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
-    int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
-    uint64_t *d_lane_seed = nullptr;
-    unsigned long long *d_after_done = nullptr;
-    // small batches (n <= kSmallHostPath): host-mapped staging, so a host-boundary step is 2 kernel launches + 1 sync
-    void *hm_actions = nullptr;    // pinned + mapped: the step kernel reads the actions straight from it
-    float *hm_obs = nullptr, *hm_reward = nullptr;
-    uint8_t *hm_done = nullptr;
-    void *hm_block = nullptr;
-    uint32_t *d_bad = nullptr;
-    uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
-    int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
-    int last_cparity = -1;
-    bool async_pending = false;
-    std::atomic<bool> busy{false};
-    LaunchCfg lcfg{4, 256, 0};
-    std::vector<GraphEntry> graphs;
-    std::vector<void *> owned;     // device allocations to free
-    std::string err;
-};
-
-namespace {
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
 int fail(gymnet_vecenv *h, int status, const char *fmt, ...) {
     char buf[512];
@@ -116,35 +50,9 @@ int fail(gymnet_vecenv *h, int status, const char *fmt, ...) {
     return status;
 }
 
-#define HIP_TRY(h, expr)                                                                              \
-    do {                                                                                              \
-        hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess)                                                                         \
-            return fail(h, e_ == hipErrorOutOfMemory ? GYMNET_ERR_OOM : GYMNET_ERR_HIP, "%s failed: %s", #expr, \
-                        hipGetErrorString(e_));                                                       \
-    } while (0)
+}  // namespace gymnet
 
-#define ST_TRY(expr)                  \
-    do {                              \
-        int s_ = (expr);              \
-        if (s_ != GYMNET_OK) return s_; \
-    } while (0)
-
-struct BusyGuard {
-    gymnet_vecenv *h;
-    bool ok;
-    explicit BusyGuard(gymnet_vecenv *hh) : h(hh), ok(false) {
-        bool expect = false;
-        ok = h->busy.compare_exchange_strong(expect, true);
-    }
-    ~BusyGuard() { if (ok) h->busy.store(false); }
-};
-
-#define ENTER(h)                                                                                         \
-    if (!(h)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");                               \
-    BusyGuard guard_(h);                                                                                 \
-    if (!guard_.ok) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "handle is in use by another call");     \
-    HIP_TRY(h, hipSetDevice((h)->device))
+namespace {
 
 template <class T>
 int dalloc(gymnet_vecenv *h, T **p, size_t count) {
@@ -156,18 +64,32 @@ int dalloc(gymnet_vecenv *h, T **p, size_t count) {
     return GYMNET_OK;
 }
 
+// Host-boundary staging (actions in, row-major observations out, reset mask) is allocated on first use: a
+// device-resident consumer (bench.py, a GPU policy) never pays for it — at 2^27 CartPole lanes it is 2.6 GiB.
+int ensure_staging(gymnet_vecenv *h, bool actions, bool pack, bool mask) {
+    if (actions && !h->d_actions) ST_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)h->padded));
+    if (pack && !h->d_pack) ST_TRY(dalloc(h, &h->d_pack, (size_t)h->padded * h->desc->obs_dim));
+    if (mask && !h->d_mask) ST_TRY(dalloc(h, &h->d_mask, (size_t)h->padded));
+    return GYMNET_OK;
+}
+
+void destroy_graph(GraphEntry &g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr; g.graph = nullptr;
+}
+
 void drop_graphs(gymnet_vecenv *h) {
-    for (auto &g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    for (auto &g : h->graphs) destroy_graph(g);
     h->graphs.clear();
 }
 
 StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     StepArgs a{};
+    const bool alias = h->desc->alias;
     a.state = h->d_state;
-    a.obs = h->d_obs;
+    a.state_out = (h->double_buffer && alias) ? h->d_state_alt : h->d_state;
+    a.obs = (h->double_buffer && !alias) ? h->d_obs_alt : h->d_obs;
     a.action = d_actions;
     a.reward = h->d_reward;
     a.done = h->d_done;
@@ -189,10 +111,35 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     return a;
 }
 
+// after a step launch with GYMNET_FLAG_DOUBLE_BUFFER: what was written becomes current
+void swap_buffers(gymnet_vecenv *h) {
+    if (!h->double_buffer) return;
+    if (h->desc->alias) { std::swap(h->d_state, h->d_state_alt); h->d_obs = h->d_state; h->d_obs_alt = h->d_state_alt; }
+    else std::swap(h->d_obs, h->d_obs_alt);
+    h->cur ^= 1;
+}
+
+// gathers the sharded done list of the most recent step into one compact list (stream-ordered, non-blocking)
+int compact_done(gymnet_vecenv *h, int32_t *d_out, uint32_t *d_count) {
+    const uint32_t *counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
+    HIP_TRY(h, launch_compact_done(counts, h->d_done_list, h->done_cap, d_out, d_count, h->stream));
+    return GYMNET_OK;
+}
+
+void recompute_extras(gymnet_vecenv *h) {
+    h->extras = (h->cfg.flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS)) != 0 ||
+                h->d_lane_seed != nullptr;
+}
+
+}  // namespace
+
+namespace gymnet {
+
 // one vector step = one kernel launch; bumps the host mirrors of the device-side counters
 int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
     StepArgs a = make_step_args(h, d_actions);
     HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
+    swap_buffers(h);
     h->last_cparity = a.cparity;
     h->tick += 1;
     h->tslot ^= 1;
@@ -223,6 +170,20 @@ int write_tick(gymnet_vecenv *h) {
     return GYMNET_OK;
 }
 
+// queues the copies of the current results to host buffers (any may be NULL) without the closing synchronize;
+// only for handles without the host-mapped small-batch path
+int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+    const EnvDesc &d = *h->desc;
+    if (obs_out) {
+        ST_TRY(ensure_staging(h, false, true, false));
+        HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (reward_out) HIP_TRY(h, hipMemcpyAsync(reward_out, h->d_reward, (size_t)h->n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (done_out) HIP_TRY(h, hipMemcpyAsync(done_out, h->d_done, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    return GYMNET_OK;
+}
+
 // copy the current results to host buffers (any may be NULL); blocks
 int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
@@ -236,12 +197,7 @@ int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_
         if (done_out) std::memcpy(done_out, h->hm_done, (size_t)h->n);
         return GYMNET_OK;
     }
-    if (obs_out) {
-        HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    }
-    if (reward_out) HIP_TRY(h, hipMemcpyAsync(reward_out, h->d_reward, (size_t)h->n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (done_out) HIP_TRY(h, hipMemcpyAsync(done_out, h->d_done, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    ST_TRY(queue_copy_out(h, obs_out, reward_out, done_out));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
 }
@@ -262,45 +218,99 @@ int validate_staged_actions(gymnet_vecenv *h, const void *d_actions) {
 }
 
 // stages host actions; *d_use receives the device-visible pointer the step kernel should read
-int stage_host_actions(gymnet_vecenv *h, const void *actions, const void **d_use) {
+int stage_host_actions(gymnet_vecenv *h, const void *actions, const void **d_use, bool validate_now) {
     if (!actions) return fail(h, GYMNET_ERR_INVALID_ARG, "actions is null");
     if (h->hm_block) {   // the previous step's kernel has completed (every host-boundary call ends with a sync)
         std::memcpy(h->hm_actions, actions, (size_t)h->n * 4);
         *d_use = h->hm_actions;
     } else {
+        ST_TRY(ensure_staging(h, true, false, false));
         HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
         *d_use = h->d_actions;
     }
-    return validate_staged_actions(h, *d_use);
+    return validate_now ? validate_staged_actions(h, *d_use) : GYMNET_OK;
 }
 
-// gathers the sharded done list of the most recent step into one compact list (stream-ordered, non-blocking)
-int compact_done(gymnet_vecenv *h, int32_t *d_out, uint32_t *d_count) {
-    const uint32_t *counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
-    HIP_TRY(h, launch_compact_done(counts, h->d_done_list, h->done_cap, d_out, d_count, h->stream));
+}  // namespace gymnet
+
+namespace gymnet {
+
+// `steps` vector steps, one kernel launch each (caller has ENTERed the handle)
+int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode) {
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
+    if (h->lcfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be 16-byte aligned");
+    const char *base = static_cast<const char *>(d_actions);
+    auto slice = [&](int64_t t) -> const void * { return base + (size_t)((t % ring) * action_stride) * 4; };
+    if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && !h->desc->box_action && steps > 0) {
+        // Discrete.Contains over every slice the rollout will read, before any state changes (one readback)
+        HIP_TRY(h, hipMemsetAsync(h->d_bad, 0, sizeof(uint32_t), h->stream));
+        for (int64_t k = 0; k < (steps < ring ? steps : ring); ++k)
+            HIP_TRY(h, launch_validate_discrete(static_cast<const int32_t *>(slice(k)), h->n, h->desc->action_n, h->d_bad, h->stream));
+        uint32_t bad = 0;
+        HIP_TRY(h, hipMemcpyAsync(&bad, h->d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (bad) return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%u lane-steps, Discrete(%d))", bad, h->desc->action_n);
+    }
+
+    // graph length: a multiple of `ring` (so every replay starts at slice 0) and even (so the double-buffered
+    // device tick, done-count halves and observation buffers are the same at every replay)
+    int64_t glen = (ring % 2 == 0) ? ring : 2 * ring;
+    int64_t t = 0;
+    // Graph replay only pays while the host launch path (~3.5 us per launch) is the bottleneck: measured on
+    // MI355X, replay beats eager launches up to ~2^18 CartPole lanes (2.6 vs 5.7 us/step at 2^16), ties at 2^19
+    // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
+    const bool launch_bound = (size_t)h->n * (size_t)h->desc->algorithmic_bytes < ((size_t)24 << 20);
+    const char *force = std::getenv("GYMNET_GRAPH");
+    const bool use_graph = graph_mode >= 0 ? graph_mode != 0 : (force ? std::atoi(force) != 0 : launch_bound);
+    if (use_graph && glen <= 4096 && steps >= glen) {
+        const int parity = h->tslot, cparity = (int)(h->step_launches & 1u), cur = h->cur;
+        GraphEntry *ge = nullptr;
+        for (auto &g : h->graphs)
+            if (g.actions == d_actions && g.len == glen && g.stride == action_stride && g.ring == ring && g.parity == parity &&
+                g.cparity == cparity && g.cur == cur)
+                ge = &g;
+        if (!ge) {
+            const uint64_t tick0 = h->tick, sl0 = h->step_launches, ls0 = h->lane_steps;
+            const int slot0 = h->tslot, cur0 = h->cur, lcp0 = h->last_cparity;
+            HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            int st = GYMNET_OK;
+            for (int64_t k = 0; k < glen && st == GYMNET_OK; ++k) st = launch_one_step(h, slice(k));
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            // capturing launched nothing: rewind the host mirrors (glen is even, so the buffer pair is back where it was)
+            h->tick = tick0; h->step_launches = sl0; h->lane_steps = ls0; h->tslot = slot0; h->last_cparity = lcp0;
+            if (h->cur != cur0) swap_buffers(h);
+            if (st != GYMNET_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (e != hipSuccess) return fail(h, GYMNET_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            hipGraphExec_t exec = nullptr;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail(h, GYMNET_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+            if (h->graphs.size() >= kMaxGraphs) {   // a trainer that keeps reallocating its action buffer must not leak graphs
+                size_t lru = 0;
+                for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+                HIP_TRY(h, hipStreamSynchronize(h->stream));          // the evicted exec may still be running
+                destroy_graph(h->graphs[lru]);
+                h->graphs.erase(h->graphs.begin() + (long)lru);
+            }
+            h->graphs.push_back(GraphEntry{d_actions, glen, action_stride, ring, parity, cparity, cur, graph, exec, 0});
+            ge = &h->graphs.back();
+        }
+        ge->last_use = ++h->graph_clock;
+        for (; t + glen <= steps; t += glen) {
+            HIP_TRY(h, hipGraphLaunch(ge->exec, h->stream));
+            h->tick += (uint64_t)glen;
+            h->step_launches += (uint64_t)glen;
+            h->lane_steps += (uint64_t)glen * (uint64_t)h->n;
+            h->last_cparity = (int)((h->step_launches - 1) & 1u);
+        }
+    }
+    for (; t < steps; ++t) ST_TRY(launch_one_step(h, slice(t)));
     return GYMNET_OK;
 }
 
-void recompute_extras(gymnet_vecenv *h) {
-    h->extras = (h->cfg.flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS)) != 0 ||
-                h->d_lane_seed != nullptr;
-}
-
-// Nothing may throw across the C ABI: every entry point body runs inside this guard.
-template <class F>
-int guarded(F &&f) noexcept {
-    try {
-        return f();
-    } catch (const std::bad_alloc &) {
-        return GYMNET_ERR_OOM;
-    } catch (...) {
-        return GYMNET_ERR_HIP;
-    }
-}
-
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-}  // namespace
+}  // namespace gymnet
 
 extern "C" {
 
@@ -317,6 +327,7 @@ const char *gymnet_status_string(int status) {
         case GYMNET_ERR_ALREADY_STEPPING: return "already running an async step";
         case GYMNET_ERR_NOT_STEPPING: return "not running an async step";
         case GYMNET_ERR_UNSUPPORTED: return "unsupported for this environment / configuration";
+        case GYMNET_ERR_RCCL: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -360,6 +371,7 @@ int gymnet_env_describe(int env_id, gymnet_env_info *out) {
 int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     return guarded([&]() -> int {
     if (!h) return GYMNET_OK;
+    DeviceScope dev_scope;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
@@ -388,6 +400,10 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "GYMNET_FLAG_FINAL_OBS needs GYMNET_FLAG_AUTORESET");
     if (cfg->d_ext_obs && cfg->ext_obs_stride < cfg->num_envs)
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "ext_obs_stride %lld < num_envs", (long long)cfg->ext_obs_stride);
+    if (cfg->d_ext_obs_alt && (!cfg->d_ext_obs || !(cfg->flags & GYMNET_FLAG_DOUBLE_BUFFER)))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt needs d_ext_obs and GYMNET_FLAG_DOUBLE_BUFFER");
+    if (cfg->d_ext_obs_alt && cfg->d_ext_obs_alt == cfg->d_ext_obs)
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt must be a different buffer than d_ext_obs");
 
     int ndev = 0;
     int s = gymnet_device_count(&ndev);
@@ -402,7 +418,9 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     h->n = cfg->num_envs;
     h->seed = cfg->seed;
     h->autoreset = (cfg->flags & GYMNET_FLAG_AUTORESET) != 0;
+    h->double_buffer = (cfg->flags & GYMNET_FLAG_DOUBLE_BUFFER) != 0;
     const EnvDesc &d = *h->desc;
+    DeviceScope dev_scope;
 
 #define CREATE_TRY(expr)                      \
     do {                                      \
@@ -424,23 +442,27 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     else { CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
 
     const int64_t padded = (h->n + 63) / 64 * 64;   // every component array starts 256-byte aligned
+    h->padded = padded;
     if (cfg->d_ext_obs) {
         if (d.alias) { h->d_state = cfg->d_ext_obs; h->sstride = cfg->ext_obs_stride; h->d_obs = h->d_state; h->ostride = h->sstride; }
         else {
             h->d_obs = cfg->d_ext_obs; h->ostride = cfg->ext_obs_stride;
-            CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded; h->own_state = true;
+            CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded;
         }
     } else {
-        CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded; h->own_state = true;
+        CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded;
         if (d.alias) { h->d_obs = h->d_state; h->ostride = h->sstride; }
-        else { CREATE_TRY(dalloc(h, &h->d_obs, (size_t)padded * d.obs_dim)); h->ostride = padded; h->own_obs = true; }
+        else { CREATE_TRY(dalloc(h, &h->d_obs, (size_t)padded * d.obs_dim)); h->ostride = padded; }
+    }
+    if (h->double_buffer) {   // the second observation buffer (for aliasing envs: the second STATE buffer), same stride
+        float *alt = cfg->d_ext_obs_alt;
+        if (!alt) CREATE_TRY(dalloc(h, &alt, (size_t)h->ostride * d.obs_dim));
+        if (d.alias) { h->d_state_alt = alt; h->d_obs_alt = alt; } else { h->d_obs_alt = alt; }
     }
     CREATE_TRY(dalloc(h, &h->d_reward, (size_t)padded));
     CREATE_TRY(dalloc(h, &h->d_done, (size_t)padded));
-    CREATE_TRY(dalloc(h, &h->d_mask, (size_t)padded));
     CREATE_TRY(dalloc(h, &h->d_tick2, 2));
-    CREATE_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)padded));
-    CREATE_TRY(dalloc(h, &h->d_pack, (size_t)padded * d.obs_dim));
+    // d_actions / d_pack / d_mask (host-boundary staging) are allocated on first use: ensure_staging()
     CREATE_TRY(dalloc(h, &h->d_after_done, (size_t)kShards * kAfterStride));
     CREATE_TRY(dalloc(h, &h->d_bad, 1));
     if (h->n <= kSmallHostPath) {
@@ -480,6 +502,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     // defined start: zero state, reward, done; sbd = -1
     CREATE_HIP(hipMemsetAsync(h->d_state, 0, (size_t)h->sstride * (d.state_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
+    if (h->d_obs_alt) CREATE_HIP(hipMemsetAsync(h->d_obs_alt, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_reward, 0, (size_t)padded * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_done, 0, (size_t)padded, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_after_done, 0, (size_t)kShards * kAfterStride * sizeof(unsigned long long), h->stream));
@@ -488,7 +511,8 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     CREATE_TRY(write_tick(h));
 
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
-    const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0);
+    const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0) &&
+                          (!h->d_obs_alt || aligned16(h->d_obs_alt));
     // Launch policy, measured on MI355X with tools/probe_step.hip and bench.py (profiles/probe_r01.txt),
     // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
     //  - <= 24 MiB (2^19 CartPole lanes): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
@@ -520,7 +544,7 @@ int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed) {
     h->seed = seed;
     h->tick = 0;
     drop_graphs(h);   // the seed is a (frozen) kernel argument of captured launches
-    h->d_lane_seed = nullptr;   // back to one key for all lanes (the old array stays owned until destroy)
+    h->d_lane_seed = nullptr;   // back to one key for all lanes (d_lane_seed_buf is kept for the next Seed(int[]))
     recompute_extras(h);
     return write_tick(h);
     });
@@ -533,14 +557,16 @@ int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t co
     if (count != h->n)   // VecEnv.cs:49
         return fail(h, GYMNET_ERR_INVALID_ARG, "Number of seeds passed should be equals to number of environments (%lld != %lld)",
                     (long long)count, (long long)h->n);
-    uint64_t *p = nullptr;
-    ST_TRY(dalloc(h, &p, (size_t)h->n));
-    HIP_TRY(h, hipMemcpyAsync(p, seeds, (size_t)h->n * 8, hipMemcpyHostToDevice, h->stream));
-    h->d_lane_seed = p;
+    // one allocation, reused by every later Seed(int[]) (it used to grow by N*8 bytes per call); the stream is drained
+    // first so no launch still in flight reads the keys being overwritten
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->d_lane_seed_buf) ST_TRY(dalloc(h, &h->d_lane_seed_buf, (size_t)h->n));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_seed_buf, seeds, (size_t)h->n * 8, hipMemcpyHostToDevice, h->stream));
+    h->d_lane_seed = h->d_lane_seed_buf;
     recompute_extras(h);
     h->tick = 0;
     drop_graphs(h);
-    return write_tick(h);
+    return write_tick(h);   // synchronizes: `seeds` is the caller's again on return
     });
 }
 
@@ -554,6 +580,9 @@ int gymnet_vecenv_reset_device(gymnet_vecenv *h) {
 int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
     return guarded([&]() -> int {
     ENTER(h);
+    // with AUTORESET the step already re-drew every finished lane (its done flag stays set as the step's RESULT):
+    // resetting "the lanes whose done flag is set" again would discard the observation the step returned
+    if (!d_mask && h->autoreset) return GYMNET_OK;
     // own done flags: the reset kernel may read its mask from the very array it clears (each lane's flag is read
     // before the same thread clears it), so no snapshot copy is needed
     return launch_reset_lanes(h, d_mask ? d_mask : h->d_done);
@@ -571,7 +600,11 @@ int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out) {
 int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (mask) HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    if (!mask && h->autoreset) return copy_out(h, obs_out, nullptr, nullptr);   // no-op, see gymnet_vecenv_reset_where_device
+    if (mask) {
+        ST_TRY(ensure_staging(h, false, false, true));
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    }
     ST_TRY(launch_reset_lanes(h, mask ? h->d_mask : h->d_done));
     return copy_out(h, obs_out, nullptr, nullptr);
     });
@@ -582,7 +615,7 @@ int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, fl
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     const void *d_act = nullptr;
-    ST_TRY(stage_host_actions(h, actions, &d_act));
+    ST_TRY(stage_host_actions(h, actions, &d_act, true));
     ST_TRY(launch_one_step(h, d_act));
     return copy_out(h, obs_out, reward_out, done_out);
     });
@@ -593,6 +626,7 @@ int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_ou
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     const EnvDesc &d = *h->desc;
+    ST_TRY(ensure_staging(h, true, false, false));
     if (d.box_action) {   // IVecEnv.Step(int) on a Box space: the int is the (scalar) torque
         float f = (float)action;
         int32_t bits;
@@ -613,7 +647,7 @@ int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions) {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     const void *d_act = nullptr;
-    ST_TRY(stage_host_actions(h, actions, &d_act));
+    ST_TRY(stage_host_actions(h, actions, &d_act, true));
     ST_TRY(launch_one_step(h, d_act));
     h->async_pending = true;
     return GYMNET_OK;
@@ -649,66 +683,7 @@ int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions) {
 int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
-    if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
-    if (h->lcfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0))
-        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be 16-byte aligned");
-    const char *base = static_cast<const char *>(d_actions);
-    auto slice = [&](int64_t t) -> const void * { return base + (size_t)((t % ring) * action_stride) * 4; };
-    if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && !h->desc->box_action && steps > 0) {
-        // Discrete.Contains over every slice the rollout will read, before any state changes (one readback)
-        HIP_TRY(h, hipMemsetAsync(h->d_bad, 0, sizeof(uint32_t), h->stream));
-        for (int64_t k = 0; k < (steps < ring ? steps : ring); ++k)
-            HIP_TRY(h, launch_validate_discrete(static_cast<const int32_t *>(slice(k)), h->n, h->desc->action_n, h->d_bad, h->stream));
-        uint32_t bad = 0;
-        HIP_TRY(h, hipMemcpyAsync(&bad, h->d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (bad) return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%u lane-steps, Discrete(%d))", bad, h->desc->action_n);
-    }
-
-    // graph length: a multiple of `ring` (so every replay starts at slice 0) and even (so the
-    // double-buffered device tick / done-count parities are the same at every replay)
-    int64_t glen = (ring % 2 == 0) ? ring : 2 * ring;
-    int64_t t = 0;
-    // Graph replay only pays while the host launch path (~3.5 us per launch) is the bottleneck: measured on
-    // MI355X, replay beats eager launches up to ~2^18 CartPole lanes (2.6 vs 5.7 us/step at 2^16), ties at 2^19
-    // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
-    const bool launch_bound = (size_t)h->n * (size_t)h->desc->algorithmic_bytes < ((size_t)24 << 20);
-    const char *force = std::getenv("GYMNET_GRAPH");
-    const bool use_graph = force ? std::atoi(force) != 0 : launch_bound;
-    if (use_graph && glen <= 4096 && steps >= glen) {
-        const int parity = h->tslot, cparity = (int)(h->step_launches & 1u);
-        GraphEntry *ge = nullptr;
-        for (auto &g : h->graphs)
-            if (g.actions == d_actions && g.len == glen && g.stride == action_stride && g.ring == ring && g.parity == parity && g.cparity == cparity)
-                ge = &g;
-        if (!ge) {
-            const uint64_t tick0 = h->tick, sl0 = h->step_launches, ls0 = h->lane_steps;
-            const int slot0 = h->tslot;
-            HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            int s = GYMNET_OK;
-            for (int64_t k = 0; k < glen && s == GYMNET_OK; ++k) s = launch_one_step(h, slice(k));
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamEndCapture(h->stream, &graph);
-            h->tick = tick0; h->step_launches = sl0; h->lane_steps = ls0; h->tslot = slot0;   // capturing launched nothing
-            if (s != GYMNET_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
-            if (e != hipSuccess) return fail(h, GYMNET_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            hipGraphExec_t exec = nullptr;
-            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail(h, GYMNET_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-            h->graphs.push_back(GraphEntry{d_actions, glen, action_stride, ring, parity, cparity, graph, exec});
-            ge = &h->graphs.back();
-        }
-        for (; t + glen <= steps; t += glen) {
-            HIP_TRY(h, hipGraphLaunch(ge->exec, h->stream));
-            h->tick += (uint64_t)glen;
-            h->step_launches += (uint64_t)glen;
-            h->lane_steps += (uint64_t)glen * (uint64_t)h->n;
-            h->last_cparity = (int)((h->step_launches - 1) & 1u);
-        }
-    }
-    for (; t < steps; ++t) ST_TRY(launch_one_step(h, slice(t)));
-    return GYMNET_OK;
+    return rollout_steps(h, d_actions, steps, action_stride, ring);
     });
 }
 
@@ -730,6 +705,7 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     r.steps = steps; r.action_stride = action_stride; r.ring = ring;
     if (rec) { r.rec_obs = rec->d_obs; r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
     HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
+    swap_buffers(h);                     // DOUBLE_BUFFER: the launch read one buffer and wrote the other, once
     h->tick += (uint64_t)steps;
     h->tslot ^= 1;                       // one launch: it read one half of d_tick2 and wrote the other
     h->step_launches += 1;
@@ -768,6 +744,18 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     out->d_episode_return = h->d_ep_ret; out->d_episode_length = h->d_ep_len;
     out->d_finished_return = h->d_fin_ret; out->d_finished_length = h->d_fin_len;
     out->stream = h->stream;
+    out->obs_buffer = h->cur;
+    out->d_obs_alt = h->d_obs_alt;
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt) {
+    return guarded([&]() -> int {
+    if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
+    if (vec) *vec = h->lcfg.vec;
+    if (block) *block = h->lcfg.block;
+    if (nt) *nt = h->lcfg.nt;
     return GYMNET_OK;
     });
 }
@@ -907,6 +895,7 @@ int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
     ENTER(h);
     if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
     if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
+    ST_TRY(ensure_staging(h, false, true, false));
     HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_final_obs, h->n, h->d_pack, h->n, h->stream));
     HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -918,8 +907,39 @@ int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int6
                                   uint64_t seed, uint64_t lane_offset, uint64_t tick) {
     return guarded([&]() -> int {
     if (!d_out || count < 0 || n <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/n");
+    DeviceScope dev_scope;
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, launch_sample_discrete(d_out, count, n, start, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_sample_discrete_masked_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
+                                         const uint8_t *d_mask, int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    return guarded([&]() -> int {
+    if (!d_out || count < 0 || n <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/n");
+    if (!d_mask) return gymnet_sample_discrete_device(device, stream, d_out, count, n, start, seed, lane_offset, tick);   // Discrete.cs:27
+    if (mask_stride != 0 && mask_stride < n) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "mask_stride must be 0 (shared row) or >= n");
+    DeviceScope dev_scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_sample_discrete_masked(d_out, count, n, start, d_mask, mask_stride, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_sample_actions_masked_device(gymnet_vecenv *h, int32_t *d_actions, const uint8_t *d_mask, int64_t mask_stride,
+                                               uint64_t seed, uint64_t tick) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    const EnvDesc &d = *h->desc;
+    if (d.box_action) return fail(h, GYMNET_ERR_UNSUPPORTED, "Box.sample cannot be provided a mask.");   // Box.cs:70
+    if (d_mask && mask_stride != 0 && mask_stride < d.action_n) return fail(h, GYMNET_ERR_INVALID_ARG, "mask_stride must be 0 (shared row) or >= n");
+    if (!d_mask)
+        HIP_TRY(h, launch_sample_discrete(d_actions, h->n, d.action_n, 0, seed, (uint64_t)h->cfg.lane_offset, tick, h->stream));
+    else
+        HIP_TRY(h, launch_sample_discrete_masked(d_actions, h->n, d.action_n, 0, d_mask, mask_stride, seed,
+                                                 (uint64_t)h->cfg.lane_offset, tick, h->stream));
     return GYMNET_OK;
     });
 }
@@ -928,6 +948,7 @@ int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t cou
                              uint64_t seed, uint64_t lane_offset, uint64_t tick) {
     return guarded([&]() -> int {
     if (!d_out || count < 0 || !(low <= high)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/count/bounds");
+    DeviceScope dev_scope;
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, launch_sample_box(d_out, count, low, high, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
     return GYMNET_OK;
@@ -966,6 +987,10 @@ int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t s
     return guarded([&]() -> int {
     if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
     if (!actions_out) return fail(h, GYMNET_ERR_INVALID_ARG, "actions_out is null");
+    {
+        ENTER(h);
+        ST_TRY(ensure_staging(h, true, false, false));
+    }
     ST_TRY(gymnet_vecenv_sample_actions_device(h, h->d_actions, seed, tick));
     ENTER(h);
     HIP_TRY(h, hipMemcpyAsync(actions_out, h->d_actions, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));

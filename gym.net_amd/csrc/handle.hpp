@@ -1,0 +1,164 @@
+// handle.hpp — what a gymnet_vecenv handle IS, plus the host-side helpers capi.hip and group.hip share.
+// Internal to the library: nothing here crosses the C ABI (include/gymnet_amd.h is the boundary).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gymnet_amd.h"
+#include "kernels.hpp"
+
+namespace gymnet {
+
+struct EnvDesc {
+    const char *name;
+    int state_dim, obs_dim;
+    bool alias, box_action, has_sbd;
+    int action_n;
+    float action_low, action_high;
+    float obs_low[8], obs_high[8];
+    float reward_low, reward_high;
+    int algorithmic_bytes;
+};
+extern const EnvDesc kEnvs[4];
+
+struct GraphEntry {
+    const void *actions;
+    int64_t len, stride, ring;
+    int parity, cparity, cur;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    uint64_t last_use;
+};
+constexpr size_t kMaxGraphs = 8;       // per handle; least-recently-used entry is destroyed beyond this
+
+}  // namespace gymnet
+
+struct gymnet_vecenv {
+    gymnet_config cfg{};
+    const gymnet::EnvDesc *desc = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, padded = 0, sstride = 0, ostride = 0;
+    bool autoreset = false, extras = false;
+    // d_state / d_obs always point at the CURRENT (most recently written) buffers; with GYMNET_FLAG_DOUBLE_BUFFER
+    // d_state_alt / d_obs_alt are what the next step writes, and the pairs swap after every step launch.
+    float *d_state = nullptr, *d_obs = nullptr;
+    float *d_state_alt = nullptr, *d_obs_alt = nullptr;
+    bool double_buffer = false;
+    int cur = 0;                   // index of the buffer d_obs points at (0 = the one reset first wrote)
+    float *d_reward = nullptr;
+    uint8_t *d_done = nullptr, *d_mask = nullptr;
+    int32_t *d_sbd = nullptr;
+    uint64_t *d_tick2 = nullptr;
+    void *d_actions = nullptr;     // staging for host-path / broadcast actions   (allocated on first use)
+    float *d_pack = nullptr;       // row-major obs staging                       (allocated on first use)
+    float *d_final_obs = nullptr;
+    int32_t *d_done_list = nullptr, *d_done_compact = nullptr;    // sharded segments / compact list (on demand)
+    uint32_t *d_done_count2 = nullptr, *d_done_total = nullptr;
+    int64_t done_cap = 0;
+    float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
+    int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
+    uint64_t *d_lane_seed = nullptr;       // active per-lane keys (NULL = one key for all lanes)
+    uint64_t *d_lane_seed_buf = nullptr;   // the one allocation Seed(int[]) reuses
+    unsigned long long *d_after_done = nullptr;
+    // small batches (n <= kSmallHostPath): host-mapped staging, so a host-boundary step is 2 kernel launches + 1 sync
+    void *hm_actions = nullptr;    // pinned + mapped: the step kernel reads the actions straight from it
+    float *hm_obs = nullptr, *hm_reward = nullptr;
+    uint8_t *hm_done = nullptr;
+    void *hm_block = nullptr;
+    uint32_t *d_bad = nullptr;
+    uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
+    int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
+    int last_cparity = -1;
+    bool async_pending = false;
+    std::atomic<bool> busy{false};
+    gymnet::LaunchCfg lcfg{4, 256, 0};
+    std::vector<gymnet::GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    std::vector<void *> owned;     // device allocations to free
+    std::string err;
+};
+
+namespace gymnet {
+
+// sets the thread-local last-error message (and the handle's), returns `status`
+int fail(gymnet_vecenv *h, int status, const char *fmt, ...);
+void set_last_error(const char *msg);
+
+// Restores the caller's current HIP device when it goes out of scope (a process that holds handles on several GPUs —
+// or shares the runtime with torch — must not find its current device changed by a library call).
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct BusyGuard {
+    gymnet_vecenv *h;
+    bool ok;
+    explicit BusyGuard(gymnet_vecenv *hh) : h(hh), ok(false) {
+        bool expect = false;
+        ok = h->busy.compare_exchange_strong(expect, true);
+    }
+    ~BusyGuard() { if (ok) h->busy.store(false); }
+};
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return ::gymnet::fail(h, e_ == hipErrorOutOfMemory ? GYMNET_ERR_OOM : GYMNET_ERR_HIP, "%s failed: %s", #expr, \
+                                  hipGetErrorString(e_));                                             \
+    } while (0)
+
+#define ST_TRY(expr)                  \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ != GYMNET_OK) return s_; \
+    } while (0)
+
+// Entry-point prologue: null check, single-caller guard, switch to the handle's device (restored on return).
+#define ENTER(h)                                                                                                   \
+    if (!(h)) return ::gymnet::fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");                                \
+    ::gymnet::BusyGuard guard_(h);                                                                                 \
+    if (!guard_.ok) return ::gymnet::fail(h, GYMNET_ERR_ALREADY_STEPPING, "handle is in use by another call");      \
+    ::gymnet::DeviceScope dev_scope_;                                                                              \
+    HIP_TRY(h, hipSetDevice((h)->device))
+
+// Nothing may throw across the C ABI: every entry point body runs inside this guard.
+template <class F>
+int guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        set_last_error("host allocation failed (std::bad_alloc)");
+        return GYMNET_ERR_OOM;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return GYMNET_ERR_HIP;
+    } catch (...) {
+        set_last_error("unexpected C++ exception inside the library");
+        return GYMNET_ERR_HIP;
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- helpers that assume the caller already ENTERed the handle (device set, busy flag held) ----------------------
+int launch_one_step(gymnet_vecenv *h, const void *d_actions);       // one vector step = one kernel launch
+int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask);    // NULL = all lanes
+int stage_host_actions(gymnet_vecenv *h, const void *actions, const void **d_use, bool validate_now);
+int validate_staged_actions(gymnet_vecenv *h, const void *d_actions);
+int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);   // no final sync (large-batch path)
+int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);         // blocks
+// graph_mode: -1 = by batch size (replay only while launch-bound), 0 = eager launches, 1 = always replay a captured graph
+int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode = -1);
+int write_tick(gymnet_vecenv *h);
+
+}  // namespace gymnet

@@ -277,7 +277,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick);
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
         for (int k = 0; k < O; ++k) store_f32<VEC, NT_SS, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
@@ -412,7 +412,7 @@ __device__ __forceinline__ void rollout_body(const StepArgs &a, const RolloutArg
     }
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, false, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) store_f32<VEC, false, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
         for (int k = 0; k < O; ++k) store_f32<VEC, false, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
@@ -567,20 +567,42 @@ __global__ __launch_bounds__(256) void sample_discrete_kernel(int32_t *__restric
                                                               uint64_t tick) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
     out[i] = start + (int32_t)__umulhi(r.w[0], (uint32_t)nvals);
+}
+
+// Discrete.Sample(mask) (Discrete.cs:18-26): valid = nonzero(mask == 1); any -> start + valid[choice(len(valid))], none -> start.
+// choice(k) = hi32(w0 * k) with the same Philox word the unmasked draw uses.  One row of `nvals` mask bytes per lane
+// (mask_stride = nvals) or one shared row (mask_stride = 0).
+__global__ __launch_bounds__(256) void sample_discrete_masked_kernel(int32_t *__restrict__ out, int64_t n, int32_t nvals, int32_t start,
+                                                                     const uint8_t *__restrict__ mask, int64_t mask_stride,
+                                                                     uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *m = mask + i * mask_stride;
+    int32_t valid = 0;
+    for (int32_t k = 0; k < nvals; ++k) valid += m[k] == 1 ? 1 : 0;
+    int32_t pick = 0;
+    if (valid > 0) {
+        const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
+        int32_t want = (int32_t)__umulhi(r.w[0], (uint32_t)valid);     // index into the list of valid actions
+        for (int32_t k = 0; k < nvals; ++k) {
+            if (m[k] == 1) { if (want == 0) { pick = k; break; } --want; }
+        }
+    }
+    out[i] = start + pick;
 }
 
 // The caller's epsilon-greedy composer (examples/.../PlaySessions/TrainingPlaySession.cs:46-52), batched:
 //   if (Random.NextDouble() <= epsilon) action = ActionSpace.Sample(); else action = policy action
-// Lane i uses Philox(seed, (lane_offset + i, tick)): word 0 is the sampled action (identical to sample_discrete_kernel),
+// Lane i uses the ACTION stream of Philox(seed, (lane_offset + i, tick)): word 0 is the sampled action (identical to sample_discrete_kernel),
 // word 1 the 24-bit uniform that is compared with epsilon.
 __global__ __launch_bounds__(256) void compose_discrete_kernel(const int32_t *__restrict__ policy, int32_t *__restrict__ out,
                                                                int64_t n, int32_t nvals, float epsilon, uint64_t seed,
                                                                uint64_t lane_offset, uint64_t tick) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
     const bool explore = u01_24(r.w[1]) <= epsilon;
     out[i] = explore ? (int32_t)__umulhi(r.w[0], (uint32_t)nvals) : policy[i];
 }
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out
                                                          uint64_t seed, uint64_t lane_offset, uint64_t tick) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PhiloxWords r = lane_words(seed, lane_offset + (uint64_t)i, tick);
+    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
     const bool blo = low > -INFINITY, bhi = high < INFINITY;     // Box.CheckBounded (Box.cs:53-58)
     const float u = u01_24(r.w[0]);
     float v;
@@ -606,6 +628,26 @@ __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out
         v = 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
     }
     out[i] = v;
+}
+
+// Direct (full-mesh) all-gather of observations, push form: this member's slice [D][N/G] is stored into
+// the same offset of every peer's replica buffer.  blockIdx.y selects the peer, so all peers' links carry traffic
+// concurrently (xGMI is point-to-point: 7 links x ~153 GB/s, one per peer); each lane moves 16 bytes per trip.  Plain stores:
+// the bytes have to leave this GPU anyway, and the kernel boundary is the release the peers' next kernels acquire against.
+__global__ __launch_bounds__(256) void push_obs_kernel(const PushArgs a) {
+    float *__restrict__ dst = a.dst[blockIdx.y];
+    const float *__restrict__ src = a.src;
+    const int64_t nvec = a.count >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec_ok) {
+        for (int64_t v = i; v < nvec; v += stride)
+            reinterpret_cast<f32x4 *>(dst)[v] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + v);
+        for (int64_t k = (nvec << 2) + i; k < a.count; k += stride) dst[k] = src[k];
+    } else {
+        for (int64_t k = i; k < a.count; k += stride) dst[k] = src[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,6 +791,24 @@ hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(sample_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, seed,
                        lane_offset, tick);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_discrete_masked(int32_t *out, int64_t n, int32_t nvals, int32_t start, const uint8_t *mask,
+                                         int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_discrete_masked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, mask,
+                       mask_stride, seed, lane_offset, tick);
+    return hipGetLastError();
+}
+
+hipError_t launch_push_obs(const PushArgs &a, hipStream_t st) {
+    if (a.count <= 0 || a.npeers <= 0) return hipSuccess;
+    // enough workgroups per peer to keep a link busy, few enough that G-1 peers do not oversubscribe the chip
+    int64_t per_peer = (a.count / 4 + 255) / 256;
+    if (per_peer > 256) per_peer = 256;
+    if (per_peer < 1) per_peer = 1;
+    hipLaunchKernelGGL(push_obs_kernel, dim3((unsigned)per_peer, (unsigned)a.npeers), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

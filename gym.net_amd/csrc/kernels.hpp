@@ -7,7 +7,9 @@ namespace gymnet {
 
 // Everything one vector-step launch needs.  Passed by value (kernarg segment).
 struct StepArgs {
-    float *state;            // [S][state_stride]  structure-of-arrays, one env per lane
+    float *state;            // [S][state_stride]  structure-of-arrays, one env per lane (read)
+    float *state_out;        // where the new state is written: == state, or the OTHER half of a double-buffered pair
+                             // (GYMNET_FLAG_DOUBLE_BUFFER: step t+1 writes B while a gather of A is still in flight)
     float *obs;              // [O][obs_stride]    (unused when the env's observation aliases its state)
     const void *action;      // int32[n] (Discrete) or float32[n] (Box)
     float *reward;           // [n]
@@ -82,6 +84,14 @@ hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int6
 hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
                                   uint64_t lane_offset, uint64_t tick, hipStream_t st);
+// Discrete.Sample(mask) (Discrete.cs:18-26): mask uint8 [n][nvals] (mask_stride = nvals) or one row for every lane (mask_stride = 0)
+hipError_t launch_sample_discrete_masked(int32_t *out, int64_t n, int32_t nvals, int32_t start, const uint8_t *mask,
+                                         int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick, hipStream_t st);
+// Direct all-gather, push form: copies `count` floats from src to the same offset inside each of `npeers` peer buffers
+// (peer-mapped device memory reached over xGMI, or buffers on the same device for logical shards).
+constexpr int kMaxPeers = 15;
+struct PushArgs { const float *src; float *dst[kMaxPeers]; int64_t count; int32_t npeers; };
+hipError_t launch_push_obs(const PushArgs &a, hipStream_t st);
 hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t n, int32_t nvals, float epsilon, uint64_t seed,
                                    uint64_t lane_offset, uint64_t tick, hipStream_t st);
 hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,

@@ -32,6 +32,14 @@ __host__ __device__ __forceinline__ PhiloxWords lane_words(uint64_t seed, uint64
                          (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// Independent streams by purpose: reset draws use the caller's key unchanged (stream 0); space sampling and the
+// epsilon-greedy composer (action stream) XOR a constant into it, so ActionSpace.Sample() with the env's own (seed, tick) can
+// never replay the words that produced a reset state.
+constexpr uint64_t kStreamReset = 0ull, kStreamAction = 0x9E3779B97F4A7C15ull;
+__host__ __device__ __forceinline__ PhiloxWords stream_words(uint64_t stream, uint64_t seed, uint64_t lane, uint64_t tick) {
+    return lane_words(seed ^ stream, lane, tick);
+}
+
 // 24-bit uniform in [0,1): exactly representable in binary32
 __host__ __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 

@@ -55,13 +55,18 @@ class ShardPlan:
         return r, global_lane - self.offset(r)
 
 
-def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream):
+def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream, ext_obs_alt=None):
     return VectorEnv(env, num_envs, device=device, seed=seed, auto_reset=auto_reset, lane_offset=lane_offset,
-                     ext_obs=ext_obs, ext_obs_stride=ext_obs_stride, stream=stream)
+                     ext_obs=ext_obs, ext_obs_stride=ext_obs_stride, stream=stream,
+                     double_buffer=ext_obs_alt is not None, ext_obs_alt=ext_obs_alt)
 
 
 class ShardedVectorEnv:
     """This rank's shard of a global batch + the optional observation all-gather.
+
+    overlap=True double-buffers the observation arrays (GYMNET_FLAG_DOUBLE_BUFFER): there are two gather buffers, step
+    t+1 writes the other one while the all-gather of step t's buffer is still in flight on a side stream, so a
+    consumer that wants every rank to see all observations pays max(step, gather) per step instead of step + gather.
 
     local_env_factory exists so the host-side sharding logic can be exercised without a GPU (the
     CPU tests inject an oracle-backed stand-in); the default — and the only thing the product ever
@@ -69,7 +74,8 @@ class ShardedVectorEnv:
     """
 
     def __init__(self, env, global_num_envs, rank=None, world_size=None, device=None, seed=0, auto_reset=True,
-                 gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None, force_gather=False):
+                 gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None, force_gather=False,
+                 overlap=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -81,6 +87,7 @@ class ShardedVectorEnv:
         self.rank, self.world_size = int(rank), int(world_size)
         self.plan = ShardPlan(global_num_envs, world_size)
         self.gather_obs = bool(gather_obs) and (world_size > 1 or force_gather)
+        self.overlap = bool(overlap) and self.gather_obs
         if gather_obs and not self.plan.even:
             raise ValueError("global_num_envs must be a multiple of world_size to all-gather observations")
         self.lane_offset, self.local_num_envs = self.plan.shard(self.rank)
@@ -94,35 +101,89 @@ class ShardedVectorEnv:
         env_id = _capi.ENV_IDS[env] if isinstance(env, str) else int(env)
         self.obs_dim = {0: 4, 1: 3, 2: 2, 3: 6}[env_id]
         n_local = self.local_num_envs
-        # rank-major gather buffer [G][D][N/G]; this rank's observation arrays ARE slice [rank]
-        self.obs_all = torch.zeros((self.world_size, self.obs_dim, n_local), dtype=torch.float32, device=self.tensor_device)
+        # rank-major gather buffers [B][G][D][N/G] (B = 2 when overlapping); this rank's observation arrays ARE slice
+        # [b][rank] of whichever buffer b the last step wrote
+        nbuf = 2 if self.overlap else 1
+        self.obs_bufs = torch.zeros((nbuf, self.world_size, self.obs_dim, n_local), dtype=torch.float32, device=self.tensor_device)
+        self.obs_all = self.obs_bufs[0]
         stream = None
-        if self.tensor_device.type == "cuda":
+        self._cuda = self.tensor_device.type == "cuda"
+        if self._cuda:
             stream = torch.cuda.current_stream(self.tensor_device).cuda_stream
-        self.local = factory(env, n_local, self.lane_offset, seed, auto_reset, self.obs_all[self.rank].data_ptr(),
-                             n_local, device, stream)
+        kw = {"ext_obs_alt": self.obs_bufs[1][self.rank].data_ptr()} if self.overlap else {}
+        self.local = factory(env, n_local, self.lane_offset, seed, auto_reset, self.obs_bufs[0][self.rank].data_ptr(),
+                             n_local, device, stream, **kw)
         self._work = None
+        self._cur = 0                      # buffer the latest observation lives in (mirror of the handle's obs_buffer)
+        self._last = 0                     # buffer gathered last
+        self._pending = [None, None]       # per buffer: an unfinished overlapped gather (cuda event or Work)
+        self._gstream = torch.cuda.Stream(self.tensor_device) if (self._cuda and self.overlap) else None
 
     # ---- stepping -----------------------------------------------------------------------------------
+    def _current_buffer(self):
+        if not self.overlap:
+            return 0
+        if hasattr(self.local, "ObsBufferIndex"):
+            self._cur = self.local.ObsBufferIndex()
+        return self._cur
+
+    def _finish(self, b):
+        """Orders later work on the main stream behind the overlapped gather of buffer b."""
+        p = self._pending[b]
+        if p is None:
+            return
+        if self._cuda:
+            self._torch.cuda.current_stream(self.tensor_device).wait_event(p)
+        else:
+            p.wait()
+        self._pending[b] = None
+
     def ResetDevice(self):
+        self._finish(self._current_buffer())               # a reset rewrites the current buffer in place
         self.local.ResetDevice()
 
     def StepDevice(self, d_actions):
         """Step this rank's lanes; d_actions: this rank's slice of the global action array (device pointer/tensor)."""
+        if self.overlap:
+            self._finish(self._current_buffer() ^ 1)       # the step writes the OTHER buffer: its last gather must be done
+            self._cur ^= 1
         self.local.StepDevice(d_actions)
 
-    def AllGatherObs(self, async_op=False):
-        """Everyone's observations into obs_all [G][D][N/G].  The send buffer is obs_all[rank] itself (in place)."""
+    def AllGatherObs(self, async_op=False, overlap=False):
+        """Everyone's observations into the current gather buffer [G][D][N/G].  The send buffer is slice [rank] of that
+        buffer itself (in place).  overlap=True (needs overlap=True at construction): the collective runs on a side
+        stream and only WaitGather() / the step that will overwrite this buffer wait for it."""
         if not self.gather_obs:
             return None
-        dist, t = self._dist, self.obs_all
+        dist, b = self._dist, self._current_buffer()
+        t = self.obs_bufs[b]
         flat_out = t.view(-1)
         flat_in = t[self.rank].reshape(-1)
-        try:
-            work = dist.all_gather_into_tensor(flat_out, flat_in, group=self.group, async_op=async_op)
-        except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
-            outs = [t[r].view(-1) for r in range(self.world_size)]
-            work = dist.all_gather(outs, flat_in.clone(), group=self.group, async_op=async_op)
+        self._last = b
+
+        def gather(async_flag):
+            try:
+                return dist.all_gather_into_tensor(flat_out, flat_in, group=self.group, async_op=async_flag)
+            except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
+                outs = [t[r].view(-1) for r in range(self.world_size)]
+                return dist.all_gather(outs, flat_in.clone(), group=self.group, async_op=async_flag)
+
+        if overlap and self.overlap:
+            if self._cuda:
+                tc = self._torch.cuda
+                ev = tc.Event()
+                ev.record(tc.current_stream(self.tensor_device))
+                with tc.stream(self._gstream):
+                    self._gstream.wait_event(ev)              # the step that produced this buffer
+                    work = gather(True)
+                    work.wait()                               # side stream waits for RCCL's stream; the host does not
+                    done = tc.Event()
+                    done.record(self._gstream)
+                self._pending[b] = done
+            else:
+                self._pending[b] = gather(True)
+            return None
+        work = gather(async_op)
         self._work = work if async_op else None
         return work
 
@@ -131,13 +192,22 @@ class ShardedVectorEnv:
             self._work.wait()
             self._work = None
 
+    def WaitGather(self):
+        """After this, work queued on the main stream sees the last gathered buffer complete."""
+        self.Wait()
+        self._finish(self._last)
+
     def GlobalObs(self):
         """[N, D]-shaped logical view of the gathered observations as a [G, D, N/G] tensor:
-        global lane g = r * (N/G) + i  ->  obs_all[r, :, i]."""
-        return self.obs_all
+        global lane g = r * (N/G) + i  ->  GlobalObs()[r, :, i].  (The buffer gathered last.)"""
+        return self.obs_bufs[self._last]
+
+    LastGatheredObs = GlobalObs
 
     def Sync(self):
         self.local.Sync()
+        if self._gstream is not None:
+            self._gstream.synchronize()
 
     def Close(self):
         self.local.Close()

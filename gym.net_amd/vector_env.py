@@ -78,19 +78,36 @@ class PendingStep:
 class VectorEnv:
     def __init__(self, env="CartPole-v1", num_envs=1, device=0, seed=0, auto_reset=False,
                  validate_actions=False, done_list=False, episode_stats=False, final_obs=False,
-                 lane_offset=0, stream=None, ext_obs=None, ext_obs_stride=0, max_episode_steps=0):
+                 lane_offset=0, stream=None, ext_obs=None, ext_obs_stride=0, max_episode_steps=0,
+                 double_buffer=False, ext_obs_alt=None):
         env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
         self._lib = capi.load_library()
         self._info = capi.env_describe(env_id)
         flags = ((capi.FLAG_AUTORESET if auto_reset else 0) | (capi.FLAG_VALIDATE_ACTIONS if validate_actions else 0)
                  | (capi.FLAG_DONE_LIST if done_list else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0)
-                 | (capi.FLAG_FINAL_OBS if final_obs else 0))
+                 | (capi.FLAG_FINAL_OBS if final_obs else 0) | (capi.FLAG_DOUBLE_BUFFER if double_buffer else 0))
         cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=env_id, num_envs=int(num_envs),
                           lane_offset=int(lane_offset), device=int(device), flags=flags,
                           seed=int(seed) & 0xFFFFFFFFFFFFFFFF, stream=_ptr(stream), d_ext_obs=_ptr(ext_obs),
-                          ext_obs_stride=int(ext_obs_stride), max_episode_steps=int(max_episode_steps), reserved=0)
+                          ext_obs_stride=int(ext_obs_stride), max_episode_steps=int(max_episode_steps), reserved=0,
+                          d_ext_obs_alt=_ptr(ext_obs_alt))
         self._h = C.c_void_p()
+        self._owns_handle = True
         capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
+        self._describe(env_id, num_envs, auto_reset)
+
+    @classmethod
+    def _borrow(cls, handle, env_id, num_envs, auto_reset):
+        """A VectorEnv view over a handle somebody else owns (a member of a GroupVectorEnv): Close() does not destroy it."""
+        self = cls.__new__(cls)
+        self._lib = capi.load_library()
+        self._info = capi.env_describe(env_id)
+        self._h = handle
+        self._owns_handle = False
+        self._describe(env_id, num_envs, auto_reset)
+        return self
+
+    def _describe(self, env_id, num_envs, auto_reset):
         i = self._info
         self.EnvId = env_id
         self.Name = i.name.decode()
@@ -113,7 +130,8 @@ class VectorEnv:
     # ---- lifecycle ------------------------------------------------------------------------------
     def Close(self):                                                                 # VecEnvWrapper.cs:26-30
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.gymnet_vecenv_destroy(self._h)
+            if self._owns_handle:
+                self._lib.gymnet_vecenv_destroy(self._h)
             self._h = C.c_void_p()
 
     Dispose = Close                                                                  # Env.cs:38-40
@@ -166,6 +184,8 @@ class VectorEnv:
         """IVecEnv.Step(int action) (IVecEnv.cs:15, VecEnvWrapper.cs:22-24) broadcasts ONE scalar action;
         an array-like gives one action per lane (extension)."""
         obs, rew, done = self._outs()
+        if isinstance(action, enum.Enum):                                            # Env<TAction>.Step(TAction), Env.cs:43-53
+            action = int(action.value)
         if isinstance(action, (int, np.integer)) and not isinstance(action, (bool, np.bool_)):
             capi.check(self._lib.gymnet_vecenv_step_broadcast(self._h, int(action), _host(obs), _host(rew), _host(done)))
         else:
@@ -174,6 +194,8 @@ class VectorEnv:
         return BatchStep(obs, rew, done.astype(bool), None)
 
     def StepAsync(self, action):                                                     # VecEnv.cs:63-65
+        if isinstance(action, enum.Enum):
+            action = int(action.value)
         if isinstance(action, (int, np.integer)):
             action = np.full(self.NumberOfEnvironments, action, dtype=self._adtype)
         a = self._actions(action)
@@ -221,6 +243,12 @@ class VectorEnv:
     def SampleActionsDevice(self, d_actions, seed=0, tick=0):
         capi.check(self._lib.gymnet_vecenv_sample_actions_device(self._h, _ptr(d_actions), int(seed), int(tick)))
 
+    def SampleActionsMaskedDevice(self, d_actions, d_mask, per_lane=True, seed=0, tick=0):
+        """ActionSpace.Sample(mask) for every lane (Discrete.cs:18-26): d_mask uint8 [N][n] (per_lane) or one shared row [n]."""
+        stride = self.ActionSpace.N if per_lane else 0
+        capi.check(self._lib.gymnet_vecenv_sample_actions_masked_device(self._h, _ptr(d_actions), _ptr(d_mask), int(stride),
+                                                                        int(seed), int(tick)))
+
     def ComposeActionsDevice(self, d_policy_actions, epsilon, d_actions_out, seed=0, tick=0):
         """Batched epsilon-greedy ComposeAction (TrainingPlaySession.cs:46-52): with probability epsilon the lane's
         action is ActionSpace.Sample(), otherwise the policy's."""
@@ -237,6 +265,16 @@ class VectorEnv:
         v = capi.DeviceView()
         capi.check(self._lib.gymnet_vecenv_device_view(self._h, C.byref(v)))
         return v
+
+    def ObsBufferIndex(self):
+        """GYMNET_FLAG_DOUBLE_BUFFER: which of the two observation buffers holds the latest observation (0 / 1)."""
+        return int(self.DeviceView().obs_buffer)
+
+    def LaunchPolicy(self):
+        """The step kernel's launch configuration the handle chose."""
+        v, b, nt = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(self._lib.gymnet_vecenv_launch_policy(self._h, C.byref(v), C.byref(b), C.byref(nt)))
+        return {"envs_per_thread": v.value, "block": b.value, "nontemporal_mask": nt.value}
 
     # ---- state access / bookkeeping -----------------------------------------------------------------
     def GetState(self):
@@ -323,6 +361,126 @@ class VectorEnv:
     reset, step, seed, close = Reset, Step, Seed, Close
 
 
+class GroupVectorEnv:
+    """One process driving G GPUs (or G logical members on one GPU): the ctypes mirror of gymnet_group_* — what a
+    P/Invoking C# host uses instead of torch.distributed.  Member m owns global lanes [m*N/G, (m+1)*N/G); every member
+    keeps a replica [G][D][N/G] of all observations on its GPU, completed by AllGatherObs() (hand-written direct push over
+    peer-mapped memory, or RCCL).  Same VecEnv surface for the host-boundary path (Reset / Step over the whole batch)."""
+
+    def __init__(self, env="CartPole-v1", global_num_envs=1, num_members=1, devices=None, seed=0, auto_reset=False,
+                 gather="direct", overlap=False, validate_actions=False, max_episode_steps=0, episode_stats=False):
+        env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
+        self._lib = capi.load_library()
+        flags = ((capi.FLAG_AUTORESET if auto_reset else 0) | (capi.FLAG_VALIDATE_ACTIONS if validate_actions else 0)
+                 | (capi.FLAG_DOUBLE_BUFFER if overlap else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0))
+        mode = {"none": capi.GATHER_NONE, "direct": capi.GATHER_DIRECT, "rccl": capi.GATHER_RCCL}[gather] if isinstance(gather, str) else int(gather)
+        devs = None
+        if devices is not None:
+            if len(devices) != num_members:
+                raise ValueError("len(devices) must equal num_members")
+            devs = (C.c_int32 * num_members)(*[int(d) for d in devices])
+        cfg = capi.GroupConfig(struct_size=C.sizeof(capi.GroupConfig), env_id=env_id, global_num_envs=int(global_num_envs),
+                               num_members=int(num_members), flags=flags, seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+                               devices=devs, gather=mode, max_episode_steps=int(max_episode_steps))
+        self._g = C.c_void_p()
+        capi.check(self._lib.gymnet_group_create(C.byref(cfg), C.byref(self._g)))
+        info = capi.env_describe(env_id)
+        self.NumberOfEnvironments = int(global_num_envs)
+        self.NumMembers = int(num_members)
+        self.LanesPerMember = int(global_num_envs) // int(num_members)
+        self.ObsDim = int(info.obs_dim)
+        self.Overlap = bool(overlap)
+        self.Members = []
+        for m in range(self.NumMembers):
+            h = C.c_void_p()
+            capi.check(self._lib.gymnet_group_member(self._g, m, C.byref(h)))
+            self.Members.append(VectorEnv._borrow(h, env_id, self.LanesPerMember, auto_reset))
+        self.ActionSpace, self.ObservationSpace = self.Members[0].ActionSpace, self.Members[0].ObservationSpace
+        self.Metadata, self.RewardRange = self.Members[0].Metadata, self.Members[0].RewardRange
+        self._adtype = self.Members[0]._adtype
+        self.Environments = []
+
+    def Close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            for m in self.Members:
+                m.Close()
+            self._lib.gymnet_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    Dispose = Close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.Close()
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+    def Seed(self, seed):
+        capi.check(self._lib.gymnet_group_seed(self._g, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    # host-boundary path over the whole batch
+    def Reset(self):
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        capi.check(self._lib.gymnet_group_reset(self._g, _host(obs)))
+        return obs
+
+    def Step(self, action):
+        n = self.NumberOfEnvironments
+        if isinstance(action, enum.Enum):
+            action = int(action.value)
+        if isinstance(action, (int, np.integer)) and not isinstance(action, (bool, np.bool_)):
+            action = np.full(n, action, dtype=self._adtype)                          # IVecEnv.Step(int): broadcast
+        a = np.ascontiguousarray(np.asarray(action).reshape(-1).astype(self._adtype, copy=False))
+        if a.shape[0] != n:
+            raise ValueError("Number of actions passed should be equals to number of environments")
+        obs, rew, done = np.empty((n, self.ObsDim), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
+        capi.check(self._lib.gymnet_group_step(self._g, _host(a), _host(obs), _host(rew), _host(done)))
+        return BatchStep(obs, rew, done.astype(bool), None)
+
+    # device-resident path
+    def ResetDevice(self):
+        capi.check(self._lib.gymnet_group_reset_device(self._g))
+
+    def _ptrs(self, d_actions):
+        if len(d_actions) != self.NumMembers:
+            raise ValueError("one device pointer per member")
+        return (C.c_void_p * self.NumMembers)(*[_ptr(p) for p in d_actions])
+
+    def StepDevice(self, d_actions):
+        capi.check(self._lib.gymnet_group_step_device(self._g, self._ptrs(d_actions)))
+
+    def RolloutDevice(self, d_actions, steps, action_stride, ring):
+        capi.check(self._lib.gymnet_group_rollout_device(self._g, self._ptrs(d_actions), int(steps), int(action_stride), int(ring)))
+
+    def AllGatherObs(self):
+        capi.check(self._lib.gymnet_group_allgather_obs(self._g))
+
+    def WaitGather(self):
+        capi.check(self._lib.gymnet_group_wait_gather(self._g))
+
+    def GlobalObsPtr(self, member):
+        p = C.c_void_p()
+        capi.check(self._lib.gymnet_group_global_obs(self._g, int(member), C.byref(p)))
+        return p.value
+
+    def ReadReplica(self, member):
+        """Member's replica of all observations on the host, [G, D, N/G] (waits for the last gather)."""
+        out = np.empty((self.NumMembers, self.ObsDim, self.LanesPerMember), np.float32)
+        capi.check(self._lib.gymnet_group_read_replica(self._g, int(member), _host(out)))
+        return out
+
+    def Sync(self):
+        capi.check(self._lib.gymnet_group_sync(self._g))
+
+    reset, step, seed, close = Reset, Step, Seed, Close
+
+
 class DummyVecEnv(VectorEnv):
     """DummyVecEnv (src/Gym/Envs/DummyVecEnv.cs:2-4): a VecEnv around ONE environment — here a 1-lane batch."""
 
@@ -354,7 +512,9 @@ class GpuEnv:
         a = np.array([action], dtype=self._v._adtype)
         return self._v.Step(a)[0]
 
-    def StepAsync(self, action):                                                     # Env.cs:23-25
+    def StepAsync(self, action):                                                     # Env.cs:23-25, 48-50
+        if isinstance(action, enum.Enum):
+            action = int(action.value)
         a = np.array([action], dtype=self._v._adtype)
         p = self._v.StepAsync(a)
 
@@ -397,5 +557,5 @@ class AcrobotEnv(GpuEnv):
     ENV = "Acrobot-v1"
 
 
-__all__ = ["VectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
+__all__ = ["VectorEnv", "GroupVectorEnv", "DummyVecEnv", "BatchStep", "PendingStep", "GpuEnv", "CartPoleEnv", "PendulumEnv", "MountainCarEnv",
            "AcrobotEnv", "AlreadySteppingError", "NotSteppingError"]

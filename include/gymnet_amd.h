@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GYMNET_ABI_VERSION 1
+#define GYMNET_ABI_VERSION 2   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups */
 
 typedef enum gymnet_status {
     GYMNET_OK = 0,
@@ -56,7 +56,8 @@ typedef enum gymnet_status {
     GYMNET_ERR_NO_DEVICE = -5,       /* no usable AMD GPU: the engine has NO CPU fallback */
     GYMNET_ERR_ALREADY_STEPPING = -6,/* AlreadySteppingError (src/Gym/Exceptions/AlreadySteppingError.cs:8-10) */
     GYMNET_ERR_NOT_STEPPING = -7,    /* NotSteppingError (src/Gym/Exceptions/NotSteppingError.cs:4-6) */
-    GYMNET_ERR_UNSUPPORTED = -8
+    GYMNET_ERR_UNSUPPORTED = -8,
+    GYMNET_ERR_RCCL = -9             /* an RCCL call failed, or librccl could not be loaded (group gather mode RCCL) */
 } gymnet_status;
 
 typedef enum gymnet_env_id {
@@ -73,6 +74,11 @@ typedef enum gymnet_env_id {
 #define GYMNET_FLAG_DONE_LIST        0x04u /* emit the compacted list of lanes that finished in the last step */
 #define GYMNET_FLAG_EPISODE_STATS    0x08u /* per-lane episode return / length bookkeeping (BasePlaySession.cs:58-69) */
 #define GYMNET_FLAG_FINAL_OBS        0x10u /* with AUTORESET: keep the terminal observation of lanes that finished */
+#define GYMNET_FLAG_DOUBLE_BUFFER    0x20u /* two observation buffers, written alternately: the step launched after buffer A was
+                                              written reads A and writes B, so a consumer (an all-gather of A over xGMI, a policy
+                                              reading A) may still be using A while the next step runs.  For envs whose observation
+                                              IS the state (CartPole, MountainCar) the state ping-pongs with it.  Which buffer holds
+                                              the latest observation: gymnet_device_view.obs_buffer / d_obs */
 
 typedef struct gymnet_vecenv gymnet_vecenv;   /* opaque handle: one batch ("VectorEnv") on one GPU */
 
@@ -93,6 +99,8 @@ typedef struct gymnet_config {
     int32_t  max_episode_steps; /* EXTENSION (the reference has no time limit): >0 truncates episodes;
                                    requires GYMNET_FLAG_EPISODE_STATS; done byte gets bit 1 (value 2) for truncation */
     int32_t  reserved;
+    float   *d_ext_obs_alt;     /* with GYMNET_FLAG_DOUBLE_BUFFER and d_ext_obs: the caller's SECOND observation buffer (same
+                                   stride), e.g. this rank's slice of a second all-gather buffer.  NULL = library allocates */
 } gymnet_config;
 
 typedef struct gymnet_env_info {
@@ -125,6 +133,9 @@ typedef struct gymnet_device_view {
     float   *d_episode_return; int32_t *d_episode_length;     /* running, EPISODE_STATS only */
     float   *d_finished_return; int32_t *d_finished_length;   /* last finished episode per lane */
     void    *stream;           /* hipStream_t all of the handle's work is ordered on */
+    int32_t  obs_buffer;       /* GYMNET_FLAG_DOUBLE_BUFFER: index (0 / 1) of the buffer d_obs points at = the latest observation */
+    int32_t  reserved;
+    float   *d_obs_alt;        /* GYMNET_FLAG_DOUBLE_BUFFER: the other buffer = what the NEXT step will write; else NULL */
 } gymnet_device_view;
 
 typedef struct gymnet_counters {
@@ -163,7 +174,9 @@ int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t co
  * state ~ U(-0.05,0.05)^4.  obs_out: host [num_envs, obs_dim] or NULL. */
 int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out);
 /* The caller's `if (done) Reset()` (README.md:36-40), batched: resets exactly the lanes with mask[i] != 0;
- * mask == NULL resets the lanes whose last returned done flag is set.  obs_out as above (all lanes). */
+ * mask == NULL resets the lanes whose last returned done flag is set.  obs_out as above (all lanes).
+ * With GYMNET_FLAG_AUTORESET the step itself already re-drew every finished lane, so mask == NULL is a NO-OP that only
+ * returns the current observations (it used to draw those lanes a second time); an explicit mask still resets. */
 int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out);
 /* EXTENSION of IVecEnv.Step (per-lane actions): N x CartPoleEnv.Step (CartPoleEnv.cs:137-186).
  * actions: host int32[num_envs] (Discrete) or float32[num_envs] (Box).  Outputs may each be NULL.  Blocks until
@@ -207,6 +220,9 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
 int gymnet_vecenv_sync(gymnet_vecenv *h);
 int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
+/* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): envs per thread (1 / 4),
+ * threads per workgroup, non-temporal stream mask (0 / 12 / 15). */
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt);
 
 /* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
 /* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */
@@ -233,10 +249,16 @@ int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_
 int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out);
 
 /* ---- batched space sampling (the step BEFORE the path: ActionSpace.Sample(), TrainingPlaySession.cs:46-49) -- */
-/* Discrete.Sample() without mask (Discrete.cs:17-28): start + randint(0, n).  Element i = start + hi32(w0 * n),
- * w0 = word 0 of Philox(key = seed, counter = (lane_offset + i, tick)). */
+/* All sampling below draws from the ACTION stream: Philox key = seed ^ 0x9E3779B97F4A7C15, so ActionSpace.Sample() called
+ * with an env's own (seed, tick) never replays the words of that env's reset draws (key = seed).
+ * Discrete.Sample() without mask (Discrete.cs:17-28): start + randint(0, n).  Element i = start + hi32(w0 * n),
+ * w0 = word 0 of Philox(action key, counter = (lane_offset + i, tick)). */
 int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
                                   uint64_t seed, uint64_t lane_offset, uint64_t tick);
+/* Discrete.Sample(mask) (Discrete.cs:18-26): valid = {k : mask[k] == 1}; none -> start, else start + valid[hi32(w0 * |valid|)].
+ * d_mask: device uint8, one row of n bytes per element (mask_stride = n) or ONE row shared by all elements (mask_stride = 0). */
+int gymnet_sample_discrete_masked_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
+                                         const uint8_t *d_mask, int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick);
 /* Box.Sample() (Box.cs:69-90), the reference's four regimes per element: bounded -> uniform(low, high);
  * low only -> low + Exp(1); high only -> high + Exp(1) (sic, Box.cs:84); unbounded -> Normal(0.5, 1) (sic, Box.cs:82).
  * low = -INFINITY / high = +INFINITY select the regime. */
@@ -245,6 +267,10 @@ int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t cou
 /* ActionSpace.Sample() for every lane of a handle into d_actions (int32 / float32 [num_envs]). */
 int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick);
 int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick);
+/* ActionSpace.Sample(mask) for every lane of a handle (Discrete action spaces only; Box.Sample(mask) throws in the
+ * reference, Box.cs:70 -> GYMNET_ERR_UNSUPPORTED). */
+int gymnet_vecenv_sample_actions_masked_device(gymnet_vecenv *h, int32_t *d_actions, const uint8_t *d_mask, int64_t mask_stride,
+                                               uint64_t seed, uint64_t tick);
 /* The caller's epsilon-greedy composer, batched (examples/ReinforcementLearning/ReinforcementLearning/PlaySessions/
  * TrainingPlaySession.cs:46-52: `if (Random.NextDouble() <= _epsilon) return ActionSpace.Sample(); return policy action`).
  * Lane i: u = 24-bit uniform from Philox word 1 of (seed, (global lane, tick)); out[i] = (u <= epsilon) ? the
@@ -252,6 +278,58 @@ int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t s
  * Discrete action spaces only. */
 int gymnet_vecenv_compose_actions_device(gymnet_vecenv *h, const int32_t *d_policy_actions, float epsilon, int32_t *d_actions_out,
                                          uint64_t seed, uint64_t tick);
+
+/* ---- multi-GPU group: ONE process (e.g. a C# host) driving G members, one per GPU ----------------------------
+ * The reference has no multi-device code; what shards is the independence of VecEnvWrapper's map (VecEnvWrapper.cs:22-24).
+ * Member m owns the contiguous global lanes [m*N/G, (m+1)*N/G) (reset draws keyed by GLOBAL lane id: results do not depend
+ * on G).  Every member keeps a replica of the whole batch's observations on its own GPU, rank-major [G][obs_dim][N/G]; the
+ * member's live observation arrays ARE slice [m] of its replica (zero-copy send side).  gymnet_group_allgather_obs completes
+ * the replicas:
+ *   DIRECT  hand-written full-mesh push: each member stores its slice into the G-1 peers' replicas through peer-mapped
+ *           memory, one peer per xGMI link, all links concurrently (~110 us for 16 MiB at 8 GPUs vs ~770 us for a ring);
+ *   RCCL    ncclAllGather (in place) on per-member communicators (ncclCommInitAll); needs G distinct devices.
+ * With GYMNET_FLAG_DOUBLE_BUFFER the gather runs on per-member side streams and overlaps the next step.
+ * All calls are stream-ordered and non-blocking unless they take host buffers. */
+typedef struct gymnet_group gymnet_group;
+typedef enum gymnet_gather_mode { GYMNET_GATHER_NONE = 0, GYMNET_GATHER_DIRECT = 1, GYMNET_GATHER_RCCL = 2 } gymnet_gather_mode;
+
+typedef struct gymnet_group_config {
+    uint32_t struct_size;       /* = sizeof(gymnet_group_config) */
+    int32_t  env_id;
+    int64_t  global_num_envs;   /* N: lanes of the whole batch; a multiple of num_members */
+    int32_t  num_members;       /* G, 1..16 */
+    uint32_t flags;             /* GYMNET_FLAG_* for every member */
+    uint64_t seed;
+    const int32_t *devices;     /* [G] HIP device ordinal per member; NULL = 0..G-1.  An ordinal may repeat (several logical
+                                   members on one GPU — how a 1-GPU box tests the path); RCCL needs distinct ordinals */
+    int32_t  gather;            /* gymnet_gather_mode */
+    int32_t  max_episode_steps;
+} gymnet_group_config;
+
+int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out);
+int gymnet_group_destroy(gymnet_group *g);
+int gymnet_group_size(gymnet_group *g, int32_t *num_members, int64_t *lanes_per_member);
+/* The member's handle (borrowed: destroyed with the group).  Everything gymnet_vecenv_* offers works on it. */
+int gymnet_group_member(gymnet_group *g, int32_t member, gymnet_vecenv **out);
+int gymnet_group_seed(gymnet_group *g, uint64_t seed);                        /* VecEnv.Seed(int), VecEnv.cs:44-46 */
+int gymnet_group_reset_device(gymnet_group *g);                               /* VecEnv.Reset() on every member */
+/* One vector step of the whole batch = one kernel launch per member.  d_actions[m]: pointer ON member m's device to that
+ * member's N/G actions. */
+int gymnet_group_step_device(gymnet_group *g, const void *const *d_actions);
+/* `steps` vector steps per member (gymnet_vecenv_rollout_device on each, launches interleaved across members). */
+int gymnet_group_rollout_device(gymnet_group *g, const void *const *d_actions, int64_t steps, int64_t action_stride, int64_t ring);
+/* Completes every member's replica with the observations of the most recent step / reset.  Work queued on a member's stream
+ * after gymnet_group_wait_gather (or, without DOUBLE_BUFFER, after this call) sees all G slices. */
+int gymnet_group_allgather_obs(gymnet_group *g);
+int gymnet_group_wait_gather(gymnet_group *g);
+/* Member m's replica that was gathered last: device float [G][obs_dim][N/G] on m's GPU. */
+int gymnet_group_global_obs(gymnet_group *g, int32_t member, float **d_obs_all);
+/* The same replica copied to the host, float [G][obs_dim][N/G]; waits for the last gather and blocks. */
+int gymnet_group_read_replica(gymnet_group *g, int32_t member, float *replica_out);
+int gymnet_group_sync(gymnet_group *g);
+/* Host-boundary forms over the whole batch (NDArray-shaped: obs [N, obs_dim], reward [N], done [N]; any may be NULL). */
+int gymnet_group_reset(gymnet_group *g, float *obs_out);
+int gymnet_group_step(gymnet_group *g, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out);
 
 #ifdef __cplusplus
 }

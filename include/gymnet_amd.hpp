@@ -16,6 +16,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gymnet_amd.h"
@@ -146,15 +147,17 @@ public:
     VectorEnv(gymnet_env_id env, int64_t num_envs, int device = 0, uint64_t seed = 0, uint32_t flags = 0,
               int64_t lane_offset = 0, void *stream = nullptr) {
         check(gymnet_env_describe((int)env, &info_));
-        gymnet_config cfg{};
-        cfg.struct_size = sizeof cfg; cfg.env_id = (int)env; cfg.num_envs = num_envs; cfg.lane_offset = lane_offset;
-        cfg.device = device; cfg.flags = flags; cfg.seed = seed; cfg.stream = stream;
-        check(gymnet_vecenv_create(&cfg, &h_));
-        n_ = num_envs;
+        // everything that can throw is built BEFORE the native handle exists: a constructor that throws runs no
+        // destructor, so an allocation failing after gymnet_vecenv_create would leak the handle
         if (info_.action_is_box) action_box_ = std::make_unique<Box>(info_.action_low, info_.action_high, 1);
         else action_discrete_ = std::make_unique<Discrete>(info_.action_n);
         observation_space_ = std::make_unique<Box>(std::vector<float>(info_.obs_low, info_.obs_low + info_.obs_dim),
                                                    std::vector<float>(info_.obs_high, info_.obs_high + info_.obs_dim));
+        gymnet_config cfg{};
+        cfg.struct_size = sizeof cfg; cfg.env_id = (int)env; cfg.num_envs = num_envs; cfg.lane_offset = lane_offset;
+        cfg.device = device; cfg.flags = flags; cfg.seed = seed; cfg.stream = stream;
+        n_ = num_envs;
+        check(gymnet_vecenv_create(&cfg, &h_));
     }
     VectorEnv(const VectorEnv &) = delete;
     VectorEnv &operator=(const VectorEnv &) = delete;
@@ -260,6 +263,9 @@ public:
     explicit CartPoleEnv(int device = 0, uint64_t seed = 0) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed) {}
     std::vector<float> Reset() { return v_.Reset(); }                           // CartPoleEnv.cs:63-67
     gymnet::Step Step(int action) { return v_.Step(std::vector<int32_t>{action})[0]; }   // CartPoleEnv.cs:137-186
+    /// Env<TAction>.Step(TAction) where TAction : Enum (Env.cs:43-53): the enum's integer value is the discrete action
+    template <class TAction, std::enable_if_t<std::is_enum<TAction>::value, int> = 0>
+    gymnet::Step Step(TAction action) { return Step(static_cast<int>(action)); }
     void Seed(int seed) { v_.Seed((uint64_t)seed); }                            // CartPoleEnv.cs:196-198
     void CloseEnvironment() { v_.Close(); }                                     // CartPoleEnv.cs:189-194
     Discrete &ActionSpace() { return *v_.ActionSpaceDiscrete(); }

@@ -54,6 +54,7 @@ def lib():
     L.ref_reset_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u32p]
     L.ref_cartpole_reset_batch_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p, C.c_int64]
     L.ref_discrete_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _i32p, C.c_int64]
+    L.ref_discrete_sample_masked_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _u8p, C.c_int64, _i32p, C.c_int64]
     L.ref_compose_discrete_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64]
     L.ref_box_uniform_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _f32p, C.c_int64]
     L.ref_pendulum_step_f64.argtypes = [_f64p, C.c_double, _f64p, C.POINTER(C.c_double)]
@@ -134,6 +135,15 @@ def cartpole_reset(seed, lane0, tick, n):
 def discrete_sample(seed, lane0, tick, nvals, start, count):
     out = np.zeros(count, dtype=np.int32)
     lib().ref_discrete_sample_batch(seed, lane0, tick, nvals, start, out, count)
+    return out
+
+
+def discrete_sample_masked(seed, lane0, tick, nvals, start, mask, count):
+    """Discrete.Sample(mask): mask uint8 [count, nvals] (per lane) or [nvals] (shared row)."""
+    mask = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+    stride = nvals if mask.ndim == 2 else 0
+    out = np.zeros(count, dtype=np.int32)
+    lib().ref_discrete_sample_masked_batch(seed, lane0, tick, nvals, start, mask.reshape(-1), stride, out, count)
     return out
 
 

@@ -239,13 +239,40 @@ void ref_cartpole_reset_batch_f32(uint64_t seed, uint64_t lane0, uint64_t tick, 
     }
 }
 
+/* Space sampling draws from the engine's ACTION stream: the same counter (lane, tick) but key = seed ^ 0x9E3779B97F4A7C15,
+ * so ActionSpace.Sample() with an env's own (seed, tick) can never replay the words of that env's reset draw (key = seed). */
+#define REF_ACTION_STREAM 0x9E3779B97F4A7C15ull
+void ref_action_words(uint64_t seed, uint64_t lane, uint64_t tick, uint32_t out[4]) {
+    ref_reset_words(seed ^ REF_ACTION_STREAM, lane, tick, out);
+}
+
 /* Discrete.Sample() — src/Gym/Spaces/Discrete.cs:17-28 (no mask): Start + randint(0, N).
- * Engine semantics: Philox word 0 of counter (lane, tick), key = seed; value = start + hi32(w*n)
+ * Engine semantics: word 0 of the action stream at counter (lane, tick); value = start + hi32(w*n)
  * (Lemire multiply-shift; exact-uniform when n is a power of two). */
 int32_t ref_discrete_sample(uint64_t seed, uint64_t lane, uint64_t tick, int32_t n, int32_t start) {
     uint32_t w[4];
-    ref_reset_words(seed, lane, tick, w);
+    ref_action_words(seed, lane, tick, w);
     return start + (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32);
+}
+
+/* Discrete.Sample(mask) — Discrete.cs:18-26: bmask = (mask == 1); any -> Start + choice(nonzero(bmask)); none -> Start.
+ * Engine semantics: choice(k) = hi32(w0 * k) with the word the unmasked draw uses.  mask: one row of n bytes per lane
+ * (mask_stride = n) or one shared row (mask_stride = 0). */
+void ref_discrete_sample_masked_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, int32_t start,
+                                      const uint8_t *mask, int64_t mask_stride, int32_t *out, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) {
+        const uint8_t *m = mask + i * mask_stride;
+        int32_t valid = 0, pick = 0;
+        for (int32_t k = 0; k < n; ++k) valid += m[k] == 1;
+        if (valid > 0) {
+            uint32_t w[4];
+            ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
+            int32_t want = (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)valid) >> 32);
+            for (int32_t k = 0; k < n; ++k)
+                if (m[k] == 1) { if (want == 0) { pick = k; break; } --want; }
+        }
+        out[i] = start + pick;
+    }
 }
 
 void ref_discrete_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, int32_t start,
@@ -258,7 +285,7 @@ void ref_compose_discrete_batch(uint64_t seed, uint64_t lane0, uint64_t tick, in
                                 const int32_t *policy, int32_t *out, int64_t count) {
     for (int64_t i = 0; i < count; ++i) {
         uint32_t w[4];
-        ref_reset_words(seed, lane0 + (uint64_t)i, tick, w);
+        ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
         out[i] = u01_24(w[1]) <= epsilon ? (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32) : policy[i];
     }
 }
@@ -269,7 +296,7 @@ void ref_box_uniform_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, 
                                   float *out, int64_t count) {
     for (int64_t i = 0; i < count; ++i) {
         uint32_t w[4];
-        ref_reset_words(seed, lane0 + (uint64_t)i, tick, w);
+        ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
         out[i] = low + (high - low) * u01_24(w[0]);
     }
 }

@@ -11,11 +11,16 @@ from oracle import capi as oracle
 
 
 class OracleLocalEnv:
-    def __init__(self, env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream):
+    def __init__(self, env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream, ext_obs_alt=None):
         assert env in ("CartPole-v1", 0) and auto_reset
         self.n, self.lane_offset, self.seed, self.tick = num_envs, lane_offset, seed, 0
-        buf = (ctypes.c_float * (4 * ext_obs_stride)).from_address(int(ext_obs))
-        self.state = np.ctypeslib.as_array(buf).reshape(4, ext_obs_stride)[:, :num_envs]   # zero-copy view
+
+        def view(ptr):
+            buf = (ctypes.c_float * (4 * ext_obs_stride)).from_address(int(ptr))
+            return np.ctypeslib.as_array(buf).reshape(4, ext_obs_stride)[:, :num_envs]   # zero-copy view
+        self.state = view(ext_obs)
+        self.alt = view(ext_obs_alt) if ext_obs_alt is not None else None    # GYMNET_FLAG_DOUBLE_BUFFER twin
+        self.cur = 0
         self.reward = np.zeros(num_envs, np.float32)
         self.done = np.zeros(num_envs, np.uint8)
 
@@ -29,9 +34,17 @@ class OracleLocalEnv:
         fresh = oracle.cartpole_reset(self.seed, self.lane_offset, self.tick, self.n)
         fin = d.astype(bool)
         s[:, fin] = fresh[:, fin]
-        self.state[:] = s
+        if self.alt is not None:                 # ping-pong: write the other buffer, which becomes current
+            self.alt[:] = s
+            self.state, self.alt = self.alt, self.state
+            self.cur ^= 1
+        else:
+            self.state[:] = s
         self.reward[:], self.done[:] = r, d
         self.tick += 1
+
+    def ObsBufferIndex(self):
+        return self.cur
 
     def Sync(self):
         pass

@@ -91,6 +91,17 @@ static void gpu_tests() {
         CHECK(episodes > 10 && episodes < 80 && steps + episodes == 1000, "alternating-action episodes average ~37 steps");
         cp.CloseEnvironment();
     }
+    {   // Env<TAction>.Step(TAction) where TAction : Enum (Env.cs:43-53): an enum-typed action equals its integer value
+        enum class Push { Left = 0, Right = 1 };
+        gymnet::CartPoleEnv a(0, 7), b(0, 7);
+        auto oa = a.Reset(); auto ob = b.Reset();
+        CHECK(oa == ob, "same seed, same first observation");
+        for (int i = 0; i < 12; ++i) {
+            gymnet::Step sa = a.Step(i % 3 == 0 ? Push::Left : Push::Right), sb = b.Step(i % 3 == 0 ? 0 : 1);
+            CHECK(sa.Observation == sb.Observation && sa.Done == sb.Done && sa.Reward == sb.Reward, "enum-typed Step == int Step");
+        }
+        a.CloseEnvironment(); b.CloseEnvironment();
+    }
     {   // README.md:32-52 — the 100 000-iteration variant of the same loop (without Render / Thread.Sleep)
         gymnet::CartPoleEnv cp(0, 99);
         bool done = true;

@@ -1,0 +1,307 @@
+"""GPU tests of the multi-GPU surface on a 1-GPU box (BASELINE config 5):
+
+  - gymnet_group_* (one process, G members): G logical members on device 0, hand-written direct all-gather, with and
+    without the double-buffered overlap; every member's replica [G][D][N/G] must equal the single-handle batch bit for bit;
+  - GYMNET_FLAG_DOUBLE_BUFFER on a single handle: ping-ponged observation / state buffers give bit-identical results to the
+    in-place handle through one-launch steps, hipGraph replay and the fused rollout;
+  - ShardedVectorEnv on the HIP engine with RCCL at world size 1 (force_gather) and `python bench.py --gpus 2` started
+    plainly (it spawns its own ranks; on a 1-GPU box they share the GPU over gloo) — each in a child process;
+  - the small ABI debts of round 1: Seed(int[]) reuses its buffer, reset_where(NULL) under AUTORESET is a no-op,
+    the graph cache is bounded, library calls restore the caller's current device, masked Discrete.Sample on the device.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x5EED
+NACT = {"CartPole-v1": 2, "Pendulum-v1": 0, "MountainCar-v0": 3, "Acrobot-v1": 3}
+
+
+def _actions(rng, name, n):
+    if name == "Pendulum-v1":
+        return rng.uniform(-2, 2, n).astype(np.float32)
+    return rng.integers(0, NACT[name], n).astype(np.int32)
+
+
+def _replica(gpu_pkg, grp, member):
+    """Member's gathered replica as a numpy array [G, D, n]."""
+    return grp.ReadReplica(member)
+
+
+@pytest.mark.parametrize("name", ["CartPole-v1", "Acrobot-v1"])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_group_of_logical_members_direct_allgather_equals_single_handle(gpu_pkg, name, overlap):
+    import torch
+    G, n = 4, 3 * 1024                   # 768 lanes per member
+    rng = np.random.default_rng(5)
+    with gpu_pkg.GroupVectorEnv(name, n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="direct", overlap=overlap) as grp, \
+            gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as one:
+        assert grp.LanesPerMember == n // G and len(grp.Members) == G
+        nl = grp.LanesPerMember
+        one.Reset()
+        grp.ResetDevice()
+        grp.AllGatherObs(); grp.WaitGather(); grp.Sync()
+        want = one.Read().Observation                                   # [n, D]
+        for m in range(G):
+            rep = _replica(gpu_pkg, grp, m)                             # [G, D, nl]
+            assert np.array_equal(np.concatenate(list(rep), axis=1).T, want), ("reset", m)
+        acts = torch.empty(n, dtype=torch.float32 if name == "Pendulum-v1" else torch.int32, device="cuda")
+        for t in range(12):
+            a = _actions(rng, name, n)
+            acts.copy_(torch.from_numpy(a)); torch.cuda.synchronize()
+            grp.StepDevice([acts[m * nl:(m + 1) * nl] for m in range(G)])
+            grp.AllGatherObs()
+            if overlap and t % 2 == 0:                                  # leave the gather in flight across the next step
+                pending = (t, one.Step(a))
+                continue
+            grp.WaitGather(); grp.Sync()
+            out = one.Step(a)
+            for m in range(G):
+                rep = _replica(gpu_pkg, grp, m)
+                assert np.array_equal(np.concatenate(list(rep), axis=1).T, out.Observation), (t, m)
+            # reward / done of every member equal the corresponding slice
+            for m in (0, G - 1):
+                r = grp.Members[m].Read()
+                assert np.array_equal(r.Reward, out.Reward[m * nl:(m + 1) * nl]) and np.array_equal(r.Done, out.Done[m * nl:(m + 1) * nl])
+
+
+def test_group_host_boundary_step_equals_single_handle(gpu_pkg):
+    G, n = 2, 10_000                      # > 4096 lanes per member: the memcpy path; 5000 % 4 == 0
+    rng = np.random.default_rng(9)
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0, 0], seed=SEED, auto_reset=True, gather="none") as grp, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as one:
+        assert np.array_equal(grp.Reset(), one.Reset())
+        for t in range(20):
+            a = rng.integers(0, 2, n).astype(np.int32)
+            g, o = grp.Step(a), one.Step(a)
+            assert np.array_equal(g.Observation, o.Observation) and np.array_equal(g.Reward, o.Reward) and np.array_equal(g.Done, o.Done)
+        g, o = grp.Step(1), one.Step(1)                                   # IVecEnv.Step(int): scalar broadcast
+        assert np.array_equal(g.Observation, o.Observation)
+        with pytest.raises(NotImplementedError):
+            grp.AllGatherObs()                                            # created with gather="none"
+    # small members take the host-mapped latency path
+    with gpu_pkg.GroupVectorEnv("Pendulum-v1", 64, 4, devices=[0] * 4, seed=3, gather="direct") as grp, \
+            gpu_pkg.VectorEnv("Pendulum-v1", 64, seed=3) as one:
+        assert np.array_equal(grp.Reset(), one.Reset())
+        a = rng.uniform(-2, 2, 64).astype(np.float32)
+        g, o = grp.Step(a), one.Step(a)
+        assert np.array_equal(g.Observation, o.Observation) and np.array_equal(g.Reward, o.Reward)
+
+
+def test_group_argument_errors_and_rccl_variant(gpu_pkg):
+    with pytest.raises(ValueError):
+        gpu_pkg.GroupVectorEnv("CartPole-v1", 1001, 4, devices=[0] * 4)          # N not a multiple of G
+    with pytest.raises(ValueError):
+        gpu_pkg.GroupVectorEnv("CartPole-v1", 1024, 2, devices=[0, 99])         # no such device
+    with pytest.raises(NotImplementedError, match="distinct GPU"):
+        gpu_pkg.GroupVectorEnv("CartPole-v1", 1024, 2, devices=[0, 0], gather="rccl")
+    # one member on one GPU: the RCCL code path end to end (dlopen librccl, ncclCommInitAll, in-place ncclAllGather)
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", 4096, 1, devices=[0], seed=SEED, auto_reset=True, gather="rccl") as grp, \
+            gpu_pkg.VectorEnv("CartPole-v1", 4096, seed=SEED, auto_reset=True) as one:
+        grp.ResetDevice(); one.Reset()
+        grp.AllGatherObs(); grp.WaitGather(); grp.Sync()
+        rep = _replica(gpu_pkg, grp, 0)
+        assert np.array_equal(rep[0].T, one.Read().Observation)
+
+
+@pytest.mark.parametrize("name", ["CartPole-v1", "Pendulum-v1", "MountainCar-v0", "Acrobot-v1"])
+def test_double_buffered_handle_is_bit_identical_to_in_place(gpu_pkg, name, monkeypatch):
+    import torch
+    n, ring = 4096 + 64, 6
+    monkeypatch.setenv("GYMNET_GRAPH", "1")                   # rollout_device through hipGraph replay (even-length graph)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True, double_buffer=True) as db, \
+            gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as ip:
+        adt = torch.float32 if name == "Pendulum-v1" else torch.int32
+        acts = torch.empty((ring, n), dtype=adt, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(ring):
+            ip.SampleActionsDevice(acts[t], seed=2, tick=t)
+        ip.Sync()
+        assert db.ObsBufferIndex() == 0 and db.DeviceView().d_obs_alt and not ip.DeviceView().d_obs_alt
+        for e in (db, ip):
+            e.ResetDevice()
+            e.StepDevice(acts[0])                             # one eager step: buffer index flips
+        assert db.ObsBufferIndex() == 1 and ip.ObsBufferIndex() == 0
+        for e in (db, ip):
+            e.RolloutDevice(acts, 3 * ring, n, ring)          # graph replay (ring is even)
+            e.RolloutFusedDevice(acts, 7, n, ring)            # one launch = one flip
+            e.StepDevice(acts[1])
+            e.Sync()
+        a, b = db.Read(), ip.Read()
+        assert np.array_equal(a.Observation, b.Observation) and np.array_equal(a.Reward, b.Reward) and np.array_equal(a.Done, b.Done)
+        assert np.array_equal(db.GetState(), ip.GetState()) and db.Tick == ip.Tick
+        # host-boundary calls keep working on whichever buffer is current
+        s = ip.GetState()
+        db.SetState(s)
+        act = ip.SampleActions(seed=4, tick=0)
+        x, y = db.Step(act), ip.Step(act)
+        assert np.array_equal(x.Observation, y.Observation)
+    with pytest.raises(ValueError):                           # the second external buffer needs the flag and the first buffer
+        gpu_pkg.VectorEnv(name, 256, ext_obs_alt=torch.zeros(4096, device="cuda"))
+
+
+def test_round1_abi_debts(gpu_pkg, oracle):
+    import torch
+    n = 1 << 16
+    # (a) Seed(int[]) in a loop no longer grows device memory (it used to hipMalloc N*8 bytes per call)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=1, auto_reset=True) as env:
+        seeds = np.arange(n, dtype=np.int64)
+        env.Seed(seeds); env.Reset()
+        free0 = torch.cuda.mem_get_info()[0]
+        for k in range(40):
+            env.Seed(seeds + k)
+        env.Sync()
+        assert free0 - torch.cuda.mem_get_info()[0] < 2 * n * 8
+        env.Seed(7)                                                      # back to one key; then per-lane again: same buffer
+        env.Seed(seeds); first = env.Reset()
+        assert np.array_equal(first[5], oracle.cartpole_reset(5, 5, 0, 1)[:, 0])
+    # (b) reset_where(NULL) under AUTORESET: the step already re-drew finished lanes; the idiomatic `if done: Reset()` is a no-op
+    with gpu_pkg.VectorEnv("CartPole-v1", 4096, seed=SEED, auto_reset=True) as env:
+        env.Reset()
+        rng = np.random.default_rng(0)
+        for t in range(40):
+            out = env.Step(rng.integers(0, 2, 4096).astype(np.int32))
+        assert out.Done.any()
+        tick = env.Tick
+        again = env.ResetWhere(None)
+        assert np.array_equal(again, out.Observation) and env.Tick == tick
+        env.ResetWhereDevice(None); env.Sync()
+        assert env.Tick == tick and np.array_equal(env.Read().Observation, out.Observation)
+        m = np.zeros(4096, np.uint8); m[3] = 1
+        o2 = env.ResetWhere(m)                                           # an explicit mask still resets
+        assert env.Tick == tick + 1 and not np.array_equal(o2[3], out.Observation[3]) and np.array_equal(o2[4], out.Observation[4])
+    # (c) the graph cache is bounded: 20 distinct action buffers, results unchanged, memory flat afterwards
+    os.environ["GYMNET_GRAPH"] = "1"
+    try:
+        with gpu_pkg.VectorEnv("CartPole-v1", 2048, seed=SEED, auto_reset=True) as a, gpu_pkg.VectorEnv("CartPole-v1", 2048, seed=SEED, auto_reset=True) as b:
+            bufs = [torch.randint(0, 2, (4, 2048), dtype=torch.int32, device="cuda") for _ in range(20)]
+            torch.cuda.synchronize()
+            a.ResetDevice(); b.ResetDevice()
+            for rep in range(2):
+                for buf in bufs:
+                    a.RolloutDevice(buf, 8, 2048, 4)
+                    for t in range(8):
+                        b.StepDevice(buf[t % 4])
+            a.Sync(); b.Sync()
+            assert np.array_equal(a.GetState(), b.GetState())
+    finally:
+        os.environ.pop("GYMNET_GRAPH", None)
+    # (d) masked Discrete.Sample on the device (Discrete.cs:18-26) equals the oracle: per-lane masks and one shared row
+    with gpu_pkg.VectorEnv("Acrobot-v1", 5000, seed=SEED, lane_offset=17) as env:
+        rng = np.random.default_rng(2)
+        mask = rng.integers(0, 2, (5000, 3)).astype(np.uint8)
+        mask[:7] = 0                                                     # no valid action -> Start
+        mask[7:11] = 2                                                   # only ==1 counts (bmask = mask == 1)
+        dm = torch.from_numpy(mask).cuda()
+        out = torch.empty(5000, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        env.SampleActionsMaskedDevice(out, dm, per_lane=True, seed=11, tick=3); env.Sync()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, oracle.discrete_sample_masked(11, 17, 3, 3, 0, mask, 5000))
+        assert (got[:11] == 0).all() and all(mask[i, got[i]] == 1 for i in range(11, 5000) if mask[i].any())
+        row = torch.tensor([0, 1, 1], dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        env.SampleActionsMaskedDevice(out, row, per_lane=False, seed=11, tick=4); env.Sync()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, oracle.discrete_sample_masked(11, 17, 4, 3, 0, np.array([0, 1, 1], np.uint8), 5000))
+        assert set(np.unique(got)) == {1, 2}
+    with gpu_pkg.VectorEnv("Pendulum-v1", 64) as env, pytest.raises(NotImplementedError):
+        env.SampleActionsMaskedDevice(out, row, per_lane=False)          # Box.sample cannot be provided a mask (Box.cs:70)
+    # (e) sampling with the env's own (seed, tick) no longer replays the reset words (action == 1 iff x0 >= 0)
+    with gpu_pkg.VectorEnv("CartPole-v1", 8192, seed=0, auto_reset=True) as env:
+        x0 = env.Reset()[:, 0]
+        act = env.SampleActions(seed=0, tick=0)
+        agree = float(((act == 1) == (x0 >= 0)).mean())
+        assert 0.45 < agree < 0.55, agree
+
+
+def test_library_calls_restore_the_current_device(gpu_pkg):
+    import torch
+    before = torch.cuda.current_device()
+    with gpu_pkg.VectorEnv("CartPole-v1", 1024, device=0, seed=1) as env:
+        env.Reset(); env.Step(1)
+    assert torch.cuda.current_device() == before
+
+
+def _run_child(code, timeout=600, env=None):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if env:
+        e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n---\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+SHARDED_CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+import __graft_entry__ as ge
+pkg = ge.load_package()
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # RCCL, world of one
+n, steps = 1 << 14, 24
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+res = {}
+for overlap in (False, True):
+    env = pkg.ShardedVectorEnv("CartPole-v1", n, rank=0, world_size=1, device=0, seed=0x5EED, auto_reset=True,
+                               gather_obs=True, tensor_device=dev, force_gather=True, overlap=overlap)
+    assert env.gather_obs and env.overlap == overlap
+    one = pkg.VectorEnv("CartPole-v1", n, seed=0x5EED, auto_reset=True)
+    rng = np.random.default_rng(1)
+    env.ResetDevice(); one.Reset()
+    acts = torch.empty(n, dtype=torch.int32, device=dev)
+    ok = True
+    for t in range(steps):
+        a = rng.integers(0, 2, n).astype(np.int32)
+        acts.copy_(torch.from_numpy(a)); torch.cuda.synchronize()
+        env.StepDevice(acts)
+        env.AllGatherObs(overlap=overlap)
+        want = one.Step(a).Observation
+        if overlap and t %% 2 == 0 and t + 1 < steps:
+            continue                                   # gather stays in flight across the next step
+        env.WaitGather(); env.Sync(); torch.cuda.synchronize()
+        got = env.GlobalObs().cpu().numpy()            # [G=1, D, n]
+        ok = ok and np.array_equal(got[0].T, want)
+    res["overlap" if overlap else "serial"] = bool(ok)
+    env.Close(); one.Close()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_sharded_vector_env_on_hip_with_rccl_world_of_one(gpu_pkg):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = _run_child(SHARDED_CHILD % port)
+    line = [l for l in out.splitlines() if l.startswith("RESULT ")][-1]
+    assert json.loads(line[7:]) == {"serial": True, "overlap": True}
+
+
+def test_plain_bench_gpus_2_spawns_its_own_ranks(gpu_pkg):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent spawns two ranks before touching the GPU;
+    on this 1-GPU box they share the device over gloo (labelled as such).  This is the driver's SCALE command shape."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ring", "8",
+                        "--num-envs", str(1 << 18)], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 5 and j["repeats"] >= 3 and j["scaling"] == "weak"
+    assert j["config"]["global_num_envs"] == 2 << 18 and j["value"] > 1e8
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert "gloo" in j["config"]["backend"] and "SHARE" in j["config"]["backend"]

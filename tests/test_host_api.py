@@ -21,15 +21,37 @@ def test_header_symbols_are_all_exported(gymnet):
     assert not missing, missing
     # and the ctypes binding covers exactly the declared set
     assert declared == set(gymnet._capi.PROTOTYPES)
-    assert lib.gymnet_abi_version() == 1
+    assert lib.gymnet_abi_version() == 2 == gymnet._capi.ABI_VERSION
+
+
+def abi_manifest():
+    """sizeof / offsetof of every ABI struct field, printed by a C program compiled from the header itself
+    (tools/abi_manifest.c) — the layout truth the bindings are checked against."""
+    import json
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="gymnet_abi_"), "abi_manifest")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tools", "abi_manifest.c")], check=True)
+    return json.loads(subprocess.run([exe], check=True, capture_output=True, text=True).stdout)
+
+
+CTYPES_OF = {"gymnet_config": "Config", "gymnet_env_info": "EnvInfo", "gymnet_device_view": "DeviceView",
+             "gymnet_counters": "Counters", "gymnet_rollout_buffers": "RolloutBuffers", "gymnet_group_config": "GroupConfig"}
 
 
 def test_struct_layouts_match_the_header(gymnet):
-    c = gymnet._capi
-    assert ctypes.sizeof(c.Config) == 72 and c.Config.seed.offset == 32 and c.Config.max_episode_steps.offset == 64
-    assert ctypes.sizeof(c.EnvInfo) == 144 and c.EnvInfo.obs_low.offset == 68
-    assert ctypes.sizeof(c.Counters) == 40
-    assert ctypes.sizeof(c.DeviceView) == 40 + 11 * 8 + 8
+    man = abi_manifest()
+    assert man["abi_version"] == gymnet._capi.ABI_VERSION
+    for cname, pyname in CTYPES_OF.items():
+        st = getattr(gymnet._capi, pyname)
+        assert ctypes.sizeof(st) == man[cname]["size"], cname
+        assert [f[0] for f in st._fields_] == [f[0] for f in man[cname]["fields"]], cname      # same fields, same order
+        for fname, off, size in man[cname]["fields"]:
+            d = getattr(st, fname)
+            assert (d.offset, d.size) == (off, size), (cname, fname)
+    # every struct the header defines is in the manifest (a new struct cannot dodge the check)
+    hdr = open(os.path.join(ROOT, "include", "gymnet_amd.h")).read()
+    assert set(re.findall(r"typedef struct (gymnet_\w+) \{", hdr)) == set(CTYPES_OF)
 
 
 def test_env_descriptions_match_the_reference_ctor(gymnet):
@@ -166,29 +188,108 @@ def test_missing_extension_raises_instead_of_falling_back(tmp_path):
     assert "RAISED" in r.stdout and "has not been built" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
 
 
+CS_SIZES = {"uint": 4, "int": 4, "long": 8, "ulong": 8, "float": 4, "IntPtr": 8, "byte": 1}
+CS_STRUCT_OF = {"gymnet_config": "GymnetConfig", "gymnet_env_info": "GymnetEnvInfo", "gymnet_device_view": "GymnetDeviceView",
+                "gymnet_counters": "GymnetCounters", "gymnet_rollout_buffers": "GymnetRolloutBuffers",
+                "gymnet_group_config": "GymnetGroupConfig"}
+
+
+def _csharp_sources():
+    return {f: open(os.path.join(ROOT, "gym.net_amd", "csharp", f)).read() for f in ("Native.cs", "VectorEnv.cs")}
+
+
+def _cs_struct_layout(text, name):
+    """[(field, offset, size)] of a [StructLayout(LayoutKind.Sequential)] struct under the default packing rules
+    (every field at its natural alignment, struct size rounded up to the largest alignment)."""
+    m = re.search(r"\[StructLayout\(LayoutKind\.Sequential\)\]\s*public (?:unsafe )?struct " + name + r"\s*\{([^{}]*)\}", text)
+    assert m, name
+    out, off, maxal = [], 0, 1
+    for decl in m.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        f = re.fullmatch(r"public (fixed )?(\w+) (\w+)(?:\[(\d+)\])?", decl)
+        assert f, (name, decl)            # one field per declaration: `public int a, b;` would hide an order mistake
+        size1 = CS_SIZES[f.group(2)]
+        count = int(f.group(4)) if f.group(4) else 1
+        off = (off + size1 - 1) // size1 * size1
+        out.append((f.group(3), off, size1 * count))
+        off += size1 * count
+        maxal = max(maxal, size1)
+    return out, (off + maxal - 1) // maxal * maxal
+
+
 def test_csharp_binding_sources_lex_cleanly_and_cover_the_header():
-    """No .NET toolchain exists here, so the C# binding cannot be compiled; the least that can be checked is that
-    both files tokenize without a single error token (pygments' C# lexer), that braces / parentheses balance, and
-    that Native.cs declares a [DllImport] for every function the header exports (minus none)."""
+    """No .NET toolchain exists here, so the C# binding cannot be compiled.  What can be checked: both files tokenize
+    without a single error token (pygments' C# lexer), braces / parentheses balance, Native.cs declares a [DllImport] for
+    EVERY function the header exports (no exceptions) and nothing the header does not, and every Sequential struct matches
+    the C layout manifest field by field."""
     from pygments.lexers.dotnet import CSharpLexer
     from pygments.token import Error
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gymnet_amd.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(gymnet_[a-z_0-9]+)\s*\(", hdr))
-    srcs = {}
-    for f in ("Native.cs", "VectorEnv.cs"):
-        text = open(os.path.join(ROOT, "gym.net_amd", "csharp", f)).read()
-        srcs[f] = text
+    srcs = _csharp_sources()
+    for f, text in srcs.items():
         toks = list(CSharpLexer().get_tokens(text))
         assert not [v for tt, v in toks if tt is Error], f
         code = re.sub(r"//.*", "", text)
         code = re.sub(r'"(\\.|[^"\\])*"', '""', code)
         for a, b in ("{}", "()", "[]"):
             assert code.count(a) == code.count(b), (f, a)
-    imported = set(re.findall(r"extern int (gymnet_[a-z_0-9]+)\(", srcs["Native.cs"])) | set(re.findall(r"extern IntPtr (gymnet_[a-z_0-9]+)\(", srcs["Native.cs"]))
-    missing = declared - imported
-    # device-side sampling helpers are not needed by the managed wrapper; everything else must be importable
-    assert missing <= {"gymnet_sample_discrete_device", "gymnet_sample_box_device", "gymnet_vecenv_sample_actions_device",
-                       "gymnet_vecenv_device_view"}, missing
+    imported = set(re.findall(r"\[DllImport\(Lib\)\] public static extern (?:int|IntPtr) (gymnet_[a-z_0-9]+)\(", srcs["Native.cs"]))
+    assert declared - imported == set(), sorted(declared - imported)
+    assert imported - declared == set(), sorted(imported - declared)
+    # every native call the managed wrapper makes is one of the declared imports
+    used = set(re.findall(r"Native\.(gymnet_[a-z_0-9]+)\(", srcs["VectorEnv.cs"]))
+    assert used and used <= imported, sorted(used - imported)
+    man = abi_manifest()
+    for cname, csname in CS_STRUCT_OF.items():
+        fields, size = _cs_struct_layout(srcs["Native.cs"], csname)
+        assert size == man[cname]["size"], (csname, size, man[cname]["size"])
+        assert fields == [tuple(f) for f in man[cname]["fields"]], csname
+    assert set(CS_STRUCT_OF) == set(CTYPES_OF)
+    # status / flag enums carry the header's values
+    for cs, c in (("Rccl = -9", "GYMNET_ERR_RCCL = -9"), ("DoubleBuffer = 0x20", "GYMNET_FLAG_DOUBLE_BUFFER    0x20u")):
+        assert cs in srcs["Native.cs"] and c in open(os.path.join(ROOT, "include", "gymnet_amd.h")).read()
+
+
+# IVecEnv (src/Gym/Envs/IVecEnv.cs:8-19): the methods a polymorphic caller can reach; VecEnv implements Seed(int), Seed(int[])
+# NON-virtually (VecEnv.cs:44-53) and StepAsync likewise (VecEnv.cs:63-65), Reset / Step / Close abstractly.
+IVECENV_METHODS = {"Reset": "NDArray[] Reset()", "Step": "Step[] Step(int action)", "Close": "void Close()",
+                   "Seed(int[])": "void Seed(int[] seed)", "Seed(int)": "void Seed(int seed)"}
+
+
+def test_csharp_vectorenv_is_a_drop_in_through_the_reference_interface():
+    """The round-1 binding hid VecEnv's non-virtual Seed / StepAsync with `public new` only: through an IVecEnv or VecEnv
+    reference the BASE methods ran over an empty Environments list.  Checks on the source text:
+    the class re-lists IVecEnv, implements both Seed overloads explicitly, overrides the abstract members, installs a
+    non-empty Environments list whose lane proxies forward Seed, and routes StepAsync through the native async pair."""
+    src = _csharp_sources()["VectorEnv.cs"]
+    code = re.sub(r"//.*", "", src)
+    head = re.search(r"public sealed unsafe class VectorEnv\s*:\s*([^{]+)\{", code)
+    bases = [b.strip() for b in head.group(1).split(",")]
+    assert bases[0] == "VecEnv" and "IVecEnv" in bases and "IDisposable" in bases
+    assert re.search(r"void IVecEnv\.Seed\(int seed\)", code) and re.search(r"void IVecEnv\.Seed\(int\[\] seed\)", code)
+    for m in ("public override NDArray[] Reset()", "public override Step[] Step(int action)", "public override void Close()"):
+        assert m in code, m
+    # a `new`-hidden member is only acceptable when the interface path is re-implemented explicitly (Seed) or the member
+    # is not part of IVecEnv at all (StepAsync)
+    for hidden in re.findall(r"public new [\w<>\[\]]+ (\w+)\(", code):
+        assert hidden in ("Seed", "StepAsync"), hidden
+    assert "Environments = new LaneList(this)" in code
+    assert re.search(r"class LaneEnv\s*:\s*IEnv", code) and "public void Seed(int seed) => Owner.SeedLaneFromProxy(Lane, seed)" in code
+    sa = code[code.index("public new Task<Step[]> StepAsync(int action)"):]
+    sa = sa[:sa.index("void IVecEnv.Seed")]
+    assert "gymnet_vecenv_step_async" in sa and "gymnet_vecenv_step_wait" in sa and "Step(action)" not in sa
+    # the list above really is the reference's interface (checked where the reference tree exists: the build container)
+    ref = "/root/reference/src/Gym/Envs/IVecEnv.cs"
+    if os.path.exists(ref):
+        text = open(ref, encoding="utf-8-sig").read()
+        methods = set(re.findall(r"^\s+([\w\[\]]+ \w+\([^)]*\));", text, flags=re.M))
+        assert methods == set(IVECENV_METHODS.values()), methods
+        vec = open("/root/reference/src/Gym/Envs/VecEnv.cs", encoding="utf-8-sig").read()
+        assert "public void Seed(int seed)" in vec and "public void Seed(int[] seed)" in vec            # non-virtual: cannot be overridden
+        assert "public Task<Step[]> StepAsync(int action)" in vec and "public IList<IEnv> Environments { get; set; }" in vec
 
 
 def test_mirror_exposes_the_reference_member_names(gymnet):

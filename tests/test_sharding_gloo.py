@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -34,7 +34,8 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     env = pkg.ShardedVectorEnv("CartPole-v1", N, rank=rank, world_size=world, seed=SEED, auto_reset=True,
-                               gather_obs=True, local_env_factory=OracleLocalEnv, tensor_device="cpu")
+                               gather_obs=True, local_env_factory=OracleLocalEnv, tensor_device="cpu", overlap=overlap)
+    assert env.overlap == overlap and env.obs_bufs.shape[0] == (2 if overlap else 1)
     assert env.local_num_envs == N // world and env.lane_offset == rank * N // world
     rng = np.random.default_rng(99)                       # every rank derives the same GLOBAL action array
     acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
@@ -43,19 +44,35 @@ def _worker(rank, world, port, out_dir):
     snaps = []
     for t in range(STEPS):
         env.StepDevice(torch.from_numpy(acts[t, lo:hi].copy()))
-        work = env.AllGatherObs(async_op=(t % 2 == 0))    # both the blocking and the overlapped form
-        env.Wait()
-        snaps.append(env.GlobalObs().clone().numpy())
+        if overlap:                                       # double-buffered: the gather of step t is only waited for
+            env.AllGatherObs(overlap=True)                # when its buffer is read here / about to be overwritten
+            if t % 3 != 0:
+                env.WaitGather()
+                snaps.append(env.GlobalObs().clone().numpy())
+            else:                                         # leave it in flight across the next step, then read it
+                last = env.GlobalObs()
+                snaps.append(None)
+                if t + 1 == STEPS:
+                    env.WaitGather()
+                    snaps[-1] = last.clone().numpy()
+            if t > 0 and snaps[t - 1] is None:
+                env._finish(env._last ^ 1)
+                snaps[t - 1] = env.obs_bufs[env._last ^ 1].clone().numpy()
+        else:
+            env.AllGatherObs(async_op=(t % 2 == 0))       # both the blocking and the async form
+            env.Wait()
+            snaps.append(env.GlobalObs().clone().numpy())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.stack(snaps))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_rollout_equals_single_shard(tmp_path, oracle):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_sharded_rollout_equals_single_shard(tmp_path, oracle, overlap):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     got = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
     assert np.array_equal(got[0], got[1])                 # every rank holds the same gathered observations
     # single shard, same seed, same global actions, same float32 kernel-semantics oracle
