@@ -153,6 +153,7 @@ int allgather(gymnet_group *g) {
                                           g->comms[m], g->gstream[m]));
         }
         RCCL_TRY(g, g->rccl.GroupEnd());
+        (void)hipGetLastError();      // see gymnet_group_create: RCCL may leave a stale HIP error behind
     }
     for (int m = 0; m < G; ++m) {
         HIP_TRY(nullptr, hipSetDevice(g->devices[m]));
@@ -305,6 +306,9 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
         g->comms.assign(G, nullptr);
         ncclResult_t r = g->rccl.CommInitAll(g->comms.data(), G, g->devices.data());
         if (r != ncclSuccess) G_FAIL(GYMNET_ERR_RCCL, "ncclCommInitAll failed: %s", g->rccl.GetErrorString(r));
+        // RCCL probes devices / peers while it initialises and leaves HIP's sticky per-thread "last error" set (seen:
+        // hipErrorInvalidDevice); the kernel launchers read that slot after each launch, so it has to be cleared here
+        (void)hipGetLastError();
     }
 #undef G_HIP
 #undef G_FAIL

@@ -164,11 +164,15 @@ def test_long_fused_rollout_stays_deterministic_and_in_bounds(gpu_pkg):
         assert f.Tick == e.Tick == T + 1 and f.Counters()["tick"] == T + 1 == e.Counters()["tick"]
 
 
-LONG_ROLLOUT_SHA256 = {   # tools/determinism_probe.py, identical across runs and across MI355X boxes
-    "CartPole-v1": "cba10d6292bcd92e9e462b7b",
-    "Pendulum-v1": "7732d5868059520b6d8b7992",
-    "MountainCar-v0": "ebcf1106b4631d46c90885c7",
-    "Acrobot-v1": "014e67b16a705a0d548a449c",
+# tools/determinism_probe.py, identical across runs and across MI355X boxes.  Re-pinned in round 2 for ONE reason: space
+# sampling moved to its own Philox stream (key ^ 0x9E3779B97F4A7C15), so the device-sampled actions this test
+# feeds changed; reset draws and all arithmetic are unchanged (the round-1 values were cba10d62…, 7732d586…, ebcf1106…,
+# 014e67b1…).  Later kernel changes in this round (packed-f32 Acrobot) must reproduce THESE values.
+LONG_ROLLOUT_SHA256 = {
+    "CartPole-v1": "4b33a229e81d658d7240b98f",
+    "Pendulum-v1": "2bfb470ea7fe5499e34837d8",
+    "MountainCar-v0": "4a4759dc8c8d567686ac7ba0",
+    "Acrobot-v1": "23693d80a6e0b6cfafddc3b5",
 }
 
 
