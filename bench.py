@@ -175,9 +175,11 @@ def main():
 
     # this rank's shard of the global batch; observations live inside the (optional) gather buffer
     can_gather = use_dist and backend == "nccl"
+    # the headline always steps IN PLACE (double-buffered observation arrays cost the step kernel ~0.8 us at this size,
+    # profiles/double_buffer_probe_r02.txt); the overlapped-gather figure below builds its own double-buffered shard
     env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
                                auto_reset=True, gather_obs=use_dist, tensor_device=dev,
-                               force_gather=args.force_dist, overlap=can_gather and not args.no_overlap)
+                               force_gather=args.force_dist, overlap=False)
     local = env.local
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
     actions = torch.empty((ring, n), dtype=adtype, device=dev)
@@ -203,19 +205,23 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def timed_region(fn):
-        """One bracketed region: barrier + synchronize, fn(), synchronize + barrier.  Returns (wall s, event ms)."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def timed_region(fn, events=True):
+        """One bracketed region: barrier + synchronize, fn(), synchronize + barrier.  Returns (wall s, event ms or nan).
+        events=False leaves the two HIP-event records (a few host us each) out of the wall-clock bracket."""
+        if events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
-        e0.record(stream)
+        if events:
+            e0.record(stream)
         fn()
-        e1.record(stream)
+        if events:
+            e1.record(stream)
         torch.cuda.synchronize(dev)
         barrier()
         t1 = time.perf_counter()
-        return t1 - t0, e0.elapsed_time(e1)
+        return t1 - t0, (e0.elapsed_time(e1) if events else float("nan"))
 
     def repeat_until(fn, min_seconds, max_repeats=MAX_REPEATS):
         """Repeats the bracketed region until min_seconds have been timed (every rank runs the same count: the count
@@ -226,7 +232,8 @@ def main():
             tr = torch.tensor([reps], dtype=torch.int64, device=red_dev)
             dist.broadcast(tr, 0)
             reps = int(tr[0])
-        rows = [first] + [timed_region(fn) for _ in range(reps - 1)]
+        # odd repeats carry the HIP events (kernel-duration figure), even repeats are the bare wall-clock bracket
+        rows = [first] + [timed_region(fn, events=(i % 2 == 0)) for i in range(reps - 1)]
         if use_dist:
             tw = torch.tensor(rows, dtype=torch.float64, device=red_dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -237,9 +244,10 @@ def main():
     torch.cuda.synchronize(dev)
     steps_before = local.Counters()["lane_steps"]
     rows = repeat_until(lambda: run(K), args.min_seconds)
-    walls = [r[0] for r in rows]
-    wall = median(walls)
-    ev_ms = median([r[1] for r in rows])
+    bare = [r[0] for r in rows if r[1] != r[1]] or [r[0] for r in rows]      # regions without event records (nan != nan)
+    walls = bare
+    wall = median(bare)
+    ev_ms = median([r[1] for r in rows if r[1] == r[1]])
     repeats = len(rows)
 
     # sanity: the engine really ran K steps on every lane in every repeat
@@ -286,22 +294,35 @@ def main():
     if can_gather and not gather_in_region:
         gathered = {}
         gs = 128
-        for label, overlapped in (("serial", False), ("overlapped", True)) if env.overlap else (("serial", False),):
+        for label, overlapped in (("serial", False), ("overlapped", True)):
+            if overlapped and args.no_overlap:
+                continue
+            genv = None
             try:
+                genv = env if not overlapped else pkg.ShardedVectorEnv(
+                    args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed, auto_reset=True,
+                    gather_obs=True, tensor_device=dev, force_gather=args.force_dist, overlap=True)
+                if overlapped:
+                    genv.ResetDevice()
+
                 def gloop(steps=gs):
                     for t in range(steps):
-                        env.StepDevice(actions[t % ring].data_ptr())
-                        env.AllGatherObs(overlap=overlapped)
-                    env.WaitGather()
+                        genv.StepDevice(actions[t % ring].data_ptr())
+                        genv.AllGatherObs(overlap=overlapped)
+                    genv.WaitGather()
                 gloop(16)
                 grows = repeat_until(gloop, args.min_seconds, max_repeats=16)
                 gwall = median([r[0] for r in grows])
-                obs = env.LastGatheredObs()
+                obs = genv.LastGatheredObs()
                 ok = bool(torch.isfinite(obs).all()) and all(float(obs[r].abs().sum()) > 0 for r in range(world))
                 gathered[label] = {"value": n * world * gs / gwall, "unit": "env-steps/s", "ms_per_step": gwall * 1e3 / gs,
                                    "steps": gs, "repeats": len(grows), "gathered_obs_finite_and_nonzero": ok}
             except Exception as e:                      # never lose the headline over the optional collective
                 gathered[label] = {"error": repr(e)[:200]}
+            finally:
+                if overlapped and genv is not None:
+                    genv.Sync()
+                    genv.Close()
         gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4
 
     # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
@@ -327,7 +348,7 @@ def main():
 
     bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
     launch_policy = local.LaunchPolicy()
-    overlap_on = env.overlap
+    overlap_on = False
     env.Close()
     del actions
     torch.cuda.empty_cache()

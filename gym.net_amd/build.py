@@ -1,6 +1,6 @@
 """Builds gym.net_amd/lib/libgymnet_amd.so: the HIP kernels + the C ABI, for gfx950 only.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared csrc/*.hip -ldl -o lib/libgymnet_amd.so
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared csrc/*.hip -ldl -o lib/libgymnet_amd.so
 
 -ffp-contract=off is part of the numerical contract (see csrc/envs.hpp): every float32 operation
 rounds on its own, in the order written.  hipcc cross-compiles without a GPU present.
@@ -14,7 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libgymnet_amd.so")
 SOURCES = ["kernels.hip", "capi.hip", "group.hip"]
 DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: on gfx950 a packed FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) occupies the SIMD for
+# ~4.9 cycles against ~2.35 for its scalar form (tools/valu_probe.hip, profiles/valu_probe_r02.txt): pairing two scalar
+# operations saves nothing and costs the v_mov shuffles that build the pairs (Acrobot: 465 -> 452 VALU per env-step).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
 
 

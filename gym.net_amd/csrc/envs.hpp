@@ -25,10 +25,17 @@ namespace gymnet {
 // reproduces it BIT FOR BIT.  Measured against float64 sin/cos: |abs error| <= 9.3e-8 for every
 // |x| <= 1e5, <= 1.5 ulp for |x| <= 10.  sin(-0) returns +0.  |x| > 65536 (or inf) falls back to OCML.
 // ---------------------------------------------------------------------------------------------
+// BOUNDED = true drops the OCML fallback: for callers whose argument is bounded by construction (Acrobot's wrapped
+// angles and RK4 stage angles, |x| < 16).  Same bits as the full version for every |x| <= 65536; beyond that the result
+// is unspecified (finite garbage or NaN, never a hang).  It exists because the ten inlined Payne-Hanek fallbacks made the
+// ALU-bound Acrobot kernel 2.5x longer than its hot path.
+template <bool BOUNDED = false>
 __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) {
-    if (__builtin_expect(fabsf(x) > 65536.0f, 0)) {   // never taken by a sane rollout; keeps huge / infinite angles defined
-        sincosf(x, &s_out, &c_out);
-        return;
+    if constexpr (!BOUNDED) {
+        if (__builtin_expect(fabsf(x) > 65536.0f, 0)) {   // never taken by a sane rollout; keeps huge / infinite angles defined
+            sincosf(x, &s_out, &c_out);
+            return;
+        }
     }
     const float n = rintf(x * 0.636619772367581343f);                 // nearest multiple of pi/2
     float r = fmaf(n, -1.5703125f, x);                                // pi/2 = 1.5703125 + 4.8375e-4 + 7.5498e-8
@@ -41,10 +48,16 @@ __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) 
     float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
     pc = fmaf(pc, z, 4.166664568298827e-2f);
     const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));            // cos r
-    const int q = (int)n & 3;
-    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
-    s_out = (q & 2) ? -ss : ss;
-    c_out = ((q + 1) & 2) ? -cc : cc;
+    // quadrant: q = n mod 4.  sin x = {s, c, -s, -c}[q], cos x = {c, -s, -c, s}[q].  The signs go in as XORs of the sign bit
+    // (bit 1 of q for the sine, bit 1 of q+1 = bit1(q) ^ bit0(q) for the cosine) instead of compare + select pairs:
+    // same bits out (negation IS a sign-bit flip), three instructions fewer per call.
+    const uint32_t q = (uint32_t)(int)n;
+    const uint32_t q30 = q << 30, q31 = q << 31;
+    const bool odd = (int32_t)q31 < 0;
+    const float ss = odd ? c : s, cc = odd ? s : c;
+    // v_bitop3_b32 with truth table 0x78 = a ^ (b & c): one instruction per output
+    s_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(ss), q30, 0x80000000u, 0x78));
+    c_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(cc), q30 ^ q31, 0x80000000u, 0x78));
 }
 __device__ __forceinline__ float sin_f32(float x) { float s, c; sincos_f32(x, s, c); return s; }
 __device__ __forceinline__ float cos_f32(float x) { float s, c; sincos_f32(x, s, c); return c; }
@@ -118,6 +131,8 @@ struct CartPole {
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = s[k];
     }
+    // observation of a state reset() has just drawn (bounded by construction: an env may use cheaper trigonometry here)
+    __device__ __forceinline__ static void observe_fresh(const float (&s)[S], float (&o)[O]) { observe(s, o); }
     // dynamics + observation of the new state in one call (Acrobot shares its trigonometry between the two)
     __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
         step(s, a, reward, done);
@@ -167,6 +182,8 @@ struct Pendulum {
         sincos_f32(s[0], sn, cs);
         o[0] = cs; o[1] = sn; o[2] = s[1];
     }
+    // observation of a state reset() has just drawn (bounded by construction: an env may use cheaper trigonometry here)
+    __device__ __forceinline__ static void observe_fresh(const float (&s)[S], float (&o)[O]) { observe(s, o); }
     __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
         step(s, a, reward, done);
         observe(s, o);
@@ -202,6 +219,8 @@ struct MountainCar {
     }
 
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) { o[0] = s[0]; o[1] = s[1]; }
+    // observation of a state reset() has just drawn (bounded by construction: an env may use cheaper trigonometry here)
+    __device__ __forceinline__ static void observe_fresh(const float (&s)[S], float (&o)[O]) { observe(s, o); }
     __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
         step(s, a, reward, done);
         observe(s, o);
@@ -221,25 +240,49 @@ struct Acrobot {
     static constexpr float PI = 3.14159265358979323846f;
 
     // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals.
-    // Acrobot is the one ALU-bound kernel of the four (RK4 = 4 x dsdt), so dsdt is written for instruction count:
-    //  - upstream's cos(th1 + th2 - pi/2) and cos(th1 - pi/2) are sin(th1 + th2) and sin(th1); with sin/cos of th1 and
-    //    th2 in hand, sin(th1 + th2) = s1*c2 + c1*s2: two sincos per stage instead of one sincos + two cos;
-    //  - the two divisions by d1 share one reciprocal.
-    // Mathematically identical to upstream; in float32 it differs from the literal transcription by rounding only
-    // (<= 1e-6 on accelerations of O(10)); the float64 oracle keeps upstream's literal formula.
+    // Acrobot is the one ALU-bound kernel of the four.  On gfx950 a wave64 FP32 VALU instruction occupies its SIMD for
+    // ~2.35 cycles whether it is v_fma_f32, v_mul_f32 or v_add_f32, and the packed forms (v_pk_fma_f32 ...) take ~4.9
+    // (measured: tools/valu_probe.hip, profiles/valu_probe_r02.txt) — packing two envs into one instruction buys nothing,
+    // and with 8 waves per SIMD resident the kernel already issues one VALU instruction every 2.5 cycles.  The only lever
+    // is the INSTRUCTION COUNT per env-step, so dsdt and the RK4 combination are written for it:
+    //  - upstream's cos(th1 + th2 - pi/2) and cos(th1 - pi/2) are sin(th1 + th2) = s1*c2 + c1*s2 and sin(th1);
+    //  - numerator and denominator of ddth2 are multiplied through by d1, so ONE reciprocal R = 1/(d1*det) serves both
+    //    accelerations (1/det = R*d1, 1/d1 = R*det) instead of two IEEE divisions (11 instructions each), and that
+    //    reciprocal is recip_p() below: 6 fma for the narrow range d1*det lives in;
+    //  - every a*b+c is an explicit fmaf (one instruction, one rounding), products are factored
+    //    (B^2 s2/2 + A B s2 = s2 B (B/2 + A));
+    //  - sincos without the OCML fallback (arguments are bounded here).
+    // ~35 instructions + two sincos per stage instead of ~54 + two.  Mathematically identical to upstream; in float32 it
+    // differs from the literal transcription by rounding only; the float64 oracle keeps upstream's literal formula and the
+    // float32 "kernel semantics" twin (oracle/classic_control_ref.c) mirrors THIS sequence operation for operation.
+    // 1/P for P = d1 * det.  With c2 in [-1, 1]: d1 = c2 + 3.5 in [2.5, 4.5], det = 2.8125 - c2^2/4 in [2.5625, 2.8125], so
+    // P lies in [6.4, 11.6] — no scaling, no special cases.  Quadratic minimax seed on [6.25, 11.75] (relative error 7.7e-3)
+    // + two Newton steps r <- r + r(1 - P r): 6 full-rate fma instead of the 10-instruction IEEE division sequence around a
+    // quarter-rate v_rcp_f32.  Result within 0.55 ulp of 1/P over the whole range (2e6 random P, tools note in DESIGN.md),
+    // and — being fma only — reproduced bit for bit by the CPU restatement.
+    __device__ __forceinline__ static float recip_p(float P) {
+        float r = fmaf(fmaf(P, 0x1.82ab8p-10f, -0x1.4640b2p-5f), P, 0x1.6677a2p-2f);
+        r = fmaf(r, fmaf(-P, r, 1.0f), r);
+        r = fmaf(r, fmaf(-P, r, 1.0f), r);
+        return r;
+    }
+
     __device__ __forceinline__ static void dsdt(const float (&s)[4], float torque, float (&d)[4]) {
-        const float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+        const float th1 = s[0], th2 = s[1], A = s[2], B = s[3];
         float s1, c1, s2, c2;
-        sincos_f32(th1, s1, c1);
-        sincos_f32(th2, s2, c2);
-        const float d1 = 0.25f + (1.25f + c2) + 2.0f;
-        const float d2 = (0.25f + 0.5f * c2) + 1.0f;
-        const float r1 = 1.0f / d1;
-        const float phi2 = 4.9f * (s1 * c2 + c1 * s2);
-        const float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * s1 + phi2;
-        const float ddth2 = (torque + d2 * r1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 * r1);
-        const float ddth1 = -(d2 * ddth2 + phi1) * r1;
-        d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+        sincos_f32<true>(th1, s1, c1);
+        sincos_f32<true>(th2, s2, c2);
+        const float d1 = c2 + 3.5f;                                   // 0.25 + (1.25 + c2) + 2
+        const float d2 = fmaf(0.5f, c2, 1.25f);                       // 0.25 + 0.5 c2 + 1
+        const float phi2 = 4.9f * fmaf(s1, c2, c1 * s2);              // m2 lc2 g sin(th1 + th2)
+        const float phi1 = fmaf(-(s2 * B), fmaf(0.5f, B, A), fmaf(14.7f, s1, phi2));   // -s2 B (B/2 + A) + 14.7 s1 + phi2
+        const float h = fmaf(-(0.5f * A), A * s2, torque - phi2);     // torque - A^2 s2 / 2 - phi2
+        const float det = fmaf(1.25f, d1, -(d2 * d2));                // (m2 lc2^2 + I2) d1 - d2^2
+        const float num = fmaf(h, d1, d2 * phi1);
+        const float R = recip_p(d1 * det);
+        const float ddth2 = num * (R * d1);
+        const float ddth1 = -fmaf(d2, ddth2, phi1) * (R * det);
+        d[0] = A; d[1] = B; d[2] = ddth1; d[3] = ddth2;
     }
 
     __device__ __forceinline__ static float wrap(float x, float m, float M) {
@@ -257,16 +300,16 @@ struct Acrobot {
         float k1[4], k2[4], k3[4], k4[4], y[4];
         dsdt(s, torque, k1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 2.0f * k1[i];
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k1[i], s[i]);
         dsdt(y, torque, k2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 2.0f * k2[i];
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k2[i], s[i]);
         dsdt(y, torque, k3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt, k3[i], s[i]);
         dsdt(y, torque, k4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 6.0f, fmaf(2.0f, k3[i], fmaf(2.0f, k2[i], k1[i])) + k4[i], s[i]);
         y[0] = wrap(y[0], -PI, PI);
         y[1] = wrap(y[1], -PI, PI);
         y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
@@ -275,9 +318,9 @@ struct Acrobot {
         for (int i = 0; i < 4; ++i) s[i] = y[i];
         // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2
         float s1, c1, s2, c2;
-        sincos_f32(y[0], s1, c1);
-        sincos_f32(y[1], s2, c2);
-        done = (-c1 - (c1 * c2 - s1 * s2)) > 1.0f;
+        sincos_f32<true>(y[0], s1, c1);
+        sincos_f32<true>(y[1], s2, c2);
+        done = (-c1 - fmaf(c1, c2, -(s1 * s2))) > 1.0f;
         reward = done ? 0.0f : -1.0f;
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = y[2]; o[5] = y[3];
     }
@@ -292,10 +335,18 @@ struct Acrobot {
         for (int k = 0; k < 4; ++k) s[k] = -0.1f + 0.2f * u01_24(r.w[k]);
     }
 
+    // any state (set_state hands over arbitrary angles): full-range sincos
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
         float s1, c1, s2, c2;
         sincos_f32(s[0], s1, c1);
         sincos_f32(s[1], s2, c2);
+        o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
+    }
+    // a freshly reset state: angles in [-0.1, 0.1) — same bits as observe(), without the fallback code
+    __device__ __forceinline__ static void observe_fresh(const float (&s)[S], float (&o)[O]) {
+        float s1, c1, s2, c2;
+        sincos_f32<true>(s[0], s1, c1);
+        sincos_f32<true>(s[1], s2, c2);
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
     }
 };

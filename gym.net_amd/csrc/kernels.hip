@@ -165,7 +165,7 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, float (&s)[Env::
         float sj[S];
         Env::reset(sj, r);
         float oj[O];
-        if constexpr (!Env::OBS_ALIASES_STATE) Env::observe(sj, oj);
+        if constexpr (!Env::OBS_ALIASES_STATE) Env::observe_fresh(sj, oj);
 #pragma unroll
         for (int jj = 0; jj < VEC; ++jj) {
             if (jj == j) {
@@ -189,22 +189,36 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, float (&s)[Env::
 //   NT        non-temporal mask: 1 state loads, 2 state/obs stores, 4 action load, 8 reward/done stores
 // ---------------------------------------------------------------------------------------------
 //   GUARD     per-element bounds checks; only the last (partial) workgroup of a launch runs the guarded body
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD>
-__device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, const uint64_t tick) {
-    constexpr int S = Env::S, O = Env::O;
-    constexpr bool NT_SL = (NT & 1) != 0, NT_SS = (NT & 2) != 0, NT_A = (NT & 4) != 0, NT_O = (NT & 8) != 0;
-    using Act = typename Env::Action;
+// What one thread reads for its VEC lanes before it can advance them.  Split from the rest of the step so that the
+// grid-stride kernel below can have the NEXT lanes' loads in flight while it computes the current ones.
+template <class Env, int VEC>
+struct LaneInputs {
+    float s[Env::S][VEC];
+    typename Env::Action act[VEC];
+    int32_t sbd[VEC];
+};
+
+template <class Env, int VEC, bool AUTORESET, int NT, bool GUARD>
+__device__ __forceinline__ void load_inputs(const StepArgs &a, const int64_t i0, LaneInputs<Env, VEC> &in) {
+    constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
     const int64_t n = a.n;
-
-    float s[S][VEC];
 #pragma unroll
-    for (int k = 0; k < S; ++k) load_f32<VEC, NT_SL, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
-    Act act[VEC];
-    if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A, GUARD>(static_cast<const float *>(a.action), i0, n, act);
-    else load_i32<VEC, NT_A, GUARD>(static_cast<const int32_t *>(a.action), i0, n, act);
+    for (int k = 0; k < Env::S; ++k) load_f32<VEC, NT_SL, GUARD>(a.state + k * a.state_stride, i0, n, in.s[k]);
+    if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A, GUARD>(static_cast<const float *>(a.action), i0, n, in.act);
+    else load_i32<VEC, NT_A, GUARD>(static_cast<const int32_t *>(a.action), i0, n, in.act);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) in.sbd[j] = 0;
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, in.sbd);
+}
 
-    int32_t sbd[VEC] = {};
-    if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, sbd);
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD>
+__device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64_t i0, const uint64_t tick, LaneInputs<Env, VEC> &in) {
+    constexpr int S = Env::S, O = Env::O;
+    constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
+    const int64_t n = a.n;
+    float (&s)[S][VEC] = in.s;
+    typename Env::Action (&act)[VEC] = in.act;
+    int32_t (&sbd)[VEC] = in.sbd;
 
     float ep_ret[VEC];
     int32_t ep_len[VEC];
@@ -311,6 +325,42 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
                     if (finished[j]) seg[base + off[j]] = (int32_t)(i0 + j);
             }
         }
+    }
+}
+
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD>
+__device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, const uint64_t tick) {
+    LaneInputs<Env, VEC> in;
+    load_inputs<Env, VEC, AUTORESET, NT, GUARD>(a, i0, in);
+    advance_and_store<Env, VEC, AUTORESET, EXTRAS, NT, GUARD>(a, i0, tick, in);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid-stride variant for the ALU-bound env (Acrobot).  The one-shot kernel above runs every wave in lock-step —
+// load, ~500 VALU of RK4, store — so the memory system idles while the ALUs work and the ALUs idle during the load and
+// store bursts of each of its two wave generations (14.7 us at 2^20 lanes against 10.6 us of memory time and ~8 us of VALU
+// issue time).  Here a thread owns several lanes (i, i + T, i + 2T, ...; still coalesced per trip) and software-pipelines
+// them: the next lane's five loads are issued BEFORE the current lane's arithmetic, and the current lane's stores drain
+// under the next lane's arithmetic.  Fewer, longer-lived waves also drift out of phase, which spreads the traffic over the
+// whole kernel.  Bit-identical to the one-shot kernel (same per-lane code, same Philox counters).
+// ---------------------------------------------------------------------------------------------
+template <class Env, bool AUTORESET, int NT>
+__global__ __launch_bounds__(256) void step_kernel_gs(const StepArgs a) {
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    LaneInputs<Env, 1> cur, nxt;
+    load_inputs<Env, 1, AUTORESET, NT, false>(a, i, cur);
+    for (;;) {
+        const int64_t j = i + T;
+        const bool more = j < a.n;
+        if (more) load_inputs<Env, 1, AUTORESET, NT, false>(a, j, nxt);
+        advance_and_store<Env, 1, AUTORESET, false, NT, false>(a, i, tick, cur);
+        if (!more) break;
+        cur = nxt;
+        i = j;
     }
 }
 
@@ -449,7 +499,7 @@ __device__ __forceinline__ void reset_lane(const ResetArgs &a, int64_t i, uint64
     for (int k = 0; k < S; ++k) a.state[k * a.state_stride + i] = s[k];
     if constexpr (!Env::OBS_ALIASES_STATE) {
         float o[O];
-        Env::observe(s, o);
+        Env::observe_fresh(s, o);
 #pragma unroll
         for (int k = 0; k < O; ++k) a.obs[k * a.obs_stride + i] = o[k];
     }
@@ -658,9 +708,16 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     const int block = cfg.block;
+    if (cfg.items > 1 && !extras && cfg.vec == 1) {       // grid-stride, software-pipelined (ALU-bound envs)
+        const int64_t per_block = 256 * (int64_t)cfg.items;
+        const dim3 ggrid(grid_for(a.n > 0 ? (a.n + per_block - 1) / per_block * 256 : 256, 256)), gblk(256);
+        if (autoreset) hipLaunchKernelGGL((step_kernel_gs<Env, true, 15>), ggrid, gblk, 0, st, a);
+        else hipLaunchKernelGGL((step_kernel_gs<Env, false, 15>), ggrid, gblk, 0, st, a);
+        return hipGetLastError();
+    }
     const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
     const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
-#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, 0, st, a)
+#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, (size_t)cfg.lds_bytes, st, a)
 #define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
     do {                                                              \
         if (cfg.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);               \
@@ -684,6 +741,7 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
     if (cfg.vec != 4) cfg.vec = 1;
     if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
     if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
+    if (cfg.items < 1) cfg.items = 1;
     switch (env_id) {
         case 0: return launch_step_env<CartPole>(autoreset, extras, a, cfg, st);
         case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);

@@ -426,21 +426,34 @@ int ref_acrobot_step_f64(double *state, int a, double *obs6, double *reward) {
     return done;
 }
 
+/* 1/P for P = d1 * det in [6.4, 11.6] (kernel semantics, gym.net_amd/csrc/envs.hpp Acrobot::recip_p): quadratic minimax
+ * seed + two Newton steps, fma only. */
+static float acrobot_recip_p_f32(float P) {
+    float r = fmaf(fmaf(P, 0x1.82ab8p-10f, -0x1.4640b2p-5f), P, 0x1.6677a2p-2f);
+    r = fmaf(r, fmaf(-P, r, 1.0f), r);
+    r = fmaf(r, fmaf(-P, r, 1.0f), r);
+    return r;
+}
+
 static void acrobot_dsdt_f32(const float s[4], float tau, float d[4]) {
-    /* kernel semantics (gym.net_amd/csrc/envs.hpp Acrobot::dsdt): constants folded (m1=m2=l1=I1=I2=1, lc1=lc2=0.5, g=9.8);
-     * cos(th1+th2-pi/2) = sin(th1+th2) = s1*c2 + c1*s2, cos(th1-pi/2) = s1; one reciprocal of d1 shared by both divisions */
-    float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+    /* kernel semantics (gym.net_amd/csrc/envs.hpp Acrobot::dsdt), operation for operation: constants folded (m1=m2=l1=I1=I2=1,
+     * lc1=lc2=0.5, g=9.8); cos(th1+th2-pi/2) = sin(th1+th2) = s1*c2 + c1*s2, cos(th1-pi/2) = s1; numerator and denominator of
+     * ddth2 multiplied through by d1 so that ONE reciprocal R = 1/(d1*det) serves both accelerations; every a*b+c is an fmaf */
+    float th1 = s[0], th2 = s[1], A = s[2], B = s[3];
     float s1, c1, s2, c2;
     ref_sincos_f32_kernel(th1, &s1, &c1);
     ref_sincos_f32_kernel(th2, &s2, &c2);
-    float d1 = 0.25f + (1.25f + c2) + 2.0f;
-    float d2 = (0.25f + 0.5f * c2) + 1.0f;
-    float r1 = 1.0f / d1;
-    float phi2 = 4.9f * (s1 * c2 + c1 * s2);
-    float phi1 = -0.5f * dth2 * dth2 * s2 - 1.0f * dth2 * dth1 * s2 + 14.7f * s1 + phi2;
-    float ddth2 = (tau + d2 * r1 * phi1 - 0.5f * dth1 * dth1 * s2 - phi2) / (1.25f - d2 * d2 * r1);
-    float ddth1 = -(d2 * ddth2 + phi1) * r1;
-    d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+    float d1 = c2 + 3.5f;
+    float d2 = fmaf(0.5f, c2, 1.25f);
+    float phi2 = 4.9f * fmaf(s1, c2, c1 * s2);
+    float phi1 = fmaf(-(s2 * B), fmaf(0.5f, B, A), fmaf(14.7f, s1, phi2));
+    float h = fmaf(-(0.5f * A), A * s2, tau - phi2);
+    float det = fmaf(1.25f, d1, -(d2 * d2));
+    float num = fmaf(h, d1, d2 * phi1);
+    float R = acrobot_recip_p_f32(d1 * det);
+    float ddth2 = num * (R * d1);
+    float ddth1 = -fmaf(d2, ddth2, phi1) * (R * det);
+    d[0] = A; d[1] = B; d[2] = ddth1; d[3] = ddth2;
 }
 
 static float wrap_f(float x, float m, float M) {
@@ -455,20 +468,20 @@ int ref_acrobot_step_f32(float *state, int a, float *obs6, float *reward) {
     float tau = (float)(a - 1);
     float k1[4], k2[4], k3[4], k4[4], y[4];
     acrobot_dsdt_f32(state, tau, k1);
-    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k1[i];
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k1[i], state[i]);
     acrobot_dsdt_f32(y, tau, k2);
-    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k2[i];
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k2[i], state[i]);
     acrobot_dsdt_f32(y, tau, k3);
-    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt * k3[i];
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(dt, k3[i], state[i]);
     acrobot_dsdt_f32(y, tau, k4);
-    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 6.0f, fmaf(2.0f, k3[i], fmaf(2.0f, k2[i], k1[i])) + k4[i], state[i]);
     y[0] = wrap_f(y[0], -PI_F, PI_F);
     y[1] = wrap_f(y[1], -PI_F, PI_F);
     y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
     y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
     for (int i = 0; i < 4; ++i) state[i] = y[i];
     ref_sincos_f32_kernel(y[0], &obs6[1], &obs6[0]); ref_sincos_f32_kernel(y[1], &obs6[3], &obs6[2]);
-    int done = (-obs6[0] - (obs6[0] * obs6[2] - obs6[1] * obs6[3])) > 1.0f;
+    int done = (-obs6[0] - fmaf(obs6[0], obs6[2], -(obs6[1] * obs6[3]))) > 1.0f;
     *reward = done ? 0.0f : -1.0f;
     obs6[4] = y[2]; obs6[5] = y[3];
     return done;
