@@ -531,11 +531,6 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     if (const char *e = std::getenv("GYMNET_VEC")) { int v = std::atoi(e); if (v == 1 || (v == 4 && can_vec4)) h->lcfg.vec = v; }
     if (const char *e = std::getenv("GYMNET_NT")) { int v = std::atoi(e); if (v == 0 || v == 12 || v == 15) h->lcfg.nt = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
-    // Acrobot (ALU-bound): the grid-stride kernel, `items` lanes per thread, when the batch is big enough to fill the chip
-    // with that many fewer threads
-    if (alu_bound && h->n >= ((int64_t)1 << 18)) h->lcfg.items = 4;
-    if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
-    if (const char *e = std::getenv("GYMNET_ITEMS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) h->lcfg.items = v; }
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = h;
@@ -755,13 +750,12 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     });
 }
 
-int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *items) {
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt) {
     return guarded([&]() -> int {
     if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
     if (vec) *vec = h->lcfg.vec;
     if (block) *block = h->lcfg.block;
     if (nt) *nt = h->lcfg.nt;
-    if (items) *items = (h->lcfg.items > 1 && h->lcfg.vec == 1 && !h->extras) ? h->lcfg.items : 1;
     return GYMNET_OK;
     });
 }

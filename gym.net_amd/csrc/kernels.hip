@@ -189,8 +189,10 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, float (&s)[Env::
 //   NT        non-temporal mask: 1 state loads, 2 state/obs stores, 4 action load, 8 reward/done stores
 // ---------------------------------------------------------------------------------------------
 //   GUARD     per-element bounds checks; only the last (partial) workgroup of a launch runs the guarded body
-// What one thread reads for its VEC lanes before it can advance them.  Split from the rest of the step so that the
-// grid-stride kernel below can have the NEXT lanes' loads in flight while it computes the current ones.
+// What one thread reads for its VEC lanes before it can advance them.  (Kept separate from the arithmetic: round 2 tried a
+// grid-stride kernel that had the NEXT lanes' loads in flight during the current lanes' arithmetic — slower on every env,
+// profiles/pipelined_kernel_probe_r02.txt: loads and stores share gfx9's in-order vmcnt, so waiting for a prefetch also
+// waits for the previous lanes' stores.)
 template <class Env, int VEC>
 struct LaneInputs {
     float s[Env::S][VEC];
@@ -333,35 +335,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     LaneInputs<Env, VEC> in;
     load_inputs<Env, VEC, AUTORESET, NT, GUARD>(a, i0, in);
     advance_and_store<Env, VEC, AUTORESET, EXTRAS, NT, GUARD>(a, i0, tick, in);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Grid-stride variant for the ALU-bound env (Acrobot).  The one-shot kernel above runs every wave in lock-step —
-// load, ~500 VALU of RK4, store — so the memory system idles while the ALUs work and the ALUs idle during the load and
-// store bursts of each of its two wave generations (14.7 us at 2^20 lanes against 10.6 us of memory time and ~8 us of VALU
-// issue time).  Here a thread owns several lanes (i, i + T, i + 2T, ...; still coalesced per trip) and software-pipelines
-// them: the next lane's five loads are issued BEFORE the current lane's arithmetic, and the current lane's stores drain
-// under the next lane's arithmetic.  Fewer, longer-lived waves also drift out of phase, which spreads the traffic over the
-// whole kernel.  Bit-identical to the one-shot kernel (same per-lane code, same Philox counters).
-// ---------------------------------------------------------------------------------------------
-template <class Env, bool AUTORESET, int NT>
-__global__ __launch_bounds__(256) void step_kernel_gs(const StepArgs a) {
-    const uint64_t tick = a.tick2[a.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
-    const int64_t T = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    LaneInputs<Env, 1> cur, nxt;
-    load_inputs<Env, 1, AUTORESET, NT, false>(a, i, cur);
-    for (;;) {
-        const int64_t j = i + T;
-        const bool more = j < a.n;
-        if (more) load_inputs<Env, 1, AUTORESET, NT, false>(a, j, nxt);
-        advance_and_store<Env, 1, AUTORESET, false, NT, false>(a, i, tick, cur);
-        if (!more) break;
-        cur = nxt;
-        i = j;
-    }
 }
 
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT>
@@ -708,16 +681,9 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     const int block = cfg.block;
-    if (cfg.items > 1 && !extras && cfg.vec == 1) {       // grid-stride, software-pipelined (ALU-bound envs)
-        const int64_t per_block = 256 * (int64_t)cfg.items;
-        const dim3 ggrid(grid_for(a.n > 0 ? (a.n + per_block - 1) / per_block * 256 : 256, 256)), gblk(256);
-        if (autoreset) hipLaunchKernelGGL((step_kernel_gs<Env, true, 15>), ggrid, gblk, 0, st, a);
-        else hipLaunchKernelGGL((step_kernel_gs<Env, false, 15>), ggrid, gblk, 0, st, a);
-        return hipGetLastError();
-    }
     const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
     const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
-#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, (size_t)cfg.lds_bytes, st, a)
+#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, 0, st, a)
 #define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
     do {                                                              \
         if (cfg.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);               \
@@ -741,7 +707,6 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
     if (cfg.vec != 4) cfg.vec = 1;
     if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
     if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
-    if (cfg.items < 1) cfg.items = 1;
     switch (env_id) {
         case 0: return launch_step_env<CartPole>(autoreset, extras, a, cfg, st);
         case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);

@@ -40,10 +40,7 @@ constexpr int kShards = 256;        // power of two
 constexpr int kCountStride = 16;    // uint32 words between shard counters (64 bytes: one counter per cache line)
 constexpr int kAfterStride = 8;     // uint64 words between after_done shards (64 bytes)
 
-// items: lanes per thread of the grid-stride, software-pipelined kernel (1 = the one-shot kernel: one thread, vec lanes)
-// lds_bytes: dynamic LDS requested per workgroup for the ONE purpose of capping occupancy (160 KiB per CU / lds_bytes
-// workgroups per CU); the kernels never touch it
-struct LaunchCfg { int vec; int block; int nt; int items = 1; int lds_bytes = 0; };
+struct LaunchCfg { int vec; int block; int nt; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

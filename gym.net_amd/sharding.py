@@ -118,6 +118,9 @@ class ShardedVectorEnv:
         self._last = 0                     # buffer gathered last
         self._pending = [None, None]       # per buffer: an unfinished overlapped gather (cuda event or Work)
         self._gstream = torch.cuda.Stream(self.tensor_device) if (self._cuda and self.overlap) else None
+        # events are created once and re-recorded: a fresh torch.cuda.Event per step costs more host time than the step kernel
+        self._ev_step = torch.cuda.Event() if self._gstream is not None else None
+        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()] if self._gstream is not None else None
 
     # ---- stepping -----------------------------------------------------------------------------------
     def _current_buffer(self):
@@ -171,15 +174,17 @@ class ShardedVectorEnv:
         if overlap and self.overlap:
             if self._cuda:
                 tc = self._torch.cuda
-                ev = tc.Event()
-                ev.record(tc.current_stream(self.tensor_device))
-                with tc.stream(self._gstream):
-                    self._gstream.wait_event(ev)              # the step that produced this buffer
+                main = tc.current_stream(self.tensor_device)
+                self._ev_step.record(main)
+                tc.set_stream(self._gstream)
+                try:
+                    self._gstream.wait_event(self._ev_step)   # the step that produced this buffer
                     work = gather(True)
                     work.wait()                               # side stream waits for RCCL's stream; the host does not
-                    done = tc.Event()
-                    done.record(self._gstream)
-                self._pending[b] = done
+                    self._ev_done[b].record(self._gstream)
+                finally:
+                    tc.set_stream(main)
+                self._pending[b] = self._ev_done[b]
             else:
                 self._pending[b] = gather(True)
             return None

@@ -220,10 +220,9 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
 int gymnet_vecenv_sync(gymnet_vecenv *h);
 int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
-/* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): envs per thread access
- * (1 / 4), threads per workgroup, non-temporal stream mask (0 / 12 / 15), and lanes per thread of the grid-stride,
- * software-pipelined kernel (1 = the one-shot kernel).  Any out pointer may be NULL. */
-int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *items);
+/* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): envs per thread (1 / 4),
+ * threads per workgroup, non-temporal stream mask (0 / 12 / 15).  Any out pointer may be NULL. */
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt);
 
 /* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
 /* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */

@@ -5,6 +5,7 @@ The reference pins nothing for CartPole (tests/Gym.Tests/Envs/Classic/CartpoleEn
 asserts nothing) => parity unpinned; these tests are what stands in for the missing pins.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ import pytest
 from oracle import numpy_ref as nr
 
 f32 = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_constants_are_the_float32_values_of_the_csharp_consts(oracle):
@@ -335,3 +337,25 @@ def test_reset_stream_is_uniform_across_lanes_and_across_ticks(oracle):
         x = sample[0].astype(np.float64)
         assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 4.0 / np.sqrt(x.size)
         assert np.abs(np.corrcoef(sample.astype(np.float64))[np.triu_indices(4, 1)]).max() < 4.0 / np.sqrt(x.size)
+
+
+def test_restatement_token_stream_equals_the_reference_text():
+    """oracle/check_against_reference.py: the C restatement's Step assignments, reward machine, Reset and constants against
+    the TEXT of CartPoleEnv.cs under /root/reference (build container only; the GPU box has no reference tree).  It does not
+    lift "parity unpinned" (nothing runs the C#), it removes transcription slips — and a seeded slip must be caught."""
+    import importlib.util
+    ref = "/root/reference/src/Gym.Environments/Envs/Classic/CartPoleEnv.cs"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    spec = importlib.util.spec_from_file_location("check_against_reference", os.path.join(ROOT, "oracle", "check_against_reference.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    assert chk.main() == 0
+    c = open(os.path.join(ROOT, "oracle", "classic_control_ref.c")).read()
+    want, _, integ = chk.reference_step(open(ref, encoding="utf-8-sig").read())
+    assert integ == "euler"
+    for a, b, var in (("costheta * temp)", "temp * costheta)", "thetaacc"), ("(double)CP_TAU * x_dot;", "(double)CP_TAU * xacc;", "x"),
+                      ("4.0 / 3.0", "(4.0 / 3.0)", "thetaacc"), ("x > (double)CP_X_THRESHOLD", "x >= (double)CP_X_THRESHOLD", "done")):
+        assert a in c
+        got, _ = chk.restatement_step(c.replace(a, b))
+        assert [v for v in chk.STEP_VARS if want[v] != got[v]] == [var], (a, b)
