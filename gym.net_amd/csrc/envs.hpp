@@ -254,7 +254,7 @@ struct Acrobot {
     //  - sincos without the OCML fallback (arguments are bounded here).
     // ~35 instructions + two sincos per stage instead of ~54 + two.  Mathematically identical to upstream; in float32 it
     // differs from the literal transcription by rounding only; the float64 oracle keeps upstream's literal formula and the
-    // float32 "kernel semantics" twin (oracle/classic_control_ref.c) mirrors THIS sequence operation for operation.
+    // float32 "kernel semantics" twin of the CPU test infrastructure mirrors THIS sequence operation for operation.
     // 1/P for P = d1 * det.  With c2 in [-1, 1]: d1 = c2 + 3.5 in [2.5, 4.5], det = 2.8125 - c2^2/4 in [2.5625, 2.8125], so
     // P lies in [6.4, 11.6] — no scaling, no special cases.  Quadratic minimax seed on [6.25, 11.75] (relative error 7.7e-3)
     // + two Newton steps r <- r + r(1 - P r): 6 full-rate fma instead of the 10-instruction IEEE division sequence around a

@@ -110,8 +110,7 @@ def reference_constants(text):
     return vals
 
 
-def main():
-    root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+def main(root="/root/reference"):
     path = os.path.join(root, REL)
     if not os.path.exists(path):
         print(f"reference not present at {path}: nothing to check (this guard only runs in the build container)")
@@ -156,4 +155,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(*sys.argv[1:2]))
