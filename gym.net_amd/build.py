@@ -14,9 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libgymnet_amd.so")
 SOURCES = ["kernels.hip", "capi.hip", "group.hip"]
 DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
-# -fno-slp-vectorize: on gfx950 a packed FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) occupies the SIMD for
-# ~4.9 cycles against ~2.35 for its scalar form (tools/valu_probe.hip, profiles/valu_probe_r02.txt): pairing two scalar
-# operations saves nothing and costs the v_mov shuffles that build the pairs (Acrobot: 465 -> 452 VALU per env-step).
+# -fno-slp-vectorize: on gfx950 a packed FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) occupies the SIMD about
+# as long as the two scalar instructions it replaces (~5 cycles against ~2.4 each in these kernels' instruction mix:
+# tools/acrobot_alu_probe.hip, tools/valu_probe.hip, profiles/*_r02.txt), so the compiler's opportunistic pairing saves
+# nothing and costs the v_mov shuffles that build the pairs (Acrobot harness: 465 VALU with it, 452 without; the four
+# bench kernels time the same either way).  Off = deterministic, purely scalar code generation.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
 

@@ -239,8 +239,8 @@ namespace gymnet {
 int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode) {
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
-    if (h->lcfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0))
-        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be 16-byte aligned");
+    if (h->lcfg.vec > 1 && (!aligned_to(d_actions, 4 * h->lcfg.vec) || (action_stride % h->lcfg.vec) != 0))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions and action_stride must be %d-byte aligned", 4 * h->lcfg.vec);
     const char *base = static_cast<const char *>(d_actions);
     auto slice = [&](int64_t t) -> const void * { return base + (size_t)((t % ring) * action_stride) * 4; };
     if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && !h->desc->box_action && steps > 0) {
@@ -528,8 +528,17 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
     else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
     if (!can_vec4) h->lcfg.vec = 1;
-    if (const char *e = std::getenv("GYMNET_VEC")) { int v = std::atoi(e); if (v == 1 || (v == 4 && can_vec4)) h->lcfg.vec = v; }
+    // Acrobot's wide form is TWO lanes per thread whose arithmetic rides the packed FP32 instructions (envs.hpp).  Opt-in
+    // (GYMNET_VEC=2): bit-identical, 287 instead of 454 VALU per env-step, and slower — 15.0 vs 14.2 us at 2^20 lanes, 13.6 vs
+    // 12.3 us per 2^20 lanes at 2^23 (profiles/acrobot_probes_r02.txt).
+    const bool can_vec2 = aligned_to(h->d_state, 8) && aligned_to(h->d_obs, 8) && (h->sstride % 2 == 0) && (h->ostride % 2 == 0) &&
+                          (!h->d_obs_alt || aligned_to(h->d_obs_alt, 8));
+    if (const char *e = std::getenv("GYMNET_VEC")) {
+        int v = std::atoi(e);
+        if (v == 1 || (v == 4 && can_vec4 && !alu_bound) || (v == 2 && can_vec2 && alu_bound)) h->lcfg.vec = v;
+    }
     if (const char *e = std::getenv("GYMNET_NT")) { int v = std::atoi(e); if (v == 0 || v == 12 || v == 15) h->lcfg.nt = v; }
+    if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -674,7 +683,8 @@ int gymnet_vecenv_step_device(gymnet_vecenv *h, const void *d_actions) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
-    if (h->lcfg.vec == 4 && !aligned16(d_actions)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions must be 16-byte aligned");
+    if (h->lcfg.vec > 1 && !aligned_to(d_actions, 4 * h->lcfg.vec))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions must be %d-byte aligned", 4 * h->lcfg.vec);
     ST_TRY(validate_staged_actions(h, d_actions));
     return launch_one_step(h, d_actions);
     });
@@ -699,7 +709,7 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     LaunchCfg cfg = h->lcfg;
     const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned16(rec->d_reward)) &&
                                  (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 3u) == 0));
-    if (cfg.vec == 4 && (!aligned16(d_actions) || (action_stride % 4) != 0 || (h->n % 4) != 0 || !rec_ok)) cfg.vec = 1;
+    if (cfg.vec > 1 && (!aligned_to(d_actions, 4 * cfg.vec) || (action_stride % cfg.vec) != 0 || (h->n % cfg.vec) != 0 || !rec_ok)) cfg.vec = 1;
     StepArgs a = make_step_args(h, d_actions);
     RolloutArgs r{};
     r.steps = steps; r.action_stride = action_stride; r.ring = ring;

@@ -25,6 +25,67 @@ namespace gymnet {
 // reproduces it BIT FOR BIT.  Measured against float64 sin/cos: |abs error| <= 9.3e-8 for every
 // |x| <= 1e5, <= 1.5 ulp for |x| <= 10.  sin(-0) returns +0.  |x| > 65536 (or inf) falls back to OCML.
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// One source for one env per lane (float) and TWO envs per lane (f2 = two floats in a VGPR pair, arithmetic on
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Each element of a packed operation is the same IEEE operation as its
+// scalar form: the two-lane code is bit-identical to running the scalar code twice (tests + the full-size checksum).
+// Not packed on this ISA (done per element): rint, float -> int conversion, integer / bit operations, selects.
+// MEASURED, and the reason the two-lane form is opt-in (GYMNET_VEC=2) rather than the default: it halves nothing that
+// matters.  The Acrobot step's arithmetic alone (tools/acrobot_alu_probe.hip, 8 waves per SIMD, no memory traffic) takes
+// 7.4 us per 2^20 env-steps as 454 scalar instructions (2.4 SIMD-cycles each in this mix) and 8.2 us as 287 packed + 287
+// scalar instructions per PAIR: a v_pk_*_f32 occupies the SIMD about as long as the two scalar instructions it replaces
+// (~5 cycles, tools/valu_probe.hip), and the per-element leftovers are not free.  DESIGN.md §4a.
+// ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+namespace vm {
+__device__ __forceinline__ float splat(float, float v) { return v; }
+__device__ __forceinline__ f2 splat(f2, float v) { return f2{v, v}; }
+__device__ __forceinline__ float fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f2 fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <class T> __device__ __forceinline__ T fmak(float k, T b, T c) { return fma(splat(b, k), b, c); }   // k*b + c
+template <class T> __device__ __forceinline__ T fmac(T a, T b, float k) { return fma(a, b, splat(a, k)); }   // a*b + k
+}  // namespace vm
+
+// quadrant fix-up of one element: sin x = {s, c, -s, -c}[q], cos x = {c, -s, -c, s}[q], q = n mod 4 (see sincos_f32)
+__device__ __forceinline__ void sincos_quadrant(float s, float c, float n, float &s_out, float &c_out) {
+    const uint32_t q = (uint32_t)(int)n;
+    const uint32_t q30 = q << 30, q31 = q << 31;
+    const bool odd = (int32_t)q31 < 0;
+    const float ss = odd ? c : s, cc = odd ? s : c;
+    s_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(ss), q30, 0x80000000u, 0x78));
+    c_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(cc), q30 ^ q31, 0x80000000u, 0x78));
+}
+
+// sincos_f32<true> for T = float or f2: the identical operation sequence per element (reduction and both polynomials on
+// the packed instructions for f2; rint and the quadrant logic per element).
+template <class T>
+__device__ __forceinline__ void sincos_bounded(T x, T &s_out, T &c_out) {
+    T n;
+    const T xs = x * vm::splat(x, 0.636619772367581343f);
+    if constexpr (sizeof(T) == sizeof(float)) n = rintf(xs);
+    else n = T{rintf(xs.x), rintf(xs.y)};
+    T r = vm::fmak(-1.5703125f, n, x);
+    r = vm::fmak(-4.837512969970703125e-4f, n, r);
+    r = vm::fmak(-7.54978995489188216e-8f, n, r);
+    const T z = r * r;
+    T ps = vm::fmac(vm::splat(z, -1.9515295891e-4f), z, 8.3321608736e-3f);
+    ps = vm::fmac(ps, z, -1.6666654611e-1f);
+    const T s = vm::fma(r * z, ps, r);
+    T pc = vm::fmac(vm::splat(z, 2.443315711809948e-5f), z, -1.388731625493765e-3f);
+    pc = vm::fmac(pc, z, 4.166664568298827e-2f);
+    const T c = vm::fma(z * z, pc, vm::fmac(vm::splat(z, -0.5f), z, 1.0f));
+    if constexpr (sizeof(T) == sizeof(float)) {
+        sincos_quadrant(s, c, n, s_out, c_out);
+    } else {
+        float s0, c0, s1, c1;
+        sincos_quadrant(s.x, c.x, n.x, s0, c0);
+        sincos_quadrant(s.y, c.y, n.y, s1, c1);
+        s_out = T{s0, s1};
+        c_out = T{c0, c1};
+    }
+}
+
 // BOUNDED = true drops the OCML fallback: for callers whose argument is bounded by construction (Acrobot's wrapped
 // angles and RK4 stage angles, |x| < 16).  Same bits as the full version for every |x| <= 65536; beyond that the result
 // is unspecified (finite garbage or NaN, never a hang).  It exists because the ten inlined Payne-Hanek fallbacks made the
@@ -37,27 +98,7 @@ __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) 
             return;
         }
     }
-    const float n = rintf(x * 0.636619772367581343f);                 // nearest multiple of pi/2
-    float r = fmaf(n, -1.5703125f, x);                                // pi/2 = 1.5703125 + 4.8375e-4 + 7.5498e-8
-    r = fmaf(n, -4.837512969970703125e-4f, r);
-    r = fmaf(n, -7.54978995489188216e-8f, r);
-    const float z = r * r;
-    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
-    const float s = fmaf(r * z, ps, r);                               // sin r
-    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));            // cos r
-    // quadrant: q = n mod 4.  sin x = {s, c, -s, -c}[q], cos x = {c, -s, -c, s}[q].  The signs go in as XORs of the sign bit
-    // (bit 1 of q for the sine, bit 1 of q+1 = bit1(q) ^ bit0(q) for the cosine) instead of compare + select pairs:
-    // same bits out (negation IS a sign-bit flip), three instructions fewer per call.
-    const uint32_t q = (uint32_t)(int)n;
-    const uint32_t q30 = q << 30, q31 = q << 31;
-    const bool odd = (int32_t)q31 < 0;
-    const float ss = odd ? c : s, cc = odd ? s : c;
-    // v_bitop3_b32 with truth table 0x78 = a ^ (b & c): one instruction per output
-    s_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(ss), q30, 0x80000000u, 0x78));
-    c_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(cc), q30 ^ q31, 0x80000000u, 0x78));
+    sincos_bounded<float>(x, s_out, c_out);
 }
 __device__ __forceinline__ float sin_f32(float x) { float s, c; sincos_f32(x, s, c); return s; }
 __device__ __forceinline__ float cos_f32(float x) { float s, c; sincos_f32(x, s, c); return c; }
@@ -85,6 +126,7 @@ struct CartPole {
     static constexpr bool OBS_ALIASES_STATE = true;
     static constexpr bool HAS_SBD = true;    // steps_beyond_done state machine  (:41,168-183)
     static constexpr bool BOX_ACTION = false;
+    static constexpr bool PACKED2 = false;   // no two-lane packed-FP32 form (the kernel is memory-bound)
     using Action = int32_t;                  // Discrete(2)                      (:47)
 
     // :24-36 — the float32 values of the C# consts (total_mass, polemass_length const-folded in float)
@@ -149,6 +191,7 @@ struct Pendulum {
     static constexpr bool OBS_ALIASES_STATE = false;
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = true;
+    static constexpr bool PACKED2 = false;
     using Action = float;                    // Box(-2, 2, (1,))
     static constexpr float PI = 3.14159265358979323846f;
 
@@ -199,6 +242,7 @@ struct MountainCar {
     static constexpr bool OBS_ALIASES_STATE = true;
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
+    static constexpr bool PACKED2 = false;
     using Action = int32_t;                  // Discrete(3)
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
@@ -236,15 +280,15 @@ struct Acrobot {
     static constexpr bool OBS_ALIASES_STATE = false;
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
+    static constexpr bool PACKED2 = true;    // step_observe_x2: two envs per thread on v_pk_*_f32
     using Action = int32_t;                  // Discrete(3): torque = a - 1
     static constexpr float PI = 3.14159265358979323846f;
 
     // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals.
-    // Acrobot is the one ALU-bound kernel of the four.  On gfx950 a wave64 FP32 VALU instruction occupies its SIMD for
-    // ~2.35 cycles whether it is v_fma_f32, v_mul_f32 or v_add_f32, and the packed forms (v_pk_fma_f32 ...) take ~4.9
-    // (measured: tools/valu_probe.hip, profiles/valu_probe_r02.txt) — packing two envs into one instruction buys nothing,
-    // and with 8 waves per SIMD resident the kernel already issues one VALU instruction every 2.5 cycles.  The only lever
-    // is the INSTRUCTION COUNT per env-step, so dsdt and the RK4 combination are written for it:
+    // Acrobot is the one kernel of the four with real arithmetic (RK4 = 4 x dsdt): ~7.4 us of VALU issue per 2^20 lanes
+    // against ~11.6 us of memory time for its 65 B per lane, in a launch of two lock-step wave generations where about half of
+    // the arithmetic ends up exposed.  The lever that works is the instruction count per env-step (682 -> 454 in round 2), so
+    // dsdt and the RK4 combination are written for it:
     //  - upstream's cos(th1 + th2 - pi/2) and cos(th1 - pi/2) are sin(th1 + th2) = s1*c2 + c1*s2 and sin(th1);
     //  - numerator and denominator of ddth2 are multiplied through by d1, so ONE reciprocal R = 1/(d1*det) serves both
     //    accelerations (1/det = R*d1, 1/d1 = R*det) instead of two IEEE divisions (11 instructions each), and that
@@ -258,30 +302,33 @@ struct Acrobot {
     // 1/P for P = d1 * det.  With c2 in [-1, 1]: d1 = c2 + 3.5 in [2.5, 4.5], det = 2.8125 - c2^2/4 in [2.5625, 2.8125], so
     // P lies in [6.4, 11.6] — no scaling, no special cases.  Quadratic minimax seed on [6.25, 11.75] (relative error 7.7e-3)
     // + two Newton steps r <- r + r(1 - P r): 6 full-rate fma instead of the 10-instruction IEEE division sequence around a
-    // quarter-rate v_rcp_f32.  Result within 0.55 ulp of 1/P over the whole range (2e6 random P, tools note in DESIGN.md),
+    // quarter-rate v_rcp_f32.  Result within 0.55 ulp of 1/P over the whole range (2e6 random P),
     // and — being fma only — reproduced bit for bit by the CPU restatement.
-    __device__ __forceinline__ static float recip_p(float P) {
-        float r = fmaf(fmaf(P, 0x1.82ab8p-10f, -0x1.4640b2p-5f), P, 0x1.6677a2p-2f);
-        r = fmaf(r, fmaf(-P, r, 1.0f), r);
-        r = fmaf(r, fmaf(-P, r, 1.0f), r);
+    template <class T>
+    __device__ __forceinline__ static T recip_p(T P) {
+        T r = vm::fmac(vm::fmac(P, vm::splat(P, 0x1.82ab8p-10f), -0x1.4640b2p-5f), P, 0x1.6677a2p-2f);
+        r = vm::fma(r, vm::fmac(-P, r, 1.0f), r);
+        r = vm::fma(r, vm::fmac(-P, r, 1.0f), r);
         return r;
     }
 
-    __device__ __forceinline__ static void dsdt(const float (&s)[4], float torque, float (&d)[4]) {
-        const float th1 = s[0], th2 = s[1], A = s[2], B = s[3];
-        float s1, c1, s2, c2;
-        sincos_f32<true>(th1, s1, c1);
-        sincos_f32<true>(th2, s2, c2);
-        const float d1 = c2 + 3.5f;                                   // 0.25 + (1.25 + c2) + 2
-        const float d2 = fmaf(0.5f, c2, 1.25f);                       // 0.25 + 0.5 c2 + 1
-        const float phi2 = 4.9f * fmaf(s1, c2, c1 * s2);              // m2 lc2 g sin(th1 + th2)
-        const float phi1 = fmaf(-(s2 * B), fmaf(0.5f, B, A), fmaf(14.7f, s1, phi2));   // -s2 B (B/2 + A) + 14.7 s1 + phi2
-        const float h = fmaf(-(0.5f * A), A * s2, torque - phi2);     // torque - A^2 s2 / 2 - phi2
-        const float det = fmaf(1.25f, d1, -(d2 * d2));                // (m2 lc2^2 + I2) d1 - d2^2
-        const float num = fmaf(h, d1, d2 * phi1);
-        const float R = recip_p(d1 * det);
-        const float ddth2 = num * (R * d1);
-        const float ddth1 = -fmaf(d2, ddth2, phi1) * (R * det);
+    // T = float: one env; T = f2: two envs of one thread, every line below one packed instruction per operation.
+    template <class T>
+    __device__ __forceinline__ static void dsdt(const T (&s)[4], T torque, T (&d)[4]) {
+        const T th1 = s[0], th2 = s[1], A = s[2], B = s[3];
+        T s1, c1, s2, c2;
+        sincos_bounded<T>(th1, s1, c1);
+        sincos_bounded<T>(th2, s2, c2);
+        const T d1 = c2 + vm::splat(c2, 3.5f);                                    // 0.25 + (1.25 + c2) + 2
+        const T d2 = vm::fmak(0.5f, c2, vm::splat(c2, 1.25f));                    // 0.25 + 0.5 c2 + 1
+        const T phi2 = vm::splat(s1, 4.9f) * vm::fma(s1, c2, c1 * s2);            // m2 lc2 g sin(th1 + th2)
+        const T phi1 = vm::fma(-(s2 * B), vm::fmak(0.5f, B, A), vm::fmak(14.7f, s1, phi2));   // -s2 B (B/2 + A) + 14.7 s1 + phi2
+        const T h = vm::fma(-(vm::splat(A, 0.5f) * A), A * s2, torque - phi2);    // torque - A^2 s2 / 2 - phi2
+        const T det = vm::fmak(1.25f, d1, -(d2 * d2));                            // (m2 lc2^2 + I2) d1 - d2^2
+        const T num = vm::fma(h, d1, d2 * phi1);
+        const T R = recip_p<T>(d1 * det);
+        const T ddth2 = num * (R * d1);
+        const T ddth1 = -vm::fma(d2, ddth2, phi1) * (R * det);
         d[0] = A; d[1] = B; d[2] = ddth1; d[3] = ddth2;
     }
 
@@ -293,36 +340,77 @@ struct Acrobot {
         return x;
     }
 
-    // One RK4 step; the sin/cos of the new angles serve both the termination test and the observation.
-    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
-        const float dt = 0.2f, mv1 = 4.0f * PI, mv2 = 9.0f * PI;
-        const float torque = (float)(a - 1);
-        float k1[4], k2[4], k3[4], k4[4], y[4];
-        dsdt(s, torque, k1);
+    // One RK4 step of dt = 0.2 with the torque held constant: y <- s + dt/6 (k1 + 2 k2 + 2 k3 + k4), 4 fma per component.
+    template <class T>
+    __device__ __forceinline__ static void rk4(const T (&s)[4], T torque, T (&y)[4]) {
+        constexpr float dt = 0.2f;
+        T k1[4], k2[4], k3[4], k4[4];
+        dsdt<T>(s, torque, k1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k1[i], s[i]);
-        dsdt(y, torque, k2);
+        for (int i = 0; i < 4; ++i) y[i] = vm::fmak(dt / 2.0f, k1[i], s[i]);
+        dsdt<T>(y, torque, k2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 2.0f, k2[i], s[i]);
-        dsdt(y, torque, k3);
+        for (int i = 0; i < 4; ++i) y[i] = vm::fmak(dt / 2.0f, k2[i], s[i]);
+        dsdt<T>(y, torque, k3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt, k3[i], s[i]);
-        dsdt(y, torque, k4);
+        for (int i = 0; i < 4; ++i) y[i] = vm::fmak(dt, k3[i], s[i]);
+        dsdt<T>(y, torque, k4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(dt / 6.0f, fmaf(2.0f, k3[i], fmaf(2.0f, k2[i], k1[i])) + k4[i], s[i]);
+        for (int i = 0; i < 4; ++i) y[i] = vm::fmak(dt / 6.0f, vm::fmak(2.0f, k3[i], vm::fmak(2.0f, k2[i], k1[i])) + k4[i], s[i]);
+    }
+
+    // wrap the angles, clamp the velocities (per element: compares and selects have no packed form)
+    __device__ __forceinline__ static void wrap_clamp(float (&y)[4]) {
+        constexpr float mv1 = 4.0f * PI, mv2 = 9.0f * PI;
         y[0] = wrap(y[0], -PI, PI);
         y[1] = wrap(y[1], -PI, PI);
         y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
         y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+    }
+
+    // One env: RK4, wrap / clamp; the sin/cos of the new angles serve both the termination test and the observation.
+    __device__ __forceinline__ static void step_observe(float (&s)[S], Action a, float &reward, bool &done, float (&o)[O]) {
+#ifdef GYMNET_PROBE_ACROBOT_NOMATH   // probe builds only: the kernel's memory traffic with (almost) no arithmetic
+        { const float t = (float)(a - 1) * 1e-3f; s[0] += t; s[1] -= t; s[2] += t; s[3] -= t;
+          done = s[0] > 3.0f; reward = -1.0f; o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; o[4] = s[2]; o[5] = s[3]; return; }
+#endif
+        float y[4];
+        rk4<float>(s, (float)(a - 1), y);
+        wrap_clamp(y);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = y[i];
         // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2
         float s1, c1, s2, c2;
-        sincos_f32<true>(y[0], s1, c1);
-        sincos_f32<true>(y[1], s2, c2);
+        sincos_bounded<float>(y[0], s1, c1);
+        sincos_bounded<float>(y[1], s2, c2);
         done = (-c1 - fmaf(c1, c2, -(s1 * s2))) > 1.0f;
         reward = done ? 0.0f : -1.0f;
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = y[2]; o[5] = y[3];
+    }
+
+    // TWO envs of one thread at once (kernels.hip: advance_all with VEC == 2): the same operations as step_observe, the
+    // arithmetic of both envs in the two halves of packed registers.  Bit-identical to two step_observe calls.
+    __device__ __forceinline__ static void step_observe_x2(float (&s)[S][2], Action (&a)[2], float (&reward)[2], bool (&done)[2],
+                                                           float (&o)[O][2]) {
+        f2 sv[4], yv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = f2{s[i][0], s[i][1]};
+        rk4<f2>(sv, f2{(float)(a[0] - 1), (float)(a[1] - 1)}, yv);
+        float y0[4], y1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { y0[i] = yv[i].x; y1[i] = yv[i].y; }
+        wrap_clamp(y0);
+        wrap_clamp(y1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[i][0] = y0[i]; s[i][1] = y1[i]; }
+        f2 s1, c1, s2, c2;
+        sincos_bounded<f2>(f2{y0[0], y1[0]}, s1, c1);
+        sincos_bounded<f2>(f2{y0[1], y1[1]}, s2, c2);
+        const f2 t = -c1 - vm::fma(c1, c2, -(s1 * s2));
+        done[0] = t.x > 1.0f; done[1] = t.y > 1.0f;
+        reward[0] = done[0] ? 0.0f : -1.0f; reward[1] = done[1] ? 0.0f : -1.0f;
+        o[0][0] = c1.x; o[0][1] = c1.y; o[1][0] = s1.x; o[1][1] = s1.y; o[2][0] = c2.x; o[2][1] = c2.y;
+        o[3][0] = s2.x; o[3][1] = s2.y; o[4][0] = y0[2]; o[4][1] = y1[2]; o[5][0] = y0[3]; o[5][1] = y1[3];
     }
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {

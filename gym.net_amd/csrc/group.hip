@@ -368,7 +368,8 @@ int gymnet_group_step_device(gymnet_group *g, const void *const *d_actions) {
     if (!d_actions) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     for (int m = 0; m < g->G; ++m) {
         if (!d_actions[m]) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_actions[%d] is null", m);
-        if (g->members[m]->lcfg.vec == 4 && !aligned16(d_actions[m])) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_actions[%d] must be 16-byte aligned", m);
+        if (g->members[m]->lcfg.vec > 1 && !aligned_to(d_actions[m], 4 * g->members[m]->lcfg.vec))
+            return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_actions[%d] must be %d-byte aligned", m, 4 * g->members[m]->lcfg.vec);
     }
     if (g->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS)     // Discrete.Contains over the WHOLE batch before any member changes state
         for (int m = 0; m < g->G; ++m) {

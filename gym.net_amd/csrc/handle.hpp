@@ -78,7 +78,7 @@ struct gymnet_vecenv {
     int last_cparity = -1;
     bool async_pending = false;
     std::atomic<bool> busy{false};
-    gymnet::LaunchCfg lcfg{4, 256, 0};
+    gymnet::LaunchCfg lcfg{4, 256, 0, 0};
     std::vector<gymnet::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     std::vector<void *> owned;     // device allocations to free
@@ -149,6 +149,7 @@ int guarded(F &&f) noexcept {
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned_to(const void *p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
 
 // ---- helpers that assume the caller already ENTERed the handle (device set, busy flag held) ----------------------
 int launch_one_step(gymnet_vecenv *h, const void *d_actions);       // one vector step = one kernel launch

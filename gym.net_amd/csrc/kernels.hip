@@ -29,8 +29,20 @@ namespace gymnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+
 template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0, int64_t n, float (&v)[VEC]) {
+    if constexpr (VEC == 2) {
+        if (!GUARD || i0 + 2 <= n) {
+            f32x2 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p + i0));
+            else t = *reinterpret_cast<const f32x2 *>(p + i0);
+            v[0] = t.x; v[1] = t.y;
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (!GUARD || i0 + 4 <= n) {
             f32x4 t;
@@ -49,6 +61,14 @@ __device__ __forceinline__ void load_f32(const float *__restrict__ p, int64_t i0
 
 template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int64_t n, const float (&v)[VEC]) {
+    if constexpr (VEC == 2) {
+        if (!GUARD || i0 + 2 <= n) {
+            f32x2 t; t.x = v[0]; t.y = v[1];
+            if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p + i0));
+            else *reinterpret_cast<f32x2 *>(p + i0) = t;
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (!GUARD || i0 + 4 <= n) {
             f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
@@ -64,6 +84,15 @@ __device__ __forceinline__ void store_f32(float *__restrict__ p, int64_t i0, int
 
 template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t i0, int64_t n, int32_t (&v)[VEC]) {
+    if constexpr (VEC == 2) {
+        if (!GUARD || i0 + 2 <= n) {
+            i32x2 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(p + i0));
+            else t = *reinterpret_cast<const i32x2 *>(p + i0);
+            v[0] = t.x; v[1] = t.y;
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (!GUARD || i0 + 4 <= n) {
             i32x4 t;
@@ -82,6 +111,14 @@ __device__ __forceinline__ void load_i32(const int32_t *__restrict__ p, int64_t 
 
 template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, int64_t n, const int32_t (&v)[VEC]) {
+    if constexpr (VEC == 2) {
+        if (!GUARD || i0 + 2 <= n) {
+            i32x2 t; t.x = v[0]; t.y = v[1];
+            if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<i32x2 *>(p + i0));
+            else *reinterpret_cast<i32x2 *>(p + i0) = t;
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (!GUARD || i0 + 4 <= n) {
             i32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
@@ -97,6 +134,14 @@ __device__ __forceinline__ void store_i32(int32_t *__restrict__ p, int64_t i0, i
 
 template <int VEC, bool NT, bool GUARD>
 __device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, int64_t n, const uint8_t (&v)[VEC]) {
+    if constexpr (VEC == 2) {
+        if (!GUARD || i0 + 2 <= n) {
+            const uint16_t w = (uint16_t)((uint16_t)v[0] | ((uint16_t)v[1] << 8));
+            if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint16_t *>(p + i0));
+            else *reinterpret_cast<uint16_t *>(p + i0) = w;
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (!GUARD || i0 + 4 <= n) {
             const uint32_t w = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
@@ -141,6 +186,38 @@ __device__ __forceinline__ void advance_sublane(float (&sj)[Env::S], typename En
         if (dn) {
             if (sbd == -1) { sbd = 0; }
             else { after = in_range; sbd += 1; rw = 0.0f; }
+        }
+    }
+}
+
+// One env-step of ALL VEC sub-lanes of a thread.  Generic: sub-lane after sub-lane.  Envs that provide a two-lane packed
+// form (Acrobot: both envs of a thread ride the v_pk_*_f32 instructions, envs.hpp) take it when VEC == 2; per element the
+// arithmetic is the same IEEE sequence, so the results are bit-identical to the sub-lane loop.
+template <class Env, int VEC, bool AUTORESET, bool GUARD>
+__device__ __forceinline__ void advance_all(float (&s)[Env::S][VEC], typename Env::Action (&act)[VEC], int32_t (&sbd)[VEC],
+                                            float (&rw)[VEC], bool (&dn)[VEC], bool (&after)[VEC], float (&o)[Env::O][VEC],
+                                            int64_t i0, int64_t n) {
+    constexpr int S = Env::S, O = Env::O;
+#ifndef GYMNET_PROBE_NO_PACK      // probe builds only: two lanes per thread, scalar arithmetic
+    constexpr bool kPack = true;
+#else
+    constexpr bool kPack = false;
+#endif
+    if constexpr (Env::PACKED2 && VEC == 2 && kPack) {
+        Env::step_observe_x2(s, act, rw, dn, o);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float sj[S], oj[O];
+#pragma unroll
+            for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw[j], dn[j], after[j], !GUARD || i0 + j < n, oj);
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+            if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                for (int k = 0; k < O; ++k) o[k][j] = oj[k];
+            }
         }
     }
 }
@@ -239,17 +316,14 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
     float o[O][VEC];
     uint32_t pending = 0;     // sub-lanes of this thread that finished and await their reset draw
 
+    float rwv[VEC];
+    bool dnv[VEC];
+    advance_all<Env, VEC, AUTORESET, GUARD>(s, act, sbd, rwv, dnv, after, o, i0, n);
+
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        float sj[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) sj[k] = s[k][j];
-        bool dn;
-        float rw;
-        float oj[O];
-        advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n, oj);
-
-        uint8_t db = dn ? 1 : 0;
+        const float rw = rwv[j];
+        uint8_t db = dnv[j] ? 1 : 0;
         if constexpr (EXTRAS) {
             if (stats) {
                 ep_ret[j] += rw;
@@ -265,7 +339,7 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
         if constexpr (EXTRAS) {
             if (fin && a.final_obs && (!GUARD || i0 + j < n)) {
 #pragma unroll
-                for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? sj[k < S ? k : 0] : oj[k];
+                for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
             }
             if (stats && fin && (!GUARD || i0 + j < n)) {
                 a.fin_ret[i0 + j] = ep_ret[j];
@@ -275,13 +349,6 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
         }
 
         if constexpr (AUTORESET) pending |= fin ? (1u << j) : 0u;
-
-#pragma unroll
-        for (int k = 0; k < S; ++k) s[k][j] = sj[k];
-        if constexpr (!Env::OBS_ALIASES_STATE) {
-#pragma unroll
-            for (int k = 0; k < O; ++k) o[k][j] = oj[k];
-        }
     }
 
     if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
@@ -399,24 +466,12 @@ __device__ __forceinline__ void rollout_body(const StepArgs &a, const RolloutArg
         bool after[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) after[j] = false;
+        bool dnv[VEC];
+        advance_all<Env, VEC, AUTORESET, GUARD>(s, act, sbd, reward, dnv, after, o, i0, n);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float sj[S];
-#pragma unroll
-            for (int k = 0; k < S; ++k) sj[k] = s[k][j];
-            bool dn;
-            float rw;
-            float oj[O];
-            advance_sublane<Env, AUTORESET>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n, oj);
-            done[j] = dn ? 1 : 0;
-            reward[j] = rw;
-            if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
-#pragma unroll
-            for (int k = 0; k < S; ++k) s[k][j] = sj[k];
-            if constexpr (!Env::OBS_ALIASES_STATE) {
-#pragma unroll
-                for (int k = 0; k < O; ++k) o[k][j] = oj[k];
-            }
+            done[j] = dnv[j] ? 1 : 0;
+            if constexpr (AUTORESET) pending |= dnv[j] ? (1u << j) : 0u;
         }
         if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
         if (ro.rec_reward) store_f32<VEC, true, GUARD>(ro.rec_reward + t * n, i0, n, reward);
@@ -681,9 +736,13 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     const int block = cfg.block;
-    const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
+    // the wide form of an env: four lanes per thread on dwordx4 streams, or — for the env with a two-lane packed-FP32 form
+    // (Acrobot) — two lanes per thread on dwordx2 streams
+    constexpr int WIDE = Env::PACKED2 ? 2 : 4;
+    const bool wide = cfg.vec > 1;
+    const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
     const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
-#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, 0, st, a)
+#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, (size_t)cfg.lds_bytes, st, a)
 #define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
     do {                                                              \
         if (cfg.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);               \
@@ -691,10 +750,10 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
         else GYMNET_LAUNCH(V, AR, EX, 0);                             \
     } while (0)
     if (extras) {   // bookkeeping variants follow the same stream policy (their own arrays stay cacheable)
-        if (cfg.vec == 4) { if (autoreset) GYMNET_LAUNCH_NT(4, true, true); else GYMNET_LAUNCH_NT(4, false, true); }
-        else              { if (autoreset) GYMNET_LAUNCH_NT(1, true, true); else GYMNET_LAUNCH_NT(1, false, true); }
-    } else if (cfg.vec == 4) {
-        if (autoreset) GYMNET_LAUNCH_NT(4, true, false); else GYMNET_LAUNCH_NT(4, false, false);
+        if (wide) { if (autoreset) GYMNET_LAUNCH_NT(WIDE, true, true); else GYMNET_LAUNCH_NT(WIDE, false, true); }
+        else      { if (autoreset) GYMNET_LAUNCH_NT(1, true, true); else GYMNET_LAUNCH_NT(1, false, true); }
+    } else if (wide) {
+        if (autoreset) GYMNET_LAUNCH_NT(WIDE, true, false); else GYMNET_LAUNCH_NT(WIDE, false, false);
     } else {
         if (autoreset) GYMNET_LAUNCH_NT(1, true, false); else GYMNET_LAUNCH_NT(1, false, false);
     }
@@ -704,7 +763,7 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
 }
 
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
-    if (cfg.vec != 4) cfg.vec = 1;
+    if (cfg.vec != 4 && cfg.vec != 2) cfg.vec = 1;
     if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
     if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
     switch (env_id) {
@@ -718,11 +777,13 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
 
 template <class Env>
 static hipError_t launch_rollout_env(bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st) {
-    const int64_t threads = (a.n + cfg.vec - 1) / cfg.vec;
+    constexpr int WIDE = Env::PACKED2 ? 2 : 4;
+    const bool wide = cfg.vec > 1;
+    const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
     const dim3 grid(grid_for(threads > 0 ? threads : 1, 256)), blk(256);
-    if (cfg.vec == 4) {
-        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, 4, true>), grid, blk, 0, st, a, r);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 4, false>), grid, blk, 0, st, a, r);
+    if (wide) {
+        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, WIDE, true>), grid, blk, 0, st, a, r);
+        else hipLaunchKernelGGL((rollout_kernel<Env, WIDE, false>), grid, blk, 0, st, a, r);
     } else {
         if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, 1, true>), grid, blk, 0, st, a, r);
         else hipLaunchKernelGGL((rollout_kernel<Env, 1, false>), grid, blk, 0, st, a, r);
@@ -731,7 +792,7 @@ static hipError_t launch_rollout_env(bool autoreset, const StepArgs &a, const Ro
 }
 
 hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st) {
-    if (cfg.vec != 4) cfg.vec = 1;
+    if (cfg.vec != 4 && cfg.vec != 2) cfg.vec = 1;
     switch (env_id) {
         case 0: return launch_rollout_env<CartPole>(autoreset, a, r, cfg, st);
         case 1: return launch_rollout_env<Pendulum>(autoreset, a, r, cfg, st);

@@ -40,7 +40,8 @@ constexpr int kShards = 256;        // power of two
 constexpr int kCountStride = 16;    // uint32 words between shard counters (64 bytes: one counter per cache line)
 constexpr int kAfterStride = 8;     // uint64 words between after_done shards (64 bytes)
 
-struct LaunchCfg { int vec; int block; int nt; };
+// lds_bytes: unused dynamic LDS requested per workgroup, for the ONE purpose of capping occupancy in probes (GYMNET_LDS)
+struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

@@ -214,3 +214,40 @@ def test_scalar_broadcast_on_a_box_action_space(gpu_pkg):
             assert np.array_equal(oa.Observation, ob.Observation) and np.array_equal(oa.Reward, ob.Reward)
         oc = a.StepAsync(1).Result(); od = b.Step(np.ones(n, np.float32))
         assert np.array_equal(oc.Observation, od.Observation)
+
+
+def test_acrobot_two_lanes_per_thread_on_packed_fp32_is_bit_identical(gpu_pkg, monkeypatch):
+    """GYMNET_VEC=2: both envs of a thread ride the v_pk_*_f32 instructions (envs.hpp step_observe_x2, dwordx2 streams).  Per
+    element it is the same IEEE sequence, so everything must equal the one-lane form bit for bit: one-launch steps with an
+    odd lane count (guarded tail), the bookkeeping variant, the fused rollout, with and without auto-reset.  (Opt-in, not the
+    default: it halves the VALU count and is still slower — DESIGN.md §4a.)"""
+    import torch
+    n, ring = 8192 + 7, 6
+    out = {}
+    for vec in (1, 2):
+        monkeypatch.setenv("GYMNET_VEC", str(vec))
+        res = []
+        for auto, stats in ((True, False), (False, False), (True, True)):
+            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats) as env:
+                assert env.LaunchPolicy()["envs_per_thread"] == vec
+                acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                for t in range(ring):
+                    env.SampleActionsDevice(acts[t], seed=5, tick=t)
+                env.ResetDevice()
+                rng = np.random.default_rng(4)
+                s0 = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
+                env.SetState(s0)                                    # fast states: wraps, clamps and terminations all happen
+                env.RolloutDevice(acts, 40, n + (n % 2), ring)
+                if not stats:
+                    env.RolloutFusedDevice(acts, 25, n + (n % 2), ring)
+                env.Sync()
+                r = env.Read()
+                res.append((env.GetState(), r.Observation, r.Reward, r.Done, env.EpisodeStats() if stats else None))
+        out[vec] = res
+    for a, b in zip(out[1], out[2]):
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y, equal_nan=True)
+        if a[4] is not None:
+            assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])
+    assert out[1][0][3].any() or out[1][1][3].any()

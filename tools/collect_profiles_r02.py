@@ -20,7 +20,8 @@ G = os.path.join(ROOT, "gpurun_out", "p2")
 # on the GPU box the databases are too big to travel back (64 MiB cap): summarise THERE into gpurun_out/p2/summary, copy here
 P = os.environ.get("GYMNET_PROFILES_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
-BYTES = {"CartPole-v1": 41, "Pendulum-v1": 37, "MountainCar-v0": 25, "Acrobot-v1": 65}
+BYTES = {"CartPole-v1": 41, "Pendulum-v1": 37, "MountainCar-v0": 25, "Acrobot-v1": 65, "Acrobot-v1-packed": 65}
+LANES = {"CartPole-v1": 4, "Pendulum-v1": 4, "MountainCar-v0": 4, "Acrobot-v1": 1, "Acrobot-v1-packed": 2}
 
 
 def capture(fn, *a):
@@ -52,7 +53,7 @@ for env, b in BYTES.items():
     d = os.path.join(G, env)
     db = os.path.join(d, "stats", "s_results.db")
     if os.path.exists(db):
-        stats_out.append(f"## rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras --env {env}\n")
+        stats_out.append(f"## rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras --env {env.replace('-packed', '   (GYMNET_VEC=2: two lanes per thread on packed FP32)')}\n")
         stats_out.append(capture(rocpd_summary.stats, db))
         line = bench_line(os.path.join(d, "stats.log"))
         if line:
@@ -68,7 +69,8 @@ for env, b in BYTES.items():
             vals[cn] = avg(pdb, cn)
     if len(vals) == 2 and None not in vals.values():
         tr = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
-        traffic.setdefault(env, {})["1048576"] = tr
+        if not env.endswith("-packed"):
+            traffic.setdefault(env, {})["1048576"] = tr
         pmc_out.append(f"## {env}: HBM-side traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB = {tr:.0f} B; algorithmic {b} B x 2^20 = {b << 20} B; ratio {tr / (b << 20):.3f}\n\n")
     sq = os.path.join(d, "SQ", "pmc_results.db")
     if os.path.exists(sq):
@@ -76,7 +78,7 @@ for env, b in BYTES.items():
         pmc_out.append(capture(rocpd_summary.pmc, sq))
         iv, wv = avg(sq, "SQ_INSTS_VALU"), avg(sq, "SQ_WAVES")
         if iv and wv:
-            vec = 4 if env != "Acrobot-v1" else 1
+            vec = LANES[env]
             pmc_out.append(f"## {env}: SQ_INSTS_VALU / SQ_WAVES = {iv / wv:.1f} VALU instructions per wave = {iv / wv / vec:.1f} per env-step "
                            f"({vec} env(s) per lane)\n\n")
 traffic["_source"] = f"profiles/rocprof_pmc_{tag}.txt: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes"

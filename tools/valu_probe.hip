@@ -1,6 +1,6 @@
 // valu_probe.hip — ground truth for the Acrobot kernel's ALU budget on gfx950: how many cycles does a wave64 FP32 VALU
 // instruction occupy its SIMD, and do the packed forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) move two floats per
-// lane in the same slot?   hipcc --offload-arch=gfx950 -O3 -o tools/valu_probe tools/valu_probe.hip
+// lane in the same slot?   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o tools/valu_probe tools/valu_probe.hip   (SLP off so that the scalar rows stay scalar)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
