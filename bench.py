@@ -251,15 +251,22 @@ def main():
     # barrier: a shared-memory spin barrier between the node's ranks when it can be set up, else the process group's
     node_barrier = None
     if use_dist and os.environ.get("GYMNET_BENCH_BARRIER", "shm") == "shm":
+        ok, nb = 1, None
         try:
             nb = NodeBarrier(rank, world, os.environ.get("MASTER_PORT", "0"))
-            dist.barrier()                                   # rank 0 has created the file
-            nb.attach()
-            dist.barrier()
+        except Exception:
+            ok = 0
+        dist.barrier()                                       # rank 0 has created the file
+        try:
+            if ok:
+                nb.attach()
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank uses the same kind of barrier, or none does
+        if int(flag[0]) == 1:
             nb()                                             # and it works
             node_barrier = nb
-        except Exception:
-            node_barrier = None
 
     def barrier():
         if node_barrier is not None:
