@@ -116,7 +116,8 @@ PROTOTYPES = {
     "gymnet_vecenv_pack_obs_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_sync": (C.c_int, [_H]),
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),
-    "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32)]),
     "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_set_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_get_steps_beyond_done": (C.c_int, [_H, _P]),

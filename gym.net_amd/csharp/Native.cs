@@ -100,7 +100,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_pack_obs_device(IntPtr h, IntPtr d_obs_rowmajor);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sync(IntPtr h);
         [DllImport(Lib)] public static extern int gymnet_vecenv_device_view(IntPtr h, out GymnetDeviceView view);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_launch_policy(IntPtr h, out int vec, out int block, out int nt);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_launch_policy(IntPtr h, out int vec, out int block, out int nt, out int sequential_lanes);
 
         // ---- state access / bookkeeping
         [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, float* state_soa);

@@ -538,6 +538,13 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         if (v == 1 || (v == 4 && can_vec4 && !alu_bound) || (v == 2 && can_vec2 && alu_bound)) h->lcfg.vec = v;
     }
     if (const char *e = std::getenv("GYMNET_NT")) { int v = std::atoi(e); if (v == 0 || v == 12 || v == 15) h->lcfg.nt = v; }
+    // Acrobot's multi-lane kernel (step_kernel_pipe: all loads first, then compute / store lane after lane) wins where the
+    // one-shot kernel would run as ~2 lock-step wave generations: it turns the launch into ONE generation of 4096 waves whose
+    // stores drain under the next lane's arithmetic.  Measured (profiles/acrobot_probes_r02.txt, us per 2^20 lanes, one-shot
+    // vs k = ceil(n / 2^18) lanes per thread): n = 2^19 15.1 vs 14.5, 3*2^18 13.9 vs 13.9, 2^20 14.9 vs 13.1, 5*2^18 13.7 vs
+    // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
+    if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
+    if (const char *e = std::getenv("GYMNET_ITEMS")) { int v = std::atoi(e); if (v >= 1 && v <= 5) h->lcfg.items = v; }
     if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY
@@ -760,12 +767,13 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     });
 }
 
-int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt) {
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *sequential_lanes) {
     return guarded([&]() -> int {
     if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
     if (vec) *vec = h->lcfg.vec;
     if (block) *block = h->lcfg.block;
     if (nt) *nt = h->lcfg.nt;
+    if (sequential_lanes) *sequential_lanes = (h->cfg.env_id == GYMNET_ENV_ACROBOT && h->lcfg.items > 1 && h->lcfg.vec == 1 && !h->extras) ? h->lcfg.items : 1;
     return GYMNET_OK;
     });
 }

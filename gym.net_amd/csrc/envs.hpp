@@ -127,6 +127,7 @@ struct CartPole {
     static constexpr bool HAS_SBD = true;    // steps_beyond_done state machine  (:41,168-183)
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = false;   // no two-lane packed-FP32 form (the kernel is memory-bound)
+    static constexpr bool PIPELINED = false; // no software-pipelined multi-lane kernel (ditto)
     using Action = int32_t;                  // Discrete(2)                      (:47)
 
     // :24-36 — the float32 values of the C# consts (total_mass, polemass_length const-folded in float)
@@ -192,6 +193,7 @@ struct Pendulum {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = true;
     static constexpr bool PACKED2 = false;
+    static constexpr bool PIPELINED = false;
     using Action = float;                    // Box(-2, 2, (1,))
     static constexpr float PI = 3.14159265358979323846f;
 
@@ -243,6 +245,7 @@ struct MountainCar {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = false;
+    static constexpr bool PIPELINED = false;
     using Action = int32_t;                  // Discrete(3)
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
@@ -281,6 +284,7 @@ struct Acrobot {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = true;    // step_observe_x2: two envs per thread on v_pk_*_f32
+    static constexpr bool PIPELINED = true;  // step_kernel_pipe: ITEMS lanes per thread, loads / arithmetic / stores overlapped
     using Action = int32_t;                  // Discrete(3): torque = a - 1
     static constexpr float PI = 3.14159265358979323846f;
 
@@ -332,11 +336,15 @@ struct Acrobot {
         d[0] = A; d[1] = B; d[2] = ddth1; d[3] = ddth2;
     }
 
+    // upstream loops `while x > M: x -= diff` / `while x < m: x += diff`.  One RK4 step of dt = 0.2 moves a clamped state by at
+    // most ~10 rad, i.e. two wraps; this is the same repeated subtraction, at most FOUR times per direction and written
+    // without a loop: identical results whenever four suffice (every state the dynamics can produce), a non-finite or
+    // absurd state cannot hang the GPU, and — no back-edge — the compiler's s_waitcnt bookkeeping stays exact across the
+    // step (a loop here made it fall back to vmcnt(0) after every lane of the software-pipelined kernel).
     __device__ __forceinline__ static float wrap(float x, float m, float M) {
-        // upstream loops `while x > M: x -= diff`; bounded here so a non-finite state cannot hang the GPU
         const float diff = M - m;
-        for (int it = 0; it < 64 && x > M; ++it) x -= diff;
-        for (int it = 0; it < 64 && x < m; ++it) x += diff;
+        if (x > M) { x -= diff; if (x > M) { x -= diff; if (x > M) { x -= diff; if (x > M) x -= diff; } } }
+        if (x < m) { x += diff; if (x < m) { x += diff; if (x < m) { x += diff; if (x < m) x += diff; } } }
         return x;
     }
 

@@ -78,7 +78,7 @@ struct gymnet_vecenv {
     int last_cparity = -1;
     bool async_pending = false;
     std::atomic<bool> busy{false};
-    gymnet::LaunchCfg lcfg{4, 256, 0, 0};
+    gymnet::LaunchCfg lcfg{4, 256, 0, 0, 1};
     std::vector<gymnet::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     std::vector<void *> owned;     // device allocations to free

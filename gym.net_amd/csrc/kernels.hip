@@ -404,6 +404,90 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int64_t i0, c
     advance_and_store<Env, VEC, AUTORESET, EXTRAS, NT, GUARD>(a, i0, tick, in);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-lane variant for the env with real arithmetic (Acrobot).  The one-shot kernel runs its (two) wave generations
+// nearly in lock-step — load burst, ~450 VALU, store burst — so at 2^20 lanes about half of the arithmetic and the head /
+// tail bursts are exposed.  Here a thread owns ITEMS lanes (i, i + T, ..., coalesced per item), fully unrolled:
+//     issue the loads of ALL its lanes | compute lane 0 | (all loads have landed) store lane 0 | compute lane 1 | store 1 ...
+// so lane k's stores drain under lane k+1's arithmetic and only the first lane's loads and the last lane's stores are
+// exposed.  The shape is dictated by how the compiler must treat gfx9's single vmcnt: with loads AND stores pending it
+// has to assume out-of-order completion and emits vmcnt(0) — a real software pipeline (prefetch lane k+2 while computing
+// lane k) therefore stalls on the previous lane's stores every trip, as a loop (profiles/pipelined_kernel_probe_r02.txt)
+// and fully unrolled alike.  With every load issued before the first store there is exactly one full wait, placed after
+// lane 0's arithmetic where it costs nothing.  Bit-identical to the one-shot kernel (same per-lane code, same counters).
+// ---------------------------------------------------------------------------------------------
+template <class Env>
+struct LaneOutputs { float s[Env::S], o[Env::O], reward; uint8_t done; int32_t sbd; };
+
+template <class Env, bool AUTORESET>
+__device__ __forceinline__ void compute_lane(const StepArgs &a, int64_t i, uint64_t tick, LaneInputs<Env, 1> &in, LaneOutputs<Env> &out) {
+    constexpr int S = Env::S, O = Env::O;
+    float o[O][1], rw[1];
+    bool dn[1], after[1] = {false};
+    advance_all<Env, 1, AUTORESET, false>(in.s, in.act, in.sbd, rw, dn, after, o, i, a.n);
+    if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<1>(a, after);
+    if constexpr (AUTORESET) reset_pending<Env, 1, false>(dn[0] ? 1u : 0u, in.s, o, a, i, a.n, tick);
+#pragma unroll
+    for (int k = 0; k < S; ++k) out.s[k] = in.s[k][0];
+#pragma unroll
+    for (int k = 0; k < O; ++k) out.o[k] = o[k][0];
+    out.reward = rw[0]; out.done = dn[0] ? 1 : 0; out.sbd = in.sbd[0];
+}
+
+template <class Env, bool AUTORESET, int NT>
+__device__ __forceinline__ void store_lane(const StepArgs &a, int64_t i, const LaneOutputs<Env> &out) {
+    constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
+    auto st = [](float *p, float v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; };
+    st(a.reward + i, out.reward, NT_O);
+    if constexpr (NT_O) __builtin_nontemporal_store(out.done, a.done + i); else a.done[i] = out.done;
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k) st(a.state_out + k * a.state_stride + i, out.s[k], NT_SS);
+    if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+        for (int k = 0; k < Env::O; ++k) st(a.obs + k * a.obs_stride + i, out.o[k], NT_SS);
+    }
+    if constexpr (!AUTORESET && Env::HAS_SBD) a.sbd[i] = out.sbd;
+}
+
+template <class Env, int ITEMS, bool AUTORESET, int NT>
+__global__ __launch_bounds__(256) void step_kernel_pipe(const StepArgs a) {
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Loads are UNCONDITIONAL (a lane past the end re-reads the last valid lane; only its stores are suppressed): a branch
+    // around a group of loads makes the compiler's waitcnt bookkeeping treat the earlier groups as the most recent ones at
+    // the join, and the wait for lane 0 below would then wait for every lane.
+    LaneInputs<Env, 1> in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int64_t idx = i + k * T;
+        load_inputs<Env, 1, AUTORESET, NT, false>(a, idx < a.n ? idx : a.n - 1, in[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        LaneOutputs<Env> out;
+        if (k == 0) {   // lane 0's inputs are needed now (and their first uses must not be hoisted into the load block)
+#pragma unroll
+            for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]));
+            asm volatile("" : "+v"(in[0].act[0]));
+        }
+        compute_lane<Env, AUTORESET>(a, i + k * T, tick, in[k], out);
+        if (k == 0) {
+            // touch every remaining lane's inputs AFTER lane 0's results exist (the extra operand ties each touch to them, or
+            // the compiler hoists the touches to the top): the one full vmcnt wait of the kernel lands HERE, after lane 0's
+            // arithmetic and before the first store, when the loads have long arrived
+#pragma unroll
+            for (int kk = 1; kk < ITEMS; ++kk) {
+#pragma unroll
+                for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[kk].s[c][0]), "+v"(out.s[Env::S - 1]));
+                asm volatile("" : "+v"(in[kk].act[0]), "+v"(out.reward));
+            }
+        }
+        if (i + k * T < a.n) store_lane<Env, AUTORESET, NT>(a, i + k * T, out);
+    }
+}
+
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
@@ -736,6 +820,24 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     const int block = cfg.block;
+    if constexpr (Env::PIPELINED) {        // multi-lane kernel, cfg.items lanes per thread (2..5)
+        if (cfg.items > 1 && !extras && cfg.vec == 1) {
+            const int items = cfg.items;
+            const int64_t per_block = 256 * (int64_t)items;
+            const dim3 pgrid(grid_for(a.n > 0 ? (a.n + per_block - 1) / per_block : 1, 1)), pblk(256);
+#define GYMNET_PIPE(I)                                                                                                  \
+    case I:                                                                                                             \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe<Env, I, true, 15>), pgrid, pblk, 0, st, a);                  \
+        else hipLaunchKernelGGL((step_kernel_pipe<Env, I, false, 15>), pgrid, pblk, 0, st, a);                           \
+        break;
+            switch (items) {
+                GYMNET_PIPE(2) GYMNET_PIPE(3) GYMNET_PIPE(4) GYMNET_PIPE(5)
+                default: return hipErrorInvalidValue;
+            }
+#undef GYMNET_PIPE
+            return hipGetLastError();
+        }
+    }
     // the wide form of an env: four lanes per thread on dwordx4 streams, or — for the env with a two-lane packed-FP32 form
     // (Acrobot) — two lanes per thread on dwordx2 streams
     constexpr int WIDE = Env::PACKED2 ? 2 : 4;

@@ -41,7 +41,8 @@ constexpr int kCountStride = 16;    // uint32 words between shard counters (64 b
 constexpr int kAfterStride = 8;     // uint64 words between after_done shards (64 bytes)
 
 // lds_bytes: unused dynamic LDS requested per workgroup, for the ONE purpose of capping occupancy in probes (GYMNET_LDS)
-struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; };
+// items: lanes per thread of the fully unrolled software-pipelined kernel (envs with PIPELINED only; 1 = one-shot kernel)
+struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

@@ -272,9 +272,9 @@ class VectorEnv:
 
     def LaunchPolicy(self):
         """The step kernel's launch configuration the handle chose."""
-        v, b, nt = C.c_int32(), C.c_int32(), C.c_int32()
-        capi.check(self._lib.gymnet_vecenv_launch_policy(self._h, C.byref(v), C.byref(b), C.byref(nt)))
-        return {"envs_per_thread": v.value, "block": b.value, "nontemporal_mask": nt.value}
+        v, b, nt, sq = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(self._lib.gymnet_vecenv_launch_policy(self._h, C.byref(v), C.byref(b), C.byref(nt), C.byref(sq)))
+        return {"envs_per_thread": v.value, "block": b.value, "nontemporal_mask": nt.value, "sequential_lanes_per_thread": sq.value}
 
     # ---- state access / bookkeeping -----------------------------------------------------------------
     def GetState(self):

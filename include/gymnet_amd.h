@@ -220,9 +220,11 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
 int gymnet_vecenv_sync(gymnet_vecenv *h);
 int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
-/* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): envs per thread (1 / 4),
- * threads per workgroup, non-temporal stream mask (0 / 12 / 15).  Any out pointer may be NULL. */
-int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt);
+/* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): lanes per thread on wide
+ * accesses (1 / 2 / 4), threads per workgroup, non-temporal stream mask (0 / 12 / 15), and lanes per thread of the multi-lane
+ * kernel that loads all of a thread's lanes first and then computes / stores them one after another (Acrobot; 1 = the
+ * one-shot kernel).  Any out pointer may be NULL. */
+int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *sequential_lanes);
 
 /* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
 /* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */

@@ -216,20 +216,24 @@ def test_scalar_broadcast_on_a_box_action_space(gpu_pkg):
         assert np.array_equal(oc.Observation, od.Observation)
 
 
-def test_acrobot_two_lanes_per_thread_on_packed_fp32_is_bit_identical(gpu_pkg, monkeypatch):
-    """GYMNET_VEC=2: both envs of a thread ride the v_pk_*_f32 instructions (envs.hpp step_observe_x2, dwordx2 streams).  Per
-    element it is the same IEEE sequence, so everything must equal the one-lane form bit for bit: one-launch steps with an
-    odd lane count (guarded tail), the bookkeeping variant, the fused rollout, with and without auto-reset.  (Opt-in, not the
-    default: it halves the VALU count and is still slower — DESIGN.md §4a.)"""
+def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
+    """Acrobot's step has three kernel forms: one lane per thread (one-shot), GYMNET_VEC=2 — both envs of a thread ride the
+    v_pk_*_f32 instructions (envs.hpp step_observe_x2, dwordx2 streams; opt-in: half the VALU count and still slower,
+    DESIGN.md §4a) — and GYMNET_ITEMS=k — k lanes per thread, all loads first, then compute / store lane after lane
+    (step_kernel_pipe; the default around 2^20 lanes).  Per lane all three run the same IEEE sequence, so everything must
+    agree bit for bit: one-launch steps with an odd lane count (clamped loads / suppressed stores in the tail), the
+    bookkeeping variant (which falls back to the one-shot kernel), the fused rollout, with and without auto-reset."""
     import torch
     n, ring = 8192 + 7, 6
     out = {}
-    for vec in (1, 2):
+    for vec, items in ((1, 1), (2, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
         monkeypatch.setenv("GYMNET_VEC", str(vec))
+        monkeypatch.setenv("GYMNET_ITEMS", str(items))
         res = []
         for auto, stats in ((True, False), (False, False), (True, True)):
             with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats) as env:
-                assert env.LaunchPolicy()["envs_per_thread"] == vec
+                pol = env.LaunchPolicy()
+                assert pol["envs_per_thread"] == vec and pol["sequential_lanes_per_thread"] == (1 if stats else items)
                 acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
                 torch.cuda.synchronize()
                 for t in range(ring):
@@ -244,10 +248,12 @@ def test_acrobot_two_lanes_per_thread_on_packed_fp32_is_bit_identical(gpu_pkg, m
                 env.Sync()
                 r = env.Read()
                 res.append((env.GetState(), r.Observation, r.Reward, r.Done, env.EpisodeStats() if stats else None))
-        out[vec] = res
-    for a, b in zip(out[1], out[2]):
-        for x, y in zip(a[:4], b[:4]):
-            assert np.array_equal(x, y, equal_nan=True)
-        if a[4] is not None:
-            assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])
-    assert out[1][0][3].any() or out[1][1][3].any()
+        out[(vec, items)] = res
+    ref = out[(1, 1)]
+    for key, res in out.items():
+        for a, b in zip(ref, res):
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y, equal_nan=True), key
+            if a[4] is not None:
+                assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1]), key
+    assert ref[0][3].any() or ref[1][3].any()
