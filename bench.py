@@ -32,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -323,6 +324,77 @@ def main():
     c = local.Counters()
     assert c["lane_steps"] - steps_before == repeats * K * n, (c, steps_before, repeats)
 
+    bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B (SURVEY.md §8(d))
+    launch_policy = local.LaunchPolicy()
+
+    def headline():
+        """The contract's JSON line from the main timing alone; the secondary figures are added to it as they arrive."""
+        launch_us = ev_ms * 1e3 / K                                          # HIP events over the (median) timed region / launches
+        achieved = bytes_per_step * n / (launch_us * 1e-6) / 1e9             # GB/s per GPU, algorithmic bytes
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")               # rocprofv3 --pmc result, per launch
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.env, {}).get(str(n))
+                if traffic is not None:
+                    traffic_source = ("NOT measured in this run: constant read from profiles/traffic.json — "
+                                      + str(tj.get("_source", "rocprofv3 --pmc passes")))
+            except Exception:
+                traffic = None
+        if gather_in_region:
+            what = "value = step + RCCL observation all-gather after every step (NOT the step-only headline)"
+        elif world > 1:
+            what = "value = step-only rate (no collective on the data path); with_obs_allgather = the same stepping plus the per-step RCCL gather"
+        else:
+            what = "value = step-only rate"
+        kernel = {"CartPole-v1": "step_kernel<CartPole,4,autoreset>", "Pendulum-v1": "step_kernel<Pendulum,4,autoreset>",
+                  "MountainCar-v0": "step_kernel<MountainCar,4,autoreset>",
+                  "Acrobot-v1": "step_kernel_pipe<Acrobot,4,autoreset>" if launch_policy.get("sequential_lanes_per_thread", 1) > 1
+                  else "step_kernel<Acrobot,1,autoreset>"}.get(args.env, "step_kernel")
+        return {
+            "metric": "env-steps/sec", "value": n * world * K / wall, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": repeats, "region_ms_median": wall * 1e3, "region_ms_min": min(walls) * 1e3, "region_ms_max": max(walls) * 1e3,
+            "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), float32 SoA state, "
+                                   f"fused auto-reset, iid random actions pre-generated in HBM; {what}",
+                       "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
+                       "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or gather_in_region) else
+                                  "one kernel launch per step; gymnet_vecenv_rollout_device: " +
+                                  ("hipGraph replay" if n * bytes_per_step < (24 << 20) else "back-to-back stream launches")),
+                       "launch_policy": launch_policy,
+                       "timing": f"median of {repeats} bracketed {K}-step regions (>= {args.min_seconds * 1e3:.0f} ms timed in total)",
+                       "backend": ("rccl" if backend == "nccl" else backend + " (ranks SHARE the GPUs that exist: plumbing check, not a multi-GPU measurement)") if use_dist else "single process",
+                       "barrier": ("shared-memory spin barrier (ranks of one node)" if node_barrier is not None else
+                                   ("process-group barrier" if use_dist else "none (one rank)")),
+                       "allgather_obs_in_timed_region": gather_in_region, "double_buffered_obs": False,
+                       "parallelism": f"lane-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel,
+                         "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
+                         "frac_by_wall": bytes_per_step * n / (wall / K) / 1e9 / HBM_PEAK_GBPS,
+                         "note": "at 2^20 lanes the working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
+        }
+
+    out = headline() if rank == 0 else {}
+    emitted = threading.Lock()
+
+    def emit_and_exit_on_timeout(section, seconds):
+        """Watchdog for a secondary section that could hang rather than fail (a collective waiting for a peer): after `seconds`
+        rank 0 prints the headline it already has, with the section marked as timed out, and every rank leaves."""
+        def fire():
+            if emitted.acquire(blocking=False):
+                if rank == 0:
+                    out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        t = threading.Timer(seconds, fire)
+        t.daemon = True
+        t.start()
+        return t
+
     extras = rank == 0 and world == 1 and not args.no_extras and not gather_in_region
     # Cross-check of the per-launch figure: 200 single launches, each bracketed by its own HIP-event pair on the
     # engine's stream (isolated launches: no back-to-back overlap with a neighbour's ramp / drain).
@@ -363,6 +435,7 @@ def main():
     if can_gather and not gather_in_region:
         gathered = {}
         gs = 128
+        watchdog = emit_and_exit_on_timeout("with_obs_allgather", 180)
         for label, overlapped in (("serial", False), ("overlapped", True)):
             if overlapped and args.no_overlap:
                 continue
@@ -393,6 +466,7 @@ def main():
                     genv.Sync()
                     genv.Close()
         gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4
+        watchdog.cancel()
 
     # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
     # beside the 8 TB/s spec peak the roofline fraction uses: cache-resident (32 MiB) and HBM-resident (2 GiB).
@@ -415,9 +489,6 @@ def main():
             copy_bw[label] = 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9
             del src, dst
 
-    bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B (SURVEY.md §8(d))
-    launch_policy = local.LaunchPolicy()
-    overlap_on = False
     env.Close()
     del actions
     torch.cuda.empty_cache()
@@ -448,51 +519,9 @@ def main():
         except Exception as e:
             big = {"error": repr(e)[:200]}
 
-    if rank == 0:
-        launch_us = ev_ms * 1e3 / K                                          # HIP events over the (median) timed region / launches
-        achieved = bytes_per_step * n / (launch_us * 1e-6) / 1e9             # GB/s per GPU, algorithmic bytes
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")               # rocprofv3 --pmc result, per launch
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(args.env, {}).get(str(n))
-                if traffic is not None:
-                    traffic_source = ("NOT measured in this run: constant read from profiles/traffic.json — "
-                                      + str(tj.get("_source", "rocprofv3 --pmc passes")))
-            except Exception:
-                traffic = None
-        if gather_in_region:
-            what = "value = step + RCCL observation all-gather after every step (NOT the step-only headline)"
-        elif world > 1:
-            what = "value = step-only rate (no collective on the data path); with_obs_allgather = the same stepping plus the per-step RCCL gather"
-        else:
-            what = "value = step-only rate"
-        out = {
-            "metric": "env-steps/sec", "value": n * world * K / wall, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "repeats": repeats, "region_ms_median": wall * 1e3, "region_ms_min": min(walls) * 1e3, "region_ms_max": max(walls) * 1e3,
-            "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), float32 SoA state, "
-                                   f"fused auto-reset, iid random actions pre-generated in HBM; {what}",
-                       "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
-                       "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or gather_in_region) else
-                                  "one kernel launch per step; gymnet_vecenv_rollout_device: " +
-                                  ("hipGraph replay" if n * bytes_per_step < (24 << 20) else "back-to-back stream launches")),
-                       "launch_policy": launch_policy,
-                       "timing": f"median of {repeats} bracketed {K}-step regions (>= {args.min_seconds * 1e3:.0f} ms timed in total)",
-                       "backend": ("rccl" if backend == "nccl" else backend + " (ranks SHARE the GPUs that exist: plumbing check, not a multi-GPU measurement)") if use_dist else "single process",
-                       "barrier": ("shared-memory spin barrier (ranks of one node)" if node_barrier is not None else
-                                   ("process-group barrier" if use_dist else "none (one rank)")),
-                       "allgather_obs_in_timed_region": gather_in_region, "double_buffered_obs": bool(overlap_on), "parallelism": f"lane-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "step_kernel<CartPole,4,autoreset>" if args.env == "CartPole-v1" else "step_kernel",
-                         "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
-                         "frac_by_wall": bytes_per_step * n / (wall / K) / 1e9 / HBM_PEAK_GBPS,
-                         "isolated_launch_us_median": single_us, "measured_copy_GBps": copy_bw,
-                         "note": "at 2^20 lanes the 43 MB working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
-        }
+    if rank == 0 and emitted.acquire(blocking=False):
+        out["roofline"]["isolated_launch_us_median"] = single_us
+        out["roofline"]["measured_copy_GBps"] = copy_bw
         if big:
             out["hbm_resident_2p27"] = big
         if fused:

@@ -21,7 +21,7 @@ G = os.path.join(ROOT, "gpurun_out", "p2")
 P = os.environ.get("GYMNET_PROFILES_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 BYTES = {"CartPole-v1": 41, "Pendulum-v1": 37, "MountainCar-v0": 25, "Acrobot-v1": 65, "Acrobot-v1-packed": 65}
-LANES = {"CartPole-v1": 4, "Pendulum-v1": 4, "MountainCar-v0": 4, "Acrobot-v1": 1, "Acrobot-v1-packed": 2}
+LANES = {"CartPole-v1": 4, "Pendulum-v1": 4, "MountainCar-v0": 4, "Acrobot-v1": 4, "Acrobot-v1-packed": 2}   # Acrobot at 2^20: step_kernel_pipe, 4 lanes per thread
 
 
 def capture(fn, *a):
