@@ -432,19 +432,26 @@ def main():
     # (a) with the gather on the critical path, (b) overlapped with the next step (double-buffered observation arrays:
     # step t+1 writes buffer B while the gather of buffer A is in flight on a side stream).
     gathered = None
-    if can_gather and not gather_in_region:
+    if use_dist and not gather_in_region:
         gathered = {}
         gs = 128
-        watchdog = emit_and_exit_on_timeout("with_obs_allgather", 180)
-        for label, overlapped in (("serial", False), ("overlapped", True)):
+        watchdog = emit_and_exit_on_timeout("with_obs_allgather", 240)
+        # serial / overlapped: RCCL all_gather_into_tensor; direct_ipc / direct_ipc_overlapped: the hand-written push of each
+        # rank's slice into its peers' replica buffers (HIP IPC peer buffers, gymnet_push_obs_device; one xGMI link per peer)
+        for label, overlapped, how in (("serial", False, "rccl"), ("overlapped", True, "rccl"),
+                                       ("direct_ipc", False, "direct"), ("direct_ipc_overlapped", True, "direct")):
             if overlapped and args.no_overlap:
                 continue
+            if how == "rccl" and backend != "nccl":      # ranks sharing a GPU over gloo: only the IPC variants can run
+                continue
             genv = None
+            own = overlapped or how == "direct"
             try:
-                genv = env if not overlapped else pkg.ShardedVectorEnv(
+                genv = env if not own else pkg.ShardedVectorEnv(
                     args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed, auto_reset=True,
-                    gather_obs=True, tensor_device=dev, force_gather=args.force_dist, overlap=True)
-                if overlapped:
+                    gather_obs=True, tensor_device=dev, force_gather=args.force_dist, overlap=overlapped, gather=how,
+                    barrier=node_barrier)
+                if own:
                     genv.ResetDevice()
 
                 def gloop(steps=gs):
@@ -462,7 +469,7 @@ def main():
             except Exception as e:                      # never lose the headline over the optional collective
                 gathered[label] = {"error": repr(e)[:200]}
             finally:
-                if overlapped and genv is not None:
+                if own and genv is not None:
                     genv.Sync()
                     genv.Close()
         gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4

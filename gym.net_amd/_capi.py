@@ -77,6 +77,10 @@ class GroupConfig(C.Structure):
                 ("devices", C.POINTER(C.c_int32)), ("gather", C.c_int32), ("max_episode_steps", C.c_int32)]
 
 
+class IpcHandle(C.Structure):
+    _fields_ = [("bytes", C.c_char * 64)]
+
+
 class RolloutBuffers(C.Structure):
     _fields_ = [("d_obs", C.c_void_p), ("d_reward", C.c_void_p), ("d_done", C.c_void_p)]
 
@@ -139,6 +143,11 @@ PROTOTYPES = {
     "gymnet_vecenv_sample_actions_device": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_compose_actions_device": (C.c_int, [_H, _P, C.c_float, _P, C.c_uint64, C.c_uint64]),
+    "gymnet_peer_buffer_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(IpcHandle)]),
+    "gymnet_peer_buffer_open": (C.c_int, [C.c_int, C.POINTER(IpcHandle), C.POINTER(C.c_void_p)]),
+    "gymnet_peer_buffer_close": (C.c_int, [C.c_int, _P]),
+    "gymnet_peer_buffer_destroy": (C.c_int, [C.c_int, _P]),
+    "gymnet_push_obs_device": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "gymnet_group_create": (C.c_int, [C.POINTER(GroupConfig), C.POINTER(_H)]),
     "gymnet_group_destroy": (C.c_int, [_H]),
     "gymnet_group_size": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

@@ -60,6 +60,9 @@ namespace Gym.Envs.Amd {
     public struct GymnetRolloutBuffers { public IntPtr d_obs; public IntPtr d_reward; public IntPtr d_done; }
 
     [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct GymnetIpcHandle { public fixed byte bytes[64]; }
+
+    [StructLayout(LayoutKind.Sequential)]
     public struct GymnetGroupConfig {
         public uint struct_size; public int env_id; public long global_num_envs; public int num_members; public uint flags;
         public ulong seed; public IntPtr devices; public int gather; public int max_episode_steps;
@@ -140,6 +143,13 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_group_sync(IntPtr g);
         [DllImport(Lib)] public static extern int gymnet_group_reset(IntPtr g, float* obs_out);
         [DllImport(Lib)] public static extern int gymnet_group_step(IntPtr g, void* actions, float* obs_out, float* reward_out, byte* done_out);
+
+        // ---- peer buffers (one process per GPU hosts: direct all-gather over HIP IPC)
+        [DllImport(Lib)] public static extern int gymnet_peer_buffer_create(int device, long bytes, out IntPtr d_ptr, out GymnetIpcHandle handle);
+        [DllImport(Lib)] public static extern int gymnet_peer_buffer_open(int device, ref GymnetIpcHandle handle, out IntPtr d_ptr);
+        [DllImport(Lib)] public static extern int gymnet_peer_buffer_close(int device, IntPtr d_ptr);
+        [DllImport(Lib)] public static extern int gymnet_peer_buffer_destroy(int device, IntPtr d_ptr);
+        [DllImport(Lib)] public static extern int gymnet_push_obs_device(int device, IntPtr stream, IntPtr d_src, IntPtr[] d_dst, int npeers, long count);
 
         /// Maps a status to the exception the reference throws for the same condition.
         public static void Check(int status) {

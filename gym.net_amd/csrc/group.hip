@@ -205,6 +205,72 @@ void destroy_group(gymnet_group *g) {
 
 extern "C" {
 
+// ---- peer buffers (one process per GPU): HIP IPC export / import + the same push kernel ------------------------------
+int gymnet_peer_buffer_create(int device, int64_t bytes, void **d_ptr, gymnet_ipc_handle *handle) {
+    return guarded([&]() -> int {
+    if (!d_ptr || !handle || bytes <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_ptr/handle/bytes");
+    static_assert(sizeof(gymnet_ipc_handle) == sizeof(hipIpcMemHandle_t), "gymnet_ipc_handle must be a hipIpcMemHandle_t");
+    DeviceScope scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)bytes);
+    if (e != hipSuccess) return fail(nullptr, GYMNET_ERR_OOM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), p);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(nullptr, GYMNET_ERR_HIP, "hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e)); }
+    *d_ptr = p;
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_peer_buffer_open(int device, const gymnet_ipc_handle *handle, void **d_ptr) {
+    return guarded([&]() -> int {
+    if (!d_ptr || !handle) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null argument");
+    DeviceScope scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof h);
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(nullptr, GYMNET_ERR_HIP, "hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    *d_ptr = p;
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_peer_buffer_close(int device, void *d_ptr) {
+    return guarded([&]() -> int {
+    if (!d_ptr) return GYMNET_OK;
+    DeviceScope scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, hipIpcCloseMemHandle(d_ptr));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_peer_buffer_destroy(int device, void *d_ptr) {
+    return guarded([&]() -> int {
+    if (!d_ptr) return GYMNET_OK;
+    DeviceScope scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, hipFree(d_ptr));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_push_obs_device(int device, void *stream, const float *d_src, float *const *d_dst, int32_t npeers, int64_t count) {
+    return guarded([&]() -> int {
+    if (!d_src || count < 0 || npeers < 0 || npeers > kMaxPeers || (npeers > 0 && !d_dst)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad src/dst/npeers/count");
+    PushArgs a{};
+    a.src = d_src; a.count = count; a.npeers = npeers;
+    for (int p = 0; p < npeers; ++p) { if (!d_dst[p]) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_dst[%d] is null", p); a.dst[p] = d_dst[p]; }
+    DeviceScope scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_push_obs(a, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+    });
+}
+
 int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
     return guarded([&]() -> int {
     if (!out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "out is null");

@@ -75,7 +75,7 @@ class ShardedVectorEnv:
 
     def __init__(self, env, global_num_envs, rank=None, world_size=None, device=None, seed=0, auto_reset=True,
                  gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None, force_gather=False,
-                 overlap=False):
+                 overlap=False, gather="rccl", barrier=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -104,10 +104,21 @@ class ShardedVectorEnv:
         # rank-major gather buffers [B][G][D][N/G] (B = 2 when overlapping); this rank's observation arrays ARE slice
         # [b][rank] of whichever buffer b the last step wrote
         nbuf = 2 if self.overlap else 1
-        self.obs_bufs = torch.zeros((nbuf, self.world_size, self.obs_dim, n_local), dtype=torch.float32, device=self.tensor_device)
+        self._cuda = self.tensor_device.type == "cuda"
+        # gather = "rccl": the collective of the process group (RCCL over xGMI for backend "nccl").
+        # gather = "direct": the hand-written push — every rank's buffers are peer buffers (HIP IPC), each rank maps all the
+        # others' and stores its slice straight into them, one xGMI link per peer (gymnet_push_obs_device); cross-process
+        # ordering is a stream synchronize + `barrier` (a callable; default: the process group's barrier).
+        self.gather = gather if (self.gather_obs and self._cuda) else "rccl"
+        self._barrier = barrier or (lambda: dist.barrier(group=process_group))
+        self._peers, self._own_base = None, None
+        shape = (nbuf, self.world_size, self.obs_dim, n_local)
+        if self.gather == "direct":
+            self.obs_bufs = self._make_peer_buffers(shape, device)
+        else:
+            self.obs_bufs = torch.zeros(shape, dtype=torch.float32, device=self.tensor_device)
         self.obs_all = self.obs_bufs[0]
         stream = None
-        self._cuda = self.tensor_device.type == "cuda"
         if self._cuda:
             stream = torch.cuda.current_stream(self.tensor_device).cuda_stream
         kw = {"ext_obs_alt": self.obs_bufs[1][self.rank].data_ptr()} if self.overlap else {}
@@ -121,6 +132,45 @@ class ShardedVectorEnv:
         # events are created once and re-recorded: a fresh torch.cuda.Event per step costs more host time than the step kernel
         self._ev_step = torch.cuda.Event() if self._gstream is not None else None
         self._ev_done = [torch.cuda.Event(), torch.cuda.Event()] if self._gstream is not None else None
+
+    # ---- direct gather: peer buffers over HIP IPC --------------------------------------------------------------
+    def _make_peer_buffers(self, shape, device):
+        import ctypes as C
+        import numpy as np
+        from . import _capi
+        torch, dist = self._torch, self._dist
+        lib = _capi.load_library()
+        nbytes = int(np.prod(shape)) * 4
+        base, handle = C.c_void_p(), _capi.IpcHandle()
+        _capi.check(lib.gymnet_peer_buffer_create(int(device), nbytes, C.byref(base), C.byref(handle)))
+        self._own_base, self._peer_dev, self._lib = base.value, int(device), lib
+
+        class _Raw:                                   # zero-copy torch view of the library's allocation
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (base.value, False), "version": 2}
+        t = torch.as_tensor(_Raw(), device=self.tensor_device)
+        handles = [None] * self.world_size
+        # all 64 bytes of the struct (a c_char array FIELD reads back as a C string, cut at the first NUL)
+        dist.all_gather_object(handles, C.string_at(C.byref(handle), 64), group=self.group)
+        self._peers = {}
+        for r, hb in enumerate(handles):
+            if r == self.rank:
+                continue
+            h, p = _capi.IpcHandle(), C.c_void_p()
+            assert len(hb) == 64
+            C.memmove(C.byref(h), hb, 64)
+            _capi.check(lib.gymnet_peer_buffer_open(int(device), C.byref(h), C.byref(p)))
+            self._peers[r] = p.value
+        return t
+
+    def _push(self, b, stream_ptr):
+        import ctypes as C
+        from . import _capi
+        G, D, n = self.world_size, self.obs_dim, self.local_num_envs
+        off = ((b * G + self.rank) * D * n) * 4                      # byte offset of slice [b][rank] in every replica
+        peers = [self._peers[r] for r in sorted(self._peers)]
+        dst = (C.c_void_p * max(1, len(peers)))(*[C.c_void_p(p + off) for p in peers])
+        _capi.check(self._lib.gymnet_push_obs_device(self._peer_dev, C.c_void_p(stream_ptr), C.c_void_p(self._own_base + off), dst,
+                                                     len(peers), D * n))
 
     # ---- stepping -----------------------------------------------------------------------------------
     def _current_buffer(self):
@@ -163,6 +213,22 @@ class ShardedVectorEnv:
         flat_out = t.view(-1)
         flat_in = t[self.rank].reshape(-1)
         self._last = b
+        if self.gather == "direct":
+            tc = self._torch.cuda
+            main = tc.current_stream(self.tensor_device)
+            self._barrier()                                   # every rank is done reading the replicas about to be overwritten
+            if overlap and self.overlap:
+                self._ev_step.record(main)
+                self._gstream.wait_event(self._ev_step)       # the step that produced this buffer
+                self._push(b, self._gstream.cuda_stream)
+                self._ev_done[b].record(self._gstream)
+                self._pending[b] = self._ev_done[b]
+                self._direct_inflight = True
+            else:
+                self._push(b, main.cuda_stream)
+                main.synchronize()
+                self._barrier()                               # every rank's pushes have landed
+            return None
 
         def gather(async_flag):
             try:
@@ -200,6 +266,10 @@ class ShardedVectorEnv:
     def WaitGather(self):
         """After this, work queued on the main stream sees the last gathered buffer complete."""
         self.Wait()
+        if self.gather == "direct" and getattr(self, "_direct_inflight", False):
+            self._gstream.synchronize()
+            self._barrier()                                   # every rank's pushes have landed
+            self._direct_inflight = False
         self._finish(self._last)
 
     def GlobalObs(self):
@@ -216,3 +286,12 @@ class ShardedVectorEnv:
 
     def Close(self):
         self.local.Close()
+        if self._peers is not None:
+            if self._cuda:
+                self._torch.cuda.synchronize(self.tensor_device)
+            self._barrier()                                   # nobody still pushes into a buffer that is about to go away
+            for p in self._peers.values():
+                self._lib.gymnet_peer_buffer_close(self._peer_dev, p)
+            self._peers = None
+            self.obs_bufs = self.obs_all = None
+            self._lib.gymnet_peer_buffer_destroy(self._peer_dev, self._own_base)

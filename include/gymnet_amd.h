@@ -333,6 +333,22 @@ int gymnet_group_sync(gymnet_group *g);
 int gymnet_group_reset(gymnet_group *g, float *obs_out);
 int gymnet_group_step(gymnet_group *g, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out);
 
+/* ---- peer buffers: the direct all-gather for ONE PROCESS PER GPU hosts ---------------------------------------------
+ * gymnet_group_* needs all GPUs in one process.  A host that runs one process per GPU (torch.distributed, MPI, a .NET
+ * launcher) gets the same hand-written push over xGMI with these four calls: every rank creates its replica buffer
+ * [G][obs_dim][N/G] as a peer buffer, hands the 64-byte handle to the other ranks by whatever channel it has, opens theirs,
+ * creates its handle with d_ext_obs = buffer + rank * obs_dim * (N/G), and after a step pushes its slice into every
+ * peer's replica.  Cross-process ordering is the host's: synchronize the stream, then a node barrier, before anyone reads a
+ * replica or pushes into it again.  (HIP IPC; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform's driver.) */
+typedef struct gymnet_ipc_handle { char bytes[64]; } gymnet_ipc_handle;
+int gymnet_peer_buffer_create(int device, int64_t bytes, void **d_ptr, gymnet_ipc_handle *handle);   /* hipMalloc + zero + export */
+int gymnet_peer_buffer_open(int device, const gymnet_ipc_handle *handle, void **d_ptr);              /* map a peer's buffer */
+int gymnet_peer_buffer_close(int device, void *d_ptr);                                               /* unmap an opened buffer */
+int gymnet_peer_buffer_destroy(int device, void *d_ptr);                                             /* free a created buffer */
+/* Stores `count` floats from d_src into the same-shaped slice d_dst[p] of every peer (p < npeers <= 15), all peers
+ * concurrently (one grid row per peer = one xGMI link each), on `stream` (a hipStream_t of `device`; NULL = default). */
+int gymnet_push_obs_device(int device, void *stream, const float *d_src, float *const *d_dst, int32_t npeers, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

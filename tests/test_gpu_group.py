@@ -305,3 +305,70 @@ def test_plain_bench_gpus_2_spawns_its_own_ranks(gpu_pkg):
     import torch
     if torch.cuda.device_count() < 2:
         assert "gloo" in j["config"]["backend"] and "SHARE" in j["config"]["backend"]
+    assert "shared-memory" in j["config"]["barrier"]
+    g = j["with_obs_allgather"]                       # two ranks, HIP IPC peer buffers, hand-written push: the direct gather ran
+    for k in ("direct_ipc", "direct_ipc_overlapped"):
+        assert g[k].get("gathered_obs_finite_and_nonzero") is True and g[k]["value"] > 1e8, g
+
+
+DIRECT_CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+import __graft_entry__ as ge
+pkg = ge.load_package()
+rank, world, out_dir = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
+dist.init_process_group("gloo", rank=rank, world_size=world)        # control plane only: handle exchange + barrier
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)              # both ranks share the one GPU of the box
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+n, steps = 1 << 14, 16
+for overlap in (False, True):
+    env = pkg.ShardedVectorEnv("CartPole-v1", n, rank=rank, world_size=world, device=0, seed=0x5EED, auto_reset=True,
+                               gather_obs=True, tensor_device=dev, overlap=overlap, gather="direct")
+    assert env.gather == "direct" and env.overlap == overlap
+    rng = np.random.default_rng(1)
+    lo, hi = env.lane_offset, env.lane_offset + env.local_num_envs
+    env.ResetDevice()
+    acts = torch.empty(hi - lo, dtype=torch.int32, device=dev)
+    snaps = []
+    for t in range(steps):
+        a = rng.integers(0, 2, n).astype(np.int32)
+        acts.copy_(torch.from_numpy(a[lo:hi])); torch.cuda.synchronize()
+        env.StepDevice(acts)
+        env.AllGatherObs(overlap=overlap)
+        env.WaitGather(); env.Sync(); torch.cuda.synchronize()
+        snaps.append(env.GlobalObs().cpu().numpy().copy())           # [G, D, n/G]
+    np.save(os.path.join(out_dir, f"direct_{int(overlap)}_rank{rank}.npy"), np.stack(snaps))
+    env.Close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_direct_allgather_between_two_processes_over_hip_ipc(gpu_pkg, tmp_path):
+    """One process per GPU with the hand-written gather: two ranks (sharing this box's one GPU) export their replica
+    buffers as HIP IPC peer buffers, map each other's, push their slices with gymnet_push_obs_device, and synchronise with
+    stream-sync + barrier.  Every rank's gathered [G][D][N/G] buffer must equal the single-handle batch bit for bit."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "child.py"
+    script.write_text(DIRECT_CHILD)
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n---\n".join(o[-2500:] for o in outs)
+    n, steps = 1 << 14, 16
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as one:
+        one.Reset()
+        rng = np.random.default_rng(1)
+        want = [one.Step(rng.integers(0, 2, n).astype(np.int32)).Observation for _ in range(steps)]
+    for overlap in (0, 1):
+        got = [np.load(tmp_path / f"direct_{overlap}_rank{r}.npy") for r in range(2)]
+        assert np.array_equal(got[0], got[1])
+        for t in range(steps):
+            assert np.array_equal(np.concatenate(list(got[0][t]), axis=1).T, want[t]), (overlap, t)

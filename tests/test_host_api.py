@@ -36,7 +36,8 @@ def abi_manifest():
 
 
 CTYPES_OF = {"gymnet_config": "Config", "gymnet_env_info": "EnvInfo", "gymnet_device_view": "DeviceView",
-             "gymnet_counters": "Counters", "gymnet_rollout_buffers": "RolloutBuffers", "gymnet_group_config": "GroupConfig"}
+             "gymnet_counters": "Counters", "gymnet_rollout_buffers": "RolloutBuffers", "gymnet_group_config": "GroupConfig",
+             "gymnet_ipc_handle": "IpcHandle"}
 
 
 def test_struct_layouts_match_the_header(gymnet):
@@ -191,7 +192,7 @@ def test_missing_extension_raises_instead_of_falling_back(tmp_path):
 CS_SIZES = {"uint": 4, "int": 4, "long": 8, "ulong": 8, "float": 4, "IntPtr": 8, "byte": 1}
 CS_STRUCT_OF = {"gymnet_config": "GymnetConfig", "gymnet_env_info": "GymnetEnvInfo", "gymnet_device_view": "GymnetDeviceView",
                 "gymnet_counters": "GymnetCounters", "gymnet_rollout_buffers": "GymnetRolloutBuffers",
-                "gymnet_group_config": "GymnetGroupConfig"}
+                "gymnet_group_config": "GymnetGroupConfig", "gymnet_ipc_handle": "GymnetIpcHandle"}
 
 
 def _csharp_sources():

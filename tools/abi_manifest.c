@@ -48,6 +48,9 @@ int main(void) {
     F(gymnet_group_config, num_members); F(gymnet_group_config, flags); F(gymnet_group_config, seed);
     F(gymnet_group_config, devices); F(gymnet_group_config, gather); F(gymnet_group_config, max_episode_steps);
     END();
+    BEGIN(gymnet_ipc_handle);
+    F(gymnet_ipc_handle, bytes);
+    END();
     printf(",\n \"abi_version\": %d}\n", GYMNET_ABI_VERSION);
     return 0;
 }
