@@ -256,6 +256,62 @@ private:
     std::unique_ptr<Box> action_box_, observation_space_;
 };
 
+/// ONE process driving G GPUs (gymnet_group_*): member m owns lanes [m*N/G, (m+1)*N/G); every member keeps a replica
+/// [G][obs_dim][N/G] of all observations on its GPU, completed by AllGatherObs() (hand-written direct push over peer-mapped
+/// memory, or RCCL).  The host-boundary Reset / Step take the whole batch in the NDArray layout, like VectorEnv.
+class GroupVectorEnv {
+public:
+    GroupVectorEnv(gymnet_env_id env, int64_t global_num_envs, const std::vector<int32_t> &devices, uint64_t seed = 0,
+                   uint32_t flags = GYMNET_FLAG_AUTORESET, gymnet_gather_mode gather = GYMNET_GATHER_DIRECT) {
+        check(gymnet_env_describe((int)env, &info_));
+        gymnet_group_config cfg{};
+        cfg.struct_size = sizeof cfg; cfg.env_id = (int)env; cfg.global_num_envs = global_num_envs;
+        cfg.num_members = (int32_t)devices.size(); cfg.flags = flags; cfg.seed = seed; cfg.devices = devices.data(); cfg.gather = gather;
+        n_ = global_num_envs; g_members_ = (int)devices.size();
+        check(gymnet_group_create(&cfg, &g_));
+    }
+    GroupVectorEnv(const GroupVectorEnv &) = delete;
+    GroupVectorEnv &operator=(const GroupVectorEnv &) = delete;
+    ~GroupVectorEnv() { Close(); }
+    void Close() { if (g_) { gymnet_group_destroy(g_); g_ = nullptr; } }
+
+    int64_t NumberOfEnvironments() const { return n_; }
+    int NumMembers() const { return g_members_; }
+    int ObsDim() const { return info_.obs_dim; }
+    void Seed(uint64_t seed) { check(gymnet_group_seed(g_, seed)); }
+
+    std::vector<float> Reset() {                                                // row-major [N, obs_dim]
+        std::vector<float> obs((size_t)n_ * info_.obs_dim);
+        check(gymnet_group_reset(g_, obs.data()));
+        return obs;
+    }
+    BatchStep Step(const std::vector<int32_t> &actions) {
+        if ((int64_t)actions.size() != n_) throw std::invalid_argument("Number of actions passed should be equals to number of environments");
+        BatchStep b;
+        b.N = n_; b.D = info_.obs_dim;
+        b.Observation.resize((size_t)n_ * info_.obs_dim); b.Reward.resize((size_t)n_); b.Done.resize((size_t)n_);
+        check(gymnet_group_step(g_, actions.data(), b.Observation.data(), b.Reward.data(), b.Done.data()));
+        return b;
+    }
+    BatchStep Step(int action) { return Step(std::vector<int32_t>((size_t)n_, action)); }   // IVecEnv.Step(int): scalar broadcast
+
+    void AllGatherObs() { check(gymnet_group_allgather_obs(g_)); }
+    void WaitGather() { check(gymnet_group_wait_gather(g_)); }
+    std::vector<float> ReadReplica(int member) {                               // [G][obs_dim][N/G] as member `member` holds it
+        std::vector<float> r((size_t)n_ * info_.obs_dim);
+        check(gymnet_group_read_replica(g_, member, r.data()));
+        return r;
+    }
+    void Sync() { check(gymnet_group_sync(g_)); }
+    gymnet_group *handle() const { return g_; }
+
+private:
+    gymnet_group *g_ = nullptr;
+    gymnet_env_info info_{};
+    int64_t n_ = 0;
+    int g_members_ = 0;
+};
+
 /// Single-instance Env façade (Env.cs:13-41; CartPoleEnv.cs:43-198) over a 1-lane VectorEnv, so the reference's
 /// own loop (README.md:32-52) compiles against it unchanged in shape.
 class CartPoleEnv {

@@ -155,6 +155,36 @@ static void gpu_tests() {
         CHECK(seen && after == 3, "pole fell and was stepped past done");
         CHECK(env.GetStepsBeyondDone()[0] == 3 && env.Counters().stepped_after_done == 9, "sbd counts; warning counted, not printed");
     }
+    {   // one process, G members (here: four logical members on device 0): the host-boundary step of the group equals the
+        // single batch bit for bit, and after the direct all-gather every member's replica holds all observations
+        const int64_t n = 4 * 640;
+        gymnet::GroupVectorEnv grp(GYMNET_ENV_CARTPOLE, n, {0, 0, 0, 0}, 11);
+        gymnet::VectorEnv one(GYMNET_ENV_CARTPOLE, n, 0, 11, GYMNET_FLAG_AUTORESET);
+        CHECK(grp.Reset() == one.Reset(), "group Reset == single batch");
+        std::mt19937 rng(9);
+        bool same = true;
+        gymnet::BatchStep last;
+        for (int t = 0; t < 30; ++t) {
+            std::vector<int32_t> a((size_t)n);
+            for (auto &x : a) x = (int32_t)(rng() & 1u);
+            gymnet::BatchStep g = grp.Step(a), o = one.Step(a);
+            same = same && g.Observation == o.Observation && g.Reward == o.Reward && g.Done == o.Done;
+            last = o;
+        }
+        CHECK(same, "group Step == single batch over 30 steps with auto-reset");
+        grp.AllGatherObs(); grp.WaitGather();
+        const int64_t nl = n / 4;
+        for (int m = 0; m < 4; ++m) {
+            const std::vector<float> rep = grp.ReadReplica(m);                  // [G][4][nl]
+            bool ok = true;
+            for (int r = 0; r < 4 && ok; ++r)
+                for (int k = 0; k < 4 && ok; ++k)
+                    for (int64_t i = 0; i < nl && ok; ++i)
+                        ok = rep[((size_t)r * 4 + k) * nl + i] == last.Observation[((size_t)r * nl + i) * 4 + k];
+            CHECK(ok, "every member's replica holds all observations after the direct all-gather");
+        }
+        CHECK(throws<std::invalid_argument>([] { gymnet::GroupVectorEnv bad(GYMNET_ENV_CARTPOLE, 1001, {0, 0}); }), "N not a multiple of G -> ArgumentException");
+    }
     {   // error behaviour
         gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_VALIDATE_ACTIONS);
         env.Reset();

@@ -372,3 +372,16 @@ def test_direct_allgather_between_two_processes_over_hip_ipc(gpu_pkg, tmp_path):
         assert np.array_equal(got[0], got[1])
         for t in range(steps):
             assert np.array_equal(np.concatenate(list(got[0][t]), axis=1).T, want[t]), (overlap, t)
+
+
+def test_group_create_destroy_does_not_leak(gpu_pkg):
+    import torch
+    for _ in range(3):                                        # settle allocator / RCCL one-time allocations
+        gpu_pkg.GroupVectorEnv("CartPole-v1", 1 << 16, 4, devices=[0] * 4, seed=1, auto_reset=True, overlap=True).Close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        with gpu_pkg.GroupVectorEnv("CartPole-v1", 1 << 16, 4, devices=[0] * 4, seed=1, auto_reset=True, overlap=True) as g:
+            g.ResetDevice(); g.AllGatherObs(); g.WaitGather(); g.Sync()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 20)
