@@ -385,3 +385,33 @@ def test_group_create_destroy_does_not_leak(gpu_pkg):
             g.ResetDevice(); g.AllGatherObs(); g.WaitGather(); g.Sync()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < (4 << 20)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_group_rollout_device_equals_single_handle(gpu_pkg, overlap):
+    """gymnet_group_rollout_device: with G > 1 every member replays a captured graph of `ring` steps (one host thread cannot
+    feed G GPUs with eager launches); the result must equal the single-handle rollout bit for bit, also when the observation
+    buffers ping-pong (even-length graphs keep the buffer parity)."""
+    import torch
+    G, n, ring, steps = 4, 4 * 2048, 6, 45                  # 45 = 7 graph replays of 6 + 3 eager steps
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="direct", overlap=overlap) as grp, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as one:
+        nl = grp.LanesPerMember
+        acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(ring):
+            one.SampleActionsDevice(acts[t], seed=8, tick=t)
+        one.Sync()
+        macts = [acts[:, m * nl:(m + 1) * nl].contiguous() for m in range(G)]      # [ring][nl] per member, stride nl
+        torch.cuda.synchronize()
+        one.ResetDevice(); grp.ResetDevice()
+        one.RolloutDevice(acts, steps, n, ring)
+        grp.RolloutDevice(macts, steps, nl, ring)
+        grp.AllGatherObs(); grp.WaitGather(); grp.Sync(); one.Sync()
+        want = one.Read()
+        rep = grp.ReadReplica(G - 1)
+        assert np.array_equal(np.concatenate(list(rep), axis=1).T, want.Observation)
+        for m in range(G):
+            r = grp.Members[m].Read()
+            assert np.array_equal(r.Reward, want.Reward[m * nl:(m + 1) * nl]) and np.array_equal(r.Done, want.Done[m * nl:(m + 1) * nl])
+            assert grp.Members[m].Tick == one.Tick
