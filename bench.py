@@ -276,7 +276,7 @@ def main():
             dist.barrier()
 
     def timed_region(fn, events=True):
-        """One bracketed region: barrier + synchronize, fn(), synchronize + barrier.  Returns (wall s, event ms or nan).
+        """One bracketed region: barrier + synchronize, fn(), synchronize + barrier.  Returns (wall s, event ms or -1).
         events=False leaves the two HIP-event records (a few host us each) out of the wall-clock bracket."""
         if events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -291,7 +291,7 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         t1 = time.perf_counter()
-        return t1 - t0, (e0.elapsed_time(e1) if events else float("nan"))
+        return t1 - t0, (e0.elapsed_time(e1) if events else -1.0)      # -1: a bare region (survives the MAX all-reduce, unlike NaN)
 
     def repeat_until(fn, min_seconds, max_repeats=MAX_REPEATS):
         """Repeats the bracketed region until min_seconds have been timed (every rank runs the same count: the count
@@ -314,10 +314,10 @@ def main():
     torch.cuda.synchronize(dev)
     steps_before = local.Counters()["lane_steps"]
     rows = repeat_until(lambda: run(K), args.min_seconds)
-    bare = [r[0] for r in rows if r[1] != r[1]] or [r[0] for r in rows]      # regions without event records (nan != nan)
+    bare = [r[0] for r in rows if r[1] < 0] or [r[0] for r in rows]          # regions without event records
     walls = bare
     wall = median(bare)
-    ev_ms = median([r[1] for r in rows if r[1] == r[1]])
+    ev_ms = median([r[1] for r in rows if r[1] >= 0])
     repeats = len(rows)
 
     # sanity: the engine really ran K steps on every lane in every repeat
