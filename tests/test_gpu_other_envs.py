@@ -249,6 +249,23 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
                 r = env.Read()
                 res.append((env.GetState(), r.Observation, r.Reward, r.Done, env.EpisodeStats() if stats else None))
         out[(vec, items)] = res
+    # the multi-lane kernel writing into the OTHER observation buffer (GYMNET_FLAG_DOUBLE_BUFFER)
+    monkeypatch.setenv("GYMNET_VEC", "1")
+    monkeypatch.setenv("GYMNET_ITEMS", "4")
+    with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=True, double_buffer=True) as env:
+        acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(ring):
+            env.SampleActionsDevice(acts[t], seed=5, tick=t)
+        env.ResetDevice()
+        rng = np.random.default_rng(4)
+        s0 = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
+        env.SetState(s0)
+        env.RolloutDevice(acts, 40, n + (n % 2), ring)
+        env.RolloutFusedDevice(acts, 25, n + (n % 2), ring)
+        env.Sync()
+        r = env.Read()
+        out[("double buffer", 4)] = [(env.GetState(), r.Observation, r.Reward, r.Done, None)]
     ref = out[(1, 1)]
     for key, res in out.items():
         for a, b in zip(ref, res):
