@@ -337,6 +337,24 @@ class VectorEnv:
         capi.check(self._lib.gymnet_vecenv_final_obs(self._h, _host(o)))
         return o
 
+    # ---- checkpoint / resume (an extension: the reference has none; everything the engine needs to continue bit for bit) ----
+    def Checkpoint(self):
+        """State SoA, engine tick (the Philox counter word) and, without auto-reset, steps_beyond_done.  Together with the
+        seed the caller already holds this determines every later step and reset draw: Restore() + the same actions
+        reproduce the continuation bit for bit (tests/test_gpu_cartpole.py::test_checkpoint_resume_is_bit_exact)."""
+        ck = {"env_id": self.EnvId, "num_envs": self.NumberOfEnvironments, "state": self.GetState(), "tick": self.Tick}
+        if not self.AutoReset and self.EnvId == capi.ENV_CARTPOLE:
+            ck["steps_beyond_done"] = self.GetStepsBeyondDone()
+        return ck
+
+    def Restore(self, ck):
+        if ck["env_id"] != self.EnvId or ck["num_envs"] != self.NumberOfEnvironments:
+            raise ValueError("checkpoint belongs to a different environment / batch size")
+        self.SetState(ck["state"])
+        self.Tick = ck["tick"]
+        if "steps_beyond_done" in ck:
+            self.SetStepsBeyondDone(ck["steps_beyond_done"])
+
     # VecEnv.get_attr / set_attr (VecEnv.cs:74-92) select over IEnv objects; here the per-lane
     # attributes that exist are exposed by name.
     def get_attr(self, name):
