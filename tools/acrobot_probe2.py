@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """Which part of the two-lanes-per-thread Acrobot kernel is slow: the dwordx2 accesses or the packed arithmetic?
-Usage: GYMNET_LIB_PATH=... python tools/acrobot_probe2.py <label>"""
+Usage: GYMNET_LIB_PATH=... python tools/acrobot_probe2.py <label>
+
+The probe builds of the library it is pointed at (never shipped; same sources, one macro each):
+  cd gym.net_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared \
+      kernels.hip capi.hip group.hip -ldl -DGYMNET_PROBE_NO_PACK -o ../lib/libgymnet_amd_nopack.so          # two lanes per thread, scalar math
+  ... -DGYMNET_PROBE_NO_PACK -DGYMNET_PROBE_ACROBOT_NOMATH -o ../lib/libgymnet_amd_nomath.so                  # Acrobot's traffic, no arithmetic
+"""
 import os
 import sys
 
