@@ -92,10 +92,12 @@ def test_autoreset_rollout_stays_in_bounds_and_matches_f32_oracle(gpu_pkg, oracl
 
 
 @pytest.mark.parametrize("name", ["Pendulum-v1", "MountainCar-v0", "Acrobot-v1"])
-def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name):
+@pytest.mark.parametrize("n", [4096, 1 << 20])
+def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name, n):
     # same claim as for CartPole: every float32 operation of the kernel is restated in the oracle's
-    # kernel-semantics functions (own sin/cos, IEEE ops) => bit-for-bit equal states, observations, flags
-    n = 4096
+    # kernel-semantics functions (own sin/cos, IEEE ops) => bit-for-bit equal states, observations, flags.
+    # n = 2^20 is BASELINE's batch (configs 3 and 4): there the launch policy picks the kernels the bench times
+    # (dwordx4 lanes; for Acrobot the multi-lane step_kernel_pipe) — the small case runs the scalar-lane forms.
     rng = np.random.default_rng(31)
     if name == "Pendulum-v1":
         s = np.stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n)]).astype(np.float32)
@@ -112,6 +114,9 @@ def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name):
         a = rng.integers(0, 3, n).astype(np.int32)
         ws, wo, wr, wd = oracle.acrobot_step(s, a, dtype=np.float32)
     with gpu_pkg.VectorEnv(name, n, seed=SEED) as env:
+        if n == 1 << 20:
+            pol = env.LaunchPolicy()
+            assert pol["sequential_lanes_per_thread"] == (4 if name == "Acrobot-v1" else 1) and pol["envs_per_thread"] == (1 if name == "Acrobot-v1" else 4)
         env.Reset(); env.SetState(s)
         out = env.Step(a)
         assert np.array_equal(env.GetState(), ws)
