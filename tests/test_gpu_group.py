@@ -415,3 +415,33 @@ def test_group_rollout_device_equals_single_handle(gpu_pkg, overlap):
             r = grp.Members[m].Read()
             assert np.array_equal(r.Reward, want.Reward[m * nl:(m + 1) * nl]) and np.array_equal(r.Done, want.Done[m * nl:(m + 1) * nl])
             assert grp.Members[m].Tick == one.Tick
+
+
+def test_baseline_config5_shape_on_one_device(gpu_pkg):
+    """BASELINE config 5 — CartPole, 2^23 lanes sharded 8 ways with an observation all-gather — in the only form a 1-GPU box
+    allows: eight LOGICAL members of 2^20 lanes each on device 0, double-buffered, hand-written direct gather overlapped with
+    the next step.  After every step each member's replica [8][4][2^20] must equal the single 2^23-lane batch bit for bit
+    (global-lane Philox keys, rank-major layout, zero-copy send side, buffer ping-pong)."""
+    import torch
+    G, n, steps = 8, 1 << 23, 4
+    nl = n // G
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="direct", overlap=True) as grp, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as one:
+        acts = torch.empty((steps, n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(steps):
+            one.SampleActionsDevice(acts[t], seed=3, tick=t)
+        one.Sync()
+        one.ResetDevice(); grp.ResetDevice()
+        for t in range(steps):
+            one.StepDevice(acts[t])
+            grp.StepDevice([acts[t, m * nl:(m + 1) * nl] for m in range(G)])
+            grp.AllGatherObs()
+            if t % 2 == 0 and t + 1 < steps:
+                continue                                   # this gather stays in flight across the next step
+            grp.WaitGather(); grp.Sync(); one.Sync()
+            want = one.GetState()                          # [4, n] == the observation for CartPole
+            for m in (0, G - 1):
+                rep = grp.ReadReplica(m)                   # [G, 4, nl]
+                assert np.array_equal(np.concatenate(list(rep), axis=1), want), (t, m)
+        assert one.Counters()["lane_steps"] == steps * n
