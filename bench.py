@@ -109,6 +109,15 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    import signal
+
+    def stop_children(signum, frame):                    # the launcher is being stopped: take the ranks with it
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, stop_children)
     rc = 0
     pending = set(range(args.gpus))
     while pending:
