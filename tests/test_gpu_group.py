@@ -445,3 +445,51 @@ def test_baseline_config5_shape_on_one_device(gpu_pkg):
                 rep = grp.ReadReplica(m)                   # [G, 4, nl]
                 assert np.array_equal(np.concatenate(list(rep), axis=1), want), (t, m)
         assert one.Counters()["lane_steps"] == steps * n
+
+
+def test_group_flags_validation_and_bookkeeping(gpu_pkg, oracle):
+    import torch
+    G, n = 4, 4 * 1024
+    nl = n // G
+    rng = np.random.default_rng(17)
+    # VALIDATE_ACTIONS: one bad action anywhere in the batch rejects the step before ANY member has advanced
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="none", validate_actions=True) as grp:
+        grp.Reset()
+        ticks = [m.Tick for m in grp.Members]
+        a = rng.integers(0, 2, n).astype(np.int32)
+        a[2 * nl + 5] = 7                                               # member 2
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            grp.Step(a)
+        assert [m.Tick for m in grp.Members] == ticks
+        da = torch.from_numpy(a).cuda(); torch.cuda.synchronize()
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            grp.StepDevice([da[m * nl:(m + 1) * nl] for m in range(G)])
+        assert [m.Tick for m in grp.Members] == ticks
+        a[2 * nl + 5] = 1
+        grp.Step(a)
+        assert [m.Tick for m in grp.Members] == [t + 1 for t in ticks]
+    # EPISODE_STATS on every member == the slices of the single handle's statistics
+    with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="none", episode_stats=True) as grp, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True) as one:
+        grp.Reset(); one.Reset()
+        for t in range(60):
+            a = rng.integers(0, 2, n).astype(np.int32)
+            grp.Step(a); one.Step(a)
+        ret, ln = one.EpisodeStats()
+        assert ln.max() > 0
+        for m in range(G):
+            r, l = grp.Members[m].EpisodeStats()
+            assert np.array_equal(r, ret[m * nl:(m + 1) * nl]) and np.array_equal(l, ln[m * nl:(m + 1) * nl])
+    # the stand-alone masked sampler (no handle): Discrete.Sample(mask) for an arbitrary lane range
+    lib, capi = gpu_pkg.load_library(), gpu_pkg._capi
+    cnt = 3000
+    mask = rng.integers(0, 2, (cnt, 5)).astype(np.uint8)
+    dm = torch.from_numpy(mask).cuda()
+    out = torch.empty(cnt, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    capi.check(lib.gymnet_sample_discrete_masked_device(0, None, C.c_void_p(out.data_ptr()), cnt, 5, 10, C.c_void_p(dm.data_ptr()), 5, 99, 1234, 6))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.discrete_sample_masked(99, 1234, 6, 5, 10, mask, cnt))
+    capi.check(lib.gymnet_sample_discrete_masked_device(0, None, C.c_void_p(out.data_ptr()), cnt, 5, 10, None, 0, 99, 1234, 6))   # no mask: Discrete.cs:27
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.discrete_sample(99, 1234, 6, 5, 10, cnt))
