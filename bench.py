@@ -69,7 +69,7 @@ def cpu_baseline(num_envs, target_seconds):
     cannot run here) timed on all host cores over a bounded sample of the same workload."""
     from oracle import capi as oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    hw, cores, why = usable_cpus()
     probe = oracle.cpu_baseline(num_envs, 4, cores, alloc_faithful=True)
     rate = probe["steps_per_sec"]
     t_steps = int(max(8, min(4096, target_seconds * rate / num_envs)))
@@ -80,8 +80,37 @@ def cpu_baseline(num_envs, target_seconds):
             "sample": f"{num_envs} per-instance float64 CartPole envs x {t_steps} steps, reset-on-done, "
                       f"split over {cores} threads, 2 heap allocations per step like the C# path "
                       f"({r['seconds']:.1f} s)",
+            "host": f"{hw} hardware threads; {cores} usable by this process ({why})",
             "no_alloc_variant_value": r0["steps_per_sec"],
             "single_instance_100k_steps_per_sec": r1["steps_per_sec"]}
+
+
+def usable_cpus():
+    """(hardware threads, CPUs this process may actually use, what limits them): the affinity mask and the cgroup CPU
+    quota both count — a 256-thread host under a 16-CPU quota runs 16 threads' worth of work however many are started."""
+    hw = os.cpu_count() or 1
+    n, why = hw, "no limit below the hardware"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "affinity mask"
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, why = q, f"cgroup CPU quota {quota}/{int(period)} us"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return hw, n, why
 
 
 def _free_port():
@@ -207,8 +236,11 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the engine has no CPU fallback")
     # one process per GPU; GYMNET_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist (a 1-GPU box can then
     # exercise the N > 1 plumbing: lane offsets, shard buffers, barrier, max-over-ranks) — RCCL needs one GPU per rank
-    backend = os.environ.get("GYMNET_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    # — also chosen automatically when a launcher (torch.distributed.run) starts more ranks than the node has GPUs
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    n_dev = torch.cuda.device_count()            # does not initialise the GPU on this image
+    backend = os.environ.get("GYMNET_BENCH_BACKEND", "nccl" if n_dev >= local_world else "gloo")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     red_dev = dev if backend == "nccl" else torch.device("cpu")      # where the timing reduction tensors live
@@ -395,6 +427,9 @@ def main():
         rank 0 prints the headline it already has, with the section marked as timed out, and every rank leaves."""
         def fire():
             if emitted.acquire(blocking=False):
+                import faulthandler
+                sys.stderr.write(f"[bench rank {rank}] section {section!r} timed out after {seconds} s; stacks:\n")
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)    # where each rank was stuck
                 if rank == 0:
                     out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
                     print(json.dumps(out), flush=True)
@@ -444,7 +479,7 @@ def main():
     if use_dist and not gather_in_region:
         gathered = {}
         gs = 128
-        watchdog = emit_and_exit_on_timeout("with_obs_allgather", 240)
+        watchdog = emit_and_exit_on_timeout("with_obs_allgather", int(os.environ.get("GYMNET_BENCH_WATCHDOG", "120")))
         # serial / overlapped: RCCL all_gather_into_tensor; direct_ipc / direct_ipc_overlapped: the hand-written push of each
         # rank's slice into its peers' replica buffers (HIP IPC peer buffers, gymnet_push_obs_device; one xGMI link per peer)
         for label, overlapped, how in (("serial", False, "rccl"), ("overlapped", True, "rccl"),
@@ -477,6 +512,7 @@ def main():
                                    "steps": gs, "repeats": len(grows), "gathered_obs_finite_and_nonzero": ok}
             except Exception as e:                      # never lose the headline over the optional collective
                 gathered[label] = {"error": repr(e)[:200]}
+                sys.stderr.write(f"[bench rank {rank}] with_obs_allgather/{label}: {e!r}\n")
             finally:
                 if own and genv is not None:
                     genv.Sync()

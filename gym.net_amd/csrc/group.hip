@@ -18,6 +18,7 @@
 //   A step that is about to overwrite buffer b first waits for the member's own ev_push[b][m] (its slice is still being read).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <cstring>
@@ -212,12 +213,40 @@ int gymnet_peer_buffer_create(int device, int64_t bytes, void **d_ptr, gymnet_ip
     static_assert(sizeof(gymnet_ipc_handle) == sizeof(hipIpcMemHandle_t), "gymnet_ipc_handle must be a hipIpcMemHandle_t");
     DeviceScope scope;
     HIP_TRY(nullptr, hipSetDevice(device));
+    // The export (dmabuf under HSA_ENABLE_IPC_MODE_LEGACY=0) has been seen to fail with "invalid argument" now and then
+    // when several processes create and tear down peer buffers on one GPU at the same moment; a fresh allocation at
+    // another address succeeds.  So: a few attempts, each keeping the rejected allocation alive until the end (the next
+    // hipMalloc then cannot hand back the same range), with a short back-off.
+    constexpr int kAttempts = 4;
+    void *rejected[kAttempts] = {};
+    hipError_t e = hipSuccess;
+    const char *what = "";
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, (size_t)bytes);
-    if (e != hipSuccess) return fail(nullptr, GYMNET_ERR_OOM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
-    e = hipMemset(p, 0, (size_t)bytes);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), p);
-    if (e != hipSuccess) { (void)hipFree(p); return fail(nullptr, GYMNET_ERR_HIP, "hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e)); }
+    bool oom = false;
+    for (int attempt = 0; attempt < kAttempts; ++attempt) {
+        p = nullptr;
+        e = hipMalloc(&p, (size_t)bytes);
+        what = "hipMalloc";
+        if (e != hipSuccess) { p = nullptr; oom = true; break; }
+        e = hipMemset(p, 0, (size_t)bytes);
+        what = "hipMemset";
+        if (e == hipSuccess) {
+            e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), p);
+            what = "hipIpcGetMemHandle";
+        }
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        rejected[attempt] = p;
+        p = nullptr;
+        usleep(2000u << attempt);
+    }
+    for (void *r : rejected) if (r) (void)hipFree(r);
+    if (e != hipSuccess || !p) {
+        if (p) (void)hipFree(p);
+        return fail(nullptr, oom ? GYMNET_ERR_OOM : GYMNET_ERR_HIP,
+                    "%s(%lld bytes) failed: %s (peer buffers need HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform)", what,
+                    (long long)bytes, hipGetErrorString(e));
+    }
     *d_ptr = p;
     return GYMNET_OK;
     });

@@ -142,24 +142,53 @@ class ShardedVectorEnv:
         lib = _capi.load_library()
         nbytes = int(np.prod(shape)) * 4
         base, handle = C.c_void_p(), _capi.IpcHandle()
-        _capi.check(lib.gymnet_peer_buffer_create(int(device), nbytes, C.byref(base), C.byref(handle)))
-        self._own_base, self._peer_dev, self._lib = base.value, int(device), lib
+        self._peer_dev, self._lib, self._peers = int(device), lib, {}
+
+        def agree(err, payload=None):
+            """Every rank reports (error or None, payload); a failure anywhere is raised EVERYWHERE, so no rank goes on to a
+            collective or a barrier its peers will never reach."""
+            got = [None] * self.world_size
+            dist.all_gather_object(got, (err, payload), group=self.group)
+            bad = {r: e for r, (e, _) in enumerate(got) if e is not None}
+            return bad, [pl for _, pl in got]
+
+        err = None
+        try:
+            _capi.check(lib.gymnet_peer_buffer_create(int(device), nbytes, C.byref(base), C.byref(handle)))
+        except Exception as e:                                      # noqa: BLE001 - reported to every rank below
+            err = repr(e)
+        # all 64 bytes of the struct (a c_char array FIELD reads back as a C string, cut at the first NUL)
+        bad, handles = agree(err, None if err else C.string_at(C.byref(handle), 64))
+        if bad:
+            if err is None:
+                lib.gymnet_peer_buffer_destroy(int(device), base)
+            raise RuntimeError(f"peer buffer creation failed on rank(s) {sorted(bad)}: {next(iter(bad.values()))}")
+        self._own_base = base.value
+        err = None
+        try:
+            for r, hb in enumerate(handles):
+                if r == self.rank:
+                    continue
+                h, p = _capi.IpcHandle(), C.c_void_p()
+                assert len(hb) == 64
+                C.memmove(C.byref(h), hb, 64)
+                _capi.check(lib.gymnet_peer_buffer_open(int(device), C.byref(h), C.byref(p)))
+                self._peers[r] = p.value
+        except Exception as e:                                      # noqa: BLE001
+            err = repr(e)
+        bad, _ = agree(err)
+        if bad:
+            for p in self._peers.values():
+                lib.gymnet_peer_buffer_close(int(device), p)
+            self._peers = None
+            agree(None)                                             # every importer has unmapped before any exporter frees
+            lib.gymnet_peer_buffer_destroy(int(device), self._own_base)
+            self._own_base = None
+            raise RuntimeError(f"opening peer buffers failed on rank(s) {sorted(bad)}: {next(iter(bad.values()))}")
 
         class _Raw:                                   # zero-copy torch view of the library's allocation
-            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (base.value, False), "version": 2}
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (self._own_base, False), "version": 2}
         t = torch.as_tensor(_Raw(), device=self.tensor_device)
-        handles = [None] * self.world_size
-        # all 64 bytes of the struct (a c_char array FIELD reads back as a C string, cut at the first NUL)
-        dist.all_gather_object(handles, C.string_at(C.byref(handle), 64), group=self.group)
-        self._peers = {}
-        for r, hb in enumerate(handles):
-            if r == self.rank:
-                continue
-            h, p = _capi.IpcHandle(), C.c_void_p()
-            assert len(hb) == 64
-            C.memmove(C.byref(h), hb, 64)
-            _capi.check(lib.gymnet_peer_buffer_open(int(device), C.byref(h), C.byref(p)))
-            self._peers[r] = p.value
         return t
 
     def _push(self, b, stream_ptr):
@@ -290,8 +319,12 @@ class ShardedVectorEnv:
             if self._cuda:
                 self._torch.cuda.synchronize(self.tensor_device)
             self._barrier()                                   # nobody still pushes into a buffer that is about to go away
-            for p in self._peers.values():
-                self._lib.gymnet_peer_buffer_close(self._peer_dev, p)
+            import sys
+            for r, p in self._peers.items():
+                if self._lib.gymnet_peer_buffer_close(self._peer_dev, p) != 0:
+                    sys.stderr.write(f"gym.net_amd: closing rank {r}'s peer buffer failed on rank {self.rank}\n")
             self._peers = None
             self.obs_bufs = self.obs_all = None
-            self._lib.gymnet_peer_buffer_destroy(self._peer_dev, self._own_base)
+            self._barrier()                                   # every importer has unmapped before any exporter frees
+            if self._lib.gymnet_peer_buffer_destroy(self._peer_dev, self._own_base) != 0:
+                sys.stderr.write(f"gym.net_amd: freeing rank {self.rank}'s peer buffer failed\n")

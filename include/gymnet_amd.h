@@ -339,7 +339,9 @@ int gymnet_group_step(gymnet_group *g, const void *actions, float *obs_out, floa
  * [G][obs_dim][N/G] as a peer buffer, hands the 64-byte handle to the other ranks by whatever channel it has, opens theirs,
  * creates its handle with d_ext_obs = buffer + rank * obs_dim * (N/G), and after a step pushes its slice into every
  * peer's replica.  Cross-process ordering is the host's: synchronize the stream, then a node barrier, before anyone reads a
- * replica or pushes into it again.  (HIP IPC; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform's driver.) */
+ * replica or pushes into it again.  Teardown in the same spirit: barrier, every rank closes what it opened, barrier,
+ * then every rank destroys what it created (no exporter frees memory a peer still has mapped).
+ * (HIP IPC; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform's driver.) */
 typedef struct gymnet_ipc_handle { char bytes[64]; } gymnet_ipc_handle;
 int gymnet_peer_buffer_create(int device, int64_t bytes, void **d_ptr, gymnet_ipc_handle *handle);   /* hipMalloc + zero + export */
 int gymnet_peer_buffer_open(int device, const gymnet_ipc_handle *handle, void **d_ptr);              /* map a peer's buffer */

@@ -311,6 +311,26 @@ def test_plain_bench_gpus_2_spawns_its_own_ranks(gpu_pkg):
         assert g[k].get("gathered_obs_finite_and_nonzero") is True and g[k]["value"] > 1e8, g
 
 
+@pytest.mark.gpu
+def test_bench_under_the_launcher_the_driver_uses(gpu_pkg):
+    """`python -m torch.distributed.run --nproc-per-node 2 … bench.py --gpus 2 …` — the contract's launch line for N > 1.
+    With fewer GPUs than ranks the ranks share the device over gloo (chosen automatically, labelled); with one GPU per
+    rank the same command runs over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GYMNET_BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--ring", "8", "--num-envs", str(1 << 18),
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 5 and j["scaling"] == "weak" and j["value"] > 1e8
+    import torch
+    assert ("gloo" in j["config"]["backend"]) == (torch.cuda.device_count() < 2)
+
+
 DIRECT_CHILD = r"""
 import os, sys, json
 import numpy as np
