@@ -304,7 +304,7 @@ static uint64_t g_host_tick = 0;
 template <int VEC, int NT>
 void LPROD(const Args &a, hipStream_t st) {
     StepArgs s{};
-    s.state = a.s0; s.obs = a.s0; s.action = a.action; s.reward = a.reward; s.done = a.done;
+    s.state = a.s0; s.state_out = a.s0; s.obs = a.s0; s.action = a.action; s.reward = a.reward; s.done = a.done;
     s.tick2 = g_tick2; s.n = a.n; s.state_stride = a.s1 - a.s0; s.obs_stride = s.state_stride;
     s.seed = a.seed; s.parity = (int32_t)(g_host_tick & 1); s.cparity = s.parity;
     ++g_host_tick;
