@@ -254,6 +254,75 @@ def test_csharp_binding_sources_lex_cleanly_and_cover_the_header():
         assert cs in srcs["Native.cs"] and c in open(os.path.join(ROOT, "include", "gymnet_amd.h")).read()
 
 
+def _split_args(argtext):
+    """Top-level comma split of an argument / parameter list."""
+    out, depth, cur = [], 0, ""
+    for ch in argtext:
+        if ch in "([{<":
+            depth += 1
+        elif ch in ")]}>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return [a for a in out if a != "void"]
+
+
+def _call_args(text, start):
+    """The argument text of the call whose '(' is at text[start]."""
+    depth = 0
+    for i in range(start, len(text)):
+        depth += text[i] == "("
+        depth -= text[i] == ")"
+        if depth == 0:
+            return text[start + 1:i]
+    raise AssertionError("unbalanced call")
+
+
+def test_csharp_imports_and_call_sites_have_the_headers_arity():
+    """Uncompiled C# again: every [DllImport] takes as many parameters as the C prototype it binds, and every
+    Native.gymnet_*(...) call in VectorEnv.cs passes as many arguments as that import declares."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gymnet_amd.h")).read(), flags=re.S)
+    c_arity = {}
+    for m in re.finditer(r"\b(gymnet_[a-z_0-9]+)\s*\(", hdr):
+        c_arity[m.group(1)] = len(_split_args(_call_args(hdr, m.end() - 1)))
+    srcs = _csharp_sources()
+    native = re.sub(r"//.*", "", srcs["Native.cs"])
+    cs_arity = {}
+    for m in re.finditer(r"public static extern (?:int|IntPtr) (gymnet_[a-z_0-9]+)\(", native):
+        cs_arity[m.group(1)] = len(_split_args(_call_args(native, m.end() - 1)))
+    assert cs_arity.keys() == c_arity.keys()
+    wrong = {k: (cs_arity[k], c_arity[k]) for k in c_arity if cs_arity[k] != c_arity[k]}
+    assert not wrong, wrong
+    managed = re.sub(r"//.*", "", srcs["VectorEnv.cs"])
+    calls = 0
+    for m in re.finditer(r"Native\.(gymnet_[a-z_0-9]+)\(", managed):
+        got = len(_split_args(_call_args(managed, m.end() - 1)))
+        assert got == cs_arity[m.group(1)], (m.group(1), got, cs_arity[m.group(1)], managed[m.start():m.start() + 120])
+        calls += 1
+    assert calls >= 20
+
+
+def test_ctypes_prototypes_have_the_headers_arity(gymnet):
+    """The ctypes mirror declares argtypes for every exported function, with as many parameters as the C prototype."""
+    from importlib import import_module
+    capi = import_module(gymnet.__name__ + "._capi")
+    lib = capi.load_library()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gymnet_amd.h")).read(), flags=re.S)
+    wrong = {}
+    for m in re.finditer(r"\b(gymnet_[a-z_0-9]+)\s*\(", hdr):
+        want = len(_split_args(_call_args(hdr, m.end() - 1)))
+        fn = getattr(lib, m.group(1))
+        got = None if fn.argtypes is None else len(fn.argtypes)
+        if got != want:
+            wrong[m.group(1)] = (got, want)
+    assert not wrong, wrong
+
+
 # IVecEnv (src/Gym/Envs/IVecEnv.cs:8-19): the methods a polymorphic caller can reach; VecEnv implements Seed(int), Seed(int[])
 # NON-virtually (VecEnv.cs:44-53) and StepAsync likewise (VecEnv.cs:63-65), Reset / Step / Close abstractly.
 IVECENV_METHODS = {"Reset": "NDArray[] Reset()", "Step": "Step[] Step(int action)", "Close": "void Close()",
