@@ -87,3 +87,80 @@ def test_two_rank_sharded_rollout_equals_single_shard(tmp_path, oracle, overlap)
         s = s2
         gathered = got[0][t]                               # [G, 4, N/G] rank-major
         assert np.array_equal(np.concatenate(list(gathered), axis=1), s), t
+
+
+def _failing_setup_worker(rank, world, port, out_dir, fail_stage):
+    """Peer-buffer set-up with a library whose export (stage "create") or import (stage "open") fails on rank 1 only."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    import importlib
+    capi = importlib.import_module(pkg.__name__ + "._capi")
+    sharding = importlib.import_module(pkg.__name__ + ".sharding")
+    calls = []
+
+    class FakeLib:
+        def gymnet_peer_buffer_create(self, device, nbytes, base, handle):
+            calls.append("create")
+            if fail_stage == "create" and rank == 1:
+                return capi.ERR_HIP
+            C.cast(base, C.POINTER(C.c_void_p))[0] = C.c_void_p(0x1000 * (rank + 1))
+            return 0
+
+        def gymnet_peer_buffer_open(self, device, handle, out):
+            calls.append("open")
+            if fail_stage == "open" and rank == 1:
+                return capi.ERR_HIP
+            C.cast(out, C.POINTER(C.c_void_p))[0] = C.c_void_p(0x9000)
+            return 0
+
+        def gymnet_peer_buffer_close(self, device, p):
+            calls.append("close")
+            return 0
+
+        def gymnet_peer_buffer_destroy(self, device, p):
+            calls.append("destroy")
+            return 0
+
+        def gymnet_last_error(self):
+            return b"injected failure"
+
+    fake = FakeLib()
+    capi.load_library = lambda: fake
+    env = sharding.ShardedVectorEnv.__new__(sharding.ShardedVectorEnv)
+    import torch
+    env._torch, env._dist, env.group = torch, dist, None
+    env.rank, env.world_size, env.tensor_device = rank, world, torch.device("cpu")
+    msg = ""
+    try:
+        env._make_peer_buffers((1, world, 4, 16), 0)
+    except RuntimeError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(msg + "\n" + " ".join(calls))
+    dist.barrier()                                        # both ranks are still in step: nobody is stuck in a collective
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail_stage", ["create", "open"])
+def test_peer_buffer_setup_failure_on_one_rank_is_raised_on_every_rank(tmp_path, fail_stage):
+    """The fault the 8-rank exercise found: one rank's HIP-IPC export failed and the others waited in a collective for
+    ever.  Now every rank reports its set-up result; a failure anywhere raises everywhere and what was created / opened
+    is released in order (importers close, then exporters free)."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_failing_setup_worker, args=(world, port, str(tmp_path), fail_stage), nprocs=world, join=True)
+    for r in range(world):
+        msg, calls = open(tmp_path / f"rank{r}.txt").read().split("\n")
+        assert "rank(s) [1]" in msg and ("creation failed" if fail_stage == "create" else "opening peer buffers failed") in msg, msg
+        calls = calls.split()
+        if fail_stage == "create":
+            assert calls == (["create", "destroy"] if r == 0 else ["create"]), calls
+        else:
+            assert calls == (["create", "open", "close", "destroy"] if r == 0 else ["create", "open", "destroy"]), calls
