@@ -545,6 +545,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
     if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
     if (const char *e = std::getenv("GYMNET_ITEMS")) { int v = std::atoi(e); if (v >= 1 && v <= 5) h->lcfg.items = v; }
+    if (const char *e = std::getenv("GYMNET_RESET_FORM")) { int v = std::atoi(e); if (v == 0 || v == 1) h->lcfg.reset_form = v; }
     if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY

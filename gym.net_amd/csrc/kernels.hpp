@@ -42,7 +42,9 @@ constexpr int kAfterStride = 8;     // uint64 words between after_done shards (6
 
 // lds_bytes: unused dynamic LDS requested per workgroup, for the ONE purpose of capping occupancy in probes (GYMNET_LDS)
 // items: lanes per thread of the fully unrolled software-pipelined kernel (envs with PIPELINED only; 1 = one-shot kernel)
-struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; };
+// reset_form: 1 = wave-compacted fused reset in the one-step kernel (reset_pending_wave: envs whose observation aliases the
+// state, dwordx4 lanes, lean variant)
+struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

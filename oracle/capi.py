@@ -70,6 +70,11 @@ def lib():
     L.ref_acrobot_step_f32.argtypes = [_f32p, C.c_int, _f32p, C.POINTER(C.c_float)]
     L.ref_acrobot_step_f32.restype = C.c_int
     L.ref_acrobot_reset_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
+    L.ref_env_step_batch_f32.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_void_p, _f32p, _f32p, _u8p, C.c_int64]
+    L.ref_env_step_batch_f64.argtypes = [C.c_int, _f64p, C.c_void_p, C.c_void_p, _f64p, _f64p, _u8p, C.c_int64]
+    L.ref_env_reset_batch_f32.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _f32p, C.c_void_p, C.c_int64]
+    L.ref_env_autoreset_step_batch_f32.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, _f32p, C.c_void_p,
+                                                   _f32p, _f32p, _u8p, C.c_int64]
     L.ref_cpu_baseline_run.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64,
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.ref_cpu_baseline_run.restype = C.c_double
@@ -160,78 +165,87 @@ def box_uniform_sample(seed, lane0, tick, low, high, count):
     return out
 
 
-def _per_lane(fn_reset, dim, seed, lane0, tick, n):
-    out = np.zeros((dim, n), dtype=np.float32)
-    tmp = np.zeros(dim, dtype=np.float32)
-    for i in range(n):
-        fn_reset(seed, lane0 + i, tick, tmp)
-        out[:, i] = tmp
-    return out
+ENV_IDS = {"CartPole-v1": 0, "Pendulum-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3}
+_DIMS = {0: (4, 4), 1: (2, 3), 2: (2, 2), 3: (4, 6)}          # env_id -> (state dim, observation dim)
+
+
+def _env_id(env):
+    return ENV_IDS[env] if isinstance(env, str) else int(env)
+
+
+def _actions(env_id, action):
+    return np.ascontiguousarray(np.asarray(action, dtype=np.float32 if env_id == 1 else np.int32))
+
+
+def env_step(env, state, action, sbd=None, dtype=np.float64):
+    """One batched step of any env over SoA state [S, n] (loops the per-instance restatement in C).
+    Returns (new_state[S,n], obs[O,n], reward[n], done u8[n]) in `dtype`; sbd (CartPole, int32[n]) is updated in place."""
+    e = _env_id(env)
+    S, O = _DIMS[e]
+    s = np.ascontiguousarray(np.array(state, dtype=dtype, copy=True))
+    assert s.shape[0] == S
+    n = s.shape[1]
+    a = _actions(e, action)
+    obs = np.zeros((O, n), dtype=dtype); rew = np.zeros(n, dtype=dtype); done = np.zeros(n, dtype=np.uint8)
+    b = None if sbd is None else sbd.ctypes.data_as(C.c_void_p)
+    fn = lib().ref_env_step_batch_f64 if dtype == np.float64 else lib().ref_env_step_batch_f32
+    fn(e, s, a.ctypes.data_as(C.c_void_p), b, obs, rew, done, n)
+    return s, obs, rew, done
+
+
+def env_reset(env, seed, lane0, tick, n, with_obs=False):
+    """The engine's reset draw for global lanes [lane0, lane0 + n) at `tick` (float32 SoA [S, n]); with_obs adds the observation."""
+    e = _env_id(env)
+    S, O = _DIMS[e]
+    s = np.zeros((S, n), dtype=np.float32)
+    o = np.zeros((O, n), dtype=np.float32) if with_obs else None
+    lib().ref_env_reset_batch_f32(e, seed, lane0, tick, s, None if o is None else o.ctypes.data_as(C.c_void_p), n)
+    return (s, o) if with_obs else s
+
+
+def env_autoreset_step(env, seed, lane0, tick, state, action, lane_seed=None):
+    """One vector step with the fused auto-reset, kernel (float32) semantics: finished lanes are re-drawn with
+    Philox(seed or lane_seed[i], (lane0 + i, tick)).  Returns (state[S,n], obs[O,n], reward[n], done u8[n])."""
+    e = _env_id(env)
+    S, O = _DIMS[e]
+    s = np.ascontiguousarray(np.array(state, dtype=np.float32, copy=True))
+    n = s.shape[1]
+    a = _actions(e, action)
+    obs = np.zeros((O, n), dtype=np.float32); rew = np.zeros(n, dtype=np.float32); done = np.zeros(n, dtype=np.uint8)
+    ls = None
+    if lane_seed is not None:
+        lane_seed = np.ascontiguousarray(np.asarray(lane_seed, dtype=np.uint64))
+        ls = lane_seed.ctypes.data_as(C.c_void_p)
+    lib().ref_env_autoreset_step_batch_f32(e, seed, ls, lane0, tick, s, a.ctypes.data_as(C.c_void_p), obs, rew, done, n)
+    return s, obs, rew, done
 
 
 def pendulum_reset(seed, lane0, tick, n):
-    return _per_lane(lib().ref_pendulum_reset_f32, 2, seed, lane0, tick, n)
+    return env_reset(1, seed, lane0, tick, n)
 
 
 def mountaincar_reset(seed, lane0, tick, n):
-    return _per_lane(lib().ref_mountaincar_reset_f32, 2, seed, lane0, tick, n)
+    return env_reset(2, seed, lane0, tick, n)
 
 
 def acrobot_reset(seed, lane0, tick, n):
-    return _per_lane(lib().ref_acrobot_reset_f32, 4, seed, lane0, tick, n)
+    return env_reset(3, seed, lane0, tick, n)
 
 
 def pendulum_step(state, action, dtype=np.float64):
     """Returns (new_state[2,n], obs[3,n], reward[n], done u8[n] (always 0))."""
-    s = np.array(state, dtype=dtype, copy=True)
-    n = s.shape[1]
-    obs = np.zeros((3, n), dtype=dtype)
-    rew = np.zeros(n, dtype=dtype)
-    L = lib()
-    st = np.zeros(2, dtype=dtype); o = np.zeros(3, dtype=dtype)
-    for i in range(n):
-        st[:] = s[:, i]
-        if dtype == np.float64:
-            r = C.c_double(); L.ref_pendulum_step_f64(st, float(action[i]), o, C.byref(r))
-        else:
-            r = C.c_float(); L.ref_pendulum_step_f32(st, float(action[i]), o, C.byref(r))
-        s[:, i] = st; obs[:, i] = o; rew[i] = r.value
-    return s, obs, rew, np.zeros(n, dtype=np.uint8)
+    return env_step(1, state, action, dtype=dtype)
 
 
 def mountaincar_step(state, action, dtype=np.float64):
     """Returns (new_state[2,n], reward[n], done u8[n])."""
-    s = np.array(state, dtype=dtype, copy=True)
-    n = s.shape[1]
-    rew = np.zeros(n, dtype=dtype); done = np.zeros(n, dtype=np.uint8)
-    L = lib()
-    st = np.zeros(2, dtype=dtype)
-    for i in range(n):
-        st[:] = s[:, i]
-        if dtype == np.float64:
-            r = C.c_double(); d = L.ref_mountaincar_step_f64(st, int(action[i]), C.byref(r))
-        else:
-            r = C.c_float(); d = L.ref_mountaincar_step_f32(st, int(action[i]), C.byref(r))
-        s[:, i] = st; rew[i] = r.value; done[i] = d
-    return s, rew, done
+    s, _, r, d = env_step(2, state, action, dtype=dtype)
+    return s, r, d
 
 
 def acrobot_step(state, action, dtype=np.float64):
     """Returns (new_state[4,n], obs[6,n], reward[n], done u8[n])."""
-    s = np.array(state, dtype=dtype, copy=True)
-    n = s.shape[1]
-    obs = np.zeros((6, n), dtype=dtype)
-    rew = np.zeros(n, dtype=dtype); done = np.zeros(n, dtype=np.uint8)
-    L = lib()
-    st = np.zeros(4, dtype=dtype); o = np.zeros(6, dtype=dtype)
-    for i in range(n):
-        st[:] = s[:, i]
-        if dtype == np.float64:
-            r = C.c_double(); d = L.ref_acrobot_step_f64(st, int(action[i]), o, C.byref(r))
-        else:
-            r = C.c_float(); d = L.ref_acrobot_step_f32(st, int(action[i]), o, C.byref(r))
-        s[:, i] = st; obs[:, i] = o; rew[i] = r.value; done[i] = d
-    return s, obs, rew, done
+    return env_step(3, state, action, dtype=dtype)
 
 
 def cpu_baseline(n_envs, steps, threads, alloc_faithful=True, seed=0x5EED):

@@ -492,3 +492,111 @@ void ref_acrobot_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float st
     ref_reset_words(seed, lane, tick, w);
     for (int k = 0; k < 4; ++k) state[k] = -0.1f + 0.2f * u01_24(w[k]);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Batched conveniences over structure-of-arrays [dim][n] for every env (env_id: 0 CartPole, 1 Pendulum,
+ * 2 MountainCar, 3 Acrobot), so the parity tests can replay FULL-SIZE (2^20-lane) launches in seconds.
+ * They only loop the per-instance functions above; nothing new is restated here except the observation
+ * of a freshly reset state (the same sin/cos the step uses).  `action` is int32[n], or float32[n] for Pendulum.
+ * ---------------------------------------------------------------------------------------- */
+static const int ENV_S[4] = {4, 2, 2, 4};
+static const int ENV_O[4] = {4, 3, 2, 6};
+
+int ref_env_state_dim(int env_id) { return (env_id >= 0 && env_id < 4) ? ENV_S[env_id] : -1; }
+int ref_env_obs_dim(int env_id) { return (env_id >= 0 && env_id < 4) ? ENV_O[env_id] : -1; }
+
+static void observe_f32(int env_id, const float *s, float *o) {
+    switch (env_id) {
+        case 0: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; break;             /* CartPoleEnv.cs:166,185 */
+        case 1: ref_sincos_f32_kernel(s[0], &o[1], &o[0]); o[2] = s[1]; break;
+        case 2: o[0] = s[0]; o[1] = s[1]; break;
+        default: ref_sincos_f32_kernel(s[0], &o[1], &o[0]); ref_sincos_f32_kernel(s[1], &o[3], &o[2]); o[4] = s[2]; o[5] = s[3]; break;
+    }
+}
+
+static void reset_f32(int env_id, uint64_t seed, uint64_t lane, uint64_t tick, float *s) {
+    switch (env_id) {
+        case 0: ref_cartpole_reset_f32(seed, lane, tick, s); break;
+        case 1: ref_pendulum_reset_f32(seed, lane, tick, s); break;
+        case 2: ref_mountaincar_reset_f32(seed, lane, tick, s); break;
+        default: ref_acrobot_reset_f32(seed, lane, tick, s); break;
+    }
+}
+
+/* one instance, kernel semantics; CartPole with sbd = -1 at entry (what the fused auto-reset guarantees) unless sbd given */
+static int step_one_f32(int env_id, float *s, const void *action, int64_t i, int32_t *sbd, float *o, float *reward) {
+    int done;
+    switch (env_id) {
+        case 0: { int b = sbd ? *sbd : -1; done = ref_cartpole_step_f32(s, ((const int32_t *)action)[i], &b, reward); if (sbd) *sbd = b; observe_f32(0, s, o); break; }
+        case 1: ref_pendulum_step_f32(s, ((const float *)action)[i], o, reward); done = 0; break;
+        case 2: done = ref_mountaincar_step_f32(s, ((const int32_t *)action)[i], reward); observe_f32(2, s, o); break;
+        default: done = ref_acrobot_step_f32(s, ((const int32_t *)action)[i], o, reward); break;
+    }
+    return done;
+}
+
+static int step_one_f64(int env_id, double *s, const void *action, int64_t i, int32_t *sbd, double *o, double *reward) {
+    int done;
+    switch (env_id) {
+        case 0: { int b = sbd ? *sbd : -1; float r; done = ref_cartpole_step_f64(s, ((const int32_t *)action)[i], &b, &r); if (sbd) *sbd = b;
+                  *reward = r; for (int k = 0; k < 4; ++k) o[k] = s[k]; break; }
+        case 1: ref_pendulum_step_f64(s, (double)((const float *)action)[i], o, reward); done = 0; break;
+        case 2: done = ref_mountaincar_step_f64(s, ((const int32_t *)action)[i], reward); o[0] = s[0]; o[1] = s[1]; break;
+        default: done = ref_acrobot_step_f64(s, ((const int32_t *)action)[i], o, reward); break;
+    }
+    return done;
+}
+
+void ref_env_step_batch_f32(int env_id, float *state_soa, const void *action, int32_t *sbd, float *obs_soa, float *reward,
+                            uint8_t *done, int64_t n) {
+    const int S = ENV_S[env_id], O = ENV_O[env_id];
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4], o[6], r;
+        for (int k = 0; k < S; ++k) s[k] = state_soa[(int64_t)k * n + i];
+        done[i] = (uint8_t)step_one_f32(env_id, s, action, i, sbd ? &sbd[i] : 0, o, &r);
+        reward[i] = r;
+        for (int k = 0; k < S; ++k) state_soa[(int64_t)k * n + i] = s[k];
+        for (int k = 0; k < O; ++k) obs_soa[(int64_t)k * n + i] = o[k];
+    }
+}
+
+void ref_env_step_batch_f64(int env_id, double *state_soa, const void *action, int32_t *sbd, double *obs_soa, double *reward,
+                            uint8_t *done, int64_t n) {
+    const int S = ENV_S[env_id], O = ENV_O[env_id];
+    for (int64_t i = 0; i < n; ++i) {
+        double s[4], o[6], r;
+        for (int k = 0; k < S; ++k) s[k] = state_soa[(int64_t)k * n + i];
+        done[i] = (uint8_t)step_one_f64(env_id, s, action, i, sbd ? &sbd[i] : 0, o, &r);
+        reward[i] = r;
+        for (int k = 0; k < S; ++k) state_soa[(int64_t)k * n + i] = s[k];
+        for (int k = 0; k < O; ++k) obs_soa[(int64_t)k * n + i] = o[k];
+    }
+}
+
+void ref_env_reset_batch_f32(int env_id, uint64_t seed, uint64_t lane0, uint64_t tick, float *state_soa, float *obs_soa, int64_t n) {
+    const int S = ENV_S[env_id], O = ENV_O[env_id];
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4], o[6];
+        reset_f32(env_id, seed, lane0 + (uint64_t)i, tick, s);
+        observe_f32(env_id, s, o);
+        for (int k = 0; k < S; ++k) state_soa[(int64_t)k * n + i] = s[k];
+        if (obs_soa) for (int k = 0; k < O; ++k) obs_soa[(int64_t)k * n + i] = o[k];
+    }
+}
+
+/* One vector step as the engine performs it with GYMNET_FLAG_AUTORESET (the caller's `if (done) Reset()`, README.md:36-40,
+ * fused): step every lane; reward / done are the step's; a finished lane's state and observation are replaced by the
+ * reset draw keyed (seed, lane0 + i, tick).  lane_seed (optional) gives per-lane keys (VecEnv.Seed(int[]), VecEnv.cs:48-52). */
+void ref_env_autoreset_step_batch_f32(int env_id, uint64_t seed, const uint64_t *lane_seed, uint64_t lane0, uint64_t tick,
+                                      float *state_soa, const void *action, float *obs_soa, float *reward, uint8_t *done, int64_t n) {
+    const int S = ENV_S[env_id], O = ENV_O[env_id];
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4], o[6], r;
+        for (int k = 0; k < S; ++k) s[k] = state_soa[(int64_t)k * n + i];
+        const int d = step_one_f32(env_id, s, action, i, 0, o, &r);
+        if (d) { reset_f32(env_id, lane_seed ? lane_seed[i] : seed, lane0 + (uint64_t)i, tick, s); observe_f32(env_id, s, o); }
+        done[i] = (uint8_t)d; reward[i] = r;
+        for (int k = 0; k < S; ++k) state_soa[(int64_t)k * n + i] = s[k];
+        for (int k = 0; k < O; ++k) obs_soa[(int64_t)k * n + i] = o[k];
+    }
+}

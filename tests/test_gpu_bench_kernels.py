@@ -1,0 +1,136 @@
+"""Parity of the EXACT kernel instantiations bench.py times, at BASELINE's full batch (2^20 lanes), driven the way
+the bench drives them: GYMNET_FLAG_AUTORESET, a device-sampled action ring, `RolloutDevice(acts, K, n, ring)`
+(one eager kernel launch per step at this size).  Each test
+
+  1. asserts the launch policy, so it cannot silently run another instantiation;
+  2. replays the whole K-step call on the CPU with the oracle's float32 kernel-semantics step + its Philox reset
+     draw (oracle.env_autoreset_step) — state, observation, reward and done flags must agree BIT FOR BIT;
+  3. teacher-forces one more launch of the same kernel against the float64 restatement (the reference's own
+     arithmetic, CartPoleEnv.cs:137-186 for CartPole): |state error| <= 1e-5 on the lanes that did not finish
+     (finished lanes hold their reset draw), integer outputs exact away from the rounding margin of a threshold.
+
+The round-2 full-size bit-exact tests ran the auto_reset=False instantiations; this file closes that gap.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+N = 1 << 20
+RING = 4
+
+
+def _ring(env, oracle, name, n):
+    """The bench's action ring: ActionSpace.Sample() per lane per slice on the device (key seed + 1), checked
+    against the oracle's sampler.  Returns (device tensor [RING, n], host copy)."""
+    import torch
+    box = name == "Pendulum-v1"
+    acts = torch.empty((RING, n), dtype=torch.float32 if box else torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for t in range(RING):
+        env.SampleActionsDevice(acts[t], seed=SEED + 1, tick=t)
+    env.Sync()
+    host = acts.cpu().numpy()
+    for t in range(RING):
+        want = (oracle.box_uniform_sample(SEED + 1, 0, t, -2.0, 2.0, n) if box
+                else oracle.discrete_sample(SEED + 1, 0, t, env.ActionSpace.N, 0, n))
+        assert np.array_equal(host[t], want)
+    return acts, host
+
+
+def _pin(gpu_pkg, oracle, name, policy, steps, init=None, min_done_frac=0.0):
+    with gpu_pkg.VectorEnv(name, N, seed=SEED, auto_reset=True) as env:
+        assert env.LaunchPolicy() == policy, env.LaunchPolicy()
+        acts, a_host = _ring(env, oracle, name, N)
+        env.ResetDevice()
+        env.Sync()
+        s = env.GetState()
+        assert np.array_equal(s, oracle.env_reset(name, SEED, 0, 0, N))
+        if init is not None:
+            env.SetState(init)
+            s = init.copy()
+        tick = env.Tick
+        assert tick == 1
+
+        # (1) + (2): ONE bench-shaped call, replayed from the first bit
+        env.RolloutDevice(acts, steps, N, RING)
+        env.Sync()
+        dones = 0
+        for t in range(steps):
+            s, o, r, d = oracle.env_autoreset_step(name, SEED, 0, tick + t, s, a_host[t % RING])
+            dones += int(d.sum())
+        got, last = env.GetState(), env.Read()
+        assert np.array_equal(got, s)
+        assert np.array_equal(last.Observation, o.T)
+        assert np.array_equal(last.Reward, r) and np.array_equal(last.Done, d.astype(bool))
+        assert dones >= min_done_frac * N * steps, dones
+        c = env.Counters()
+        assert c["lane_steps"] == steps * N and c["tick"] == tick + steps
+
+        # (3): one more launch of the same kernel, teacher-forced against the float64 restatement
+        env.RolloutDevice(acts, 1, N, RING)
+        env.Sync()
+        s64, o64, r64, d64 = oracle.env_step(name, got.astype(np.float64), a_host[0], dtype=np.float64)
+        s32, o32, r32, d32 = oracle.env_autoreset_step(name, SEED, 0, tick + steps, got, a_host[0])
+        got1, out = env.GetState(), env.Read()
+        assert np.array_equal(got1, s32) and np.array_equal(out.Done, d32.astype(bool)) and np.array_equal(out.Reward, r32)
+        return got, got1.astype(np.float64), out, s64, o64, r64, d64.astype(bool)
+
+
+def test_step_kernel_CartPole_vec4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
+    """BENCH's kernel: step_kernel<CartPole, 4, AUTORESET=true, EXTRAS=false, NT=15>.  48 free-running steps from the
+    reset (≈4.5 % of lanes finish per step once episodes are ~10 steps old), then the float64 bar of north_star."""
+    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "CartPole-v1", pol, 48, min_done_frac=0.02)
+    keep = ~out.Done
+    assert np.abs(got1[:, keep] - s64[:, keep]).max() <= 1e-5                      # north_star: 1e-5 abs on float32 state
+    xt, tt = float(np.float32(2.4)), float(np.float32(0.20943951606750488))
+    near = (np.abs(np.abs(s64[0]) - xt) < 1e-6) | (np.abs(np.abs(s64[2]) - tt) < 1e-6)
+    assert np.array_equal(out.Done[~near], d64[~near]) and near.sum() <= 64        # integer done: exact off the rounding margin
+    assert np.all(out.Reward == 1.0) and np.all(r64 == 1.0)                        # CartPoleEnv.cs:168-175 (sbd == -1 at entry)
+    assert out.Done.sum() > 0.02 * N
+
+
+def test_step_kernel_Pendulum_vec4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
+    """BASELINE config 3's kernel: step_kernel<Pendulum, 4, true, false, 15> (never terminates: the reset path is compiled
+    in and never taken)."""
+    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Pendulum-v1", pol, 12)
+    assert not out.Done.any() and not d64.any()
+    assert np.abs(got1 - s64).max() <= 1e-5
+    assert np.abs(out.Observation.astype(np.float64) - o64.T).max() <= 1e-5
+    assert np.abs(out.Reward.astype(np.float64) - r64).max() <= 1e-4 * 16.3          # |reward| <= 16.27
+
+
+def test_step_kernel_MountainCar_vec4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
+    """step_kernel<MountainCar, 4, true, false, 15>; start states spread over the whole track so ≈3 % of lanes reach the
+    goal per step and take the fused reset."""
+    rng = np.random.default_rng(52)
+    init = np.stack([rng.uniform(-1.2, 0.6, N), rng.uniform(-0.07, 0.07, N)]).astype(np.float32)
+    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "MountainCar-v0", pol, 12, init=init, min_done_frac=0.002)
+    keep = ~out.Done
+    assert np.abs(got1[:, keep] - s64[:, keep]).max() <= 1e-6
+    near = np.abs(s64[0] - 0.5) < 1e-6
+    assert np.array_equal(out.Done[~near], d64[~near]) and near.sum() <= 8
+    assert np.all(out.Reward == -1.0)
+
+
+def test_step_kernel_pipe_Acrobot_items4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
+    """BASELINE config 4's kernel: step_kernel_pipe<Acrobot, ITEMS=4, AUTORESET=true, NT=15> (four sequential lanes per
+    thread, scalar lanes).  Energetic start states: about a quarter of the lanes swing above the bar per step, so the
+    divergent fused reset runs in nearly every wave."""
+    rng = np.random.default_rng(53)
+    init = np.stack([rng.uniform(-3.1, 3.1, N), rng.uniform(-3.1, 3.1, N), rng.uniform(-4, 4, N), rng.uniform(-9, 9, N)]).astype(np.float32)
+    pol = {"envs_per_thread": 1, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 4}
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Acrobot-v1", pol, 10, init=init, min_done_frac=0.01)
+    keep = ~out.Done
+    dang = np.abs(np.angle(np.exp(1j * (got1[:2] - s64[:2]))))[:, keep]            # angles wrap at +-pi: compare on the circle
+    dvel = np.abs(got1[2:] - s64[2:])[:, keep]
+    assert dang.max() <= 1e-4 and dvel.max() <= 1e-3                                # float32 rounding through RK4, dt = 0.2
+    calm = ((np.abs(got0[2]) < 2) & (np.abs(got0[3]) < 2))[keep]
+    assert calm.sum() > 1000 and dang[:, calm].max() <= 1e-5 and dvel[:, calm].max() <= 2e-5
+    margin = np.abs((-np.cos(s64[0]) - np.cos(s64[1] + s64[0])) - 1.0) < 1e-4
+    assert np.array_equal(out.Done[~margin], d64[~margin])
+    assert np.array_equal(out.Reward, np.where(out.Done, 0.0, -1.0).astype(np.float32))
