@@ -389,10 +389,7 @@ def main():
             what = "value = step-only rate (no collective on the data path); with_obs_allgather = the same stepping plus the per-step RCCL gather"
         else:
             what = "value = step-only rate"
-        kernel = {"CartPole-v1": "step_kernel<CartPole,4,autoreset>", "Pendulum-v1": "step_kernel<Pendulum,4,autoreset>",
-                  "MountainCar-v0": "step_kernel<MountainCar,4,autoreset>",
-                  "Acrobot-v1": "step_kernel_pipe<Acrobot,4,autoreset>" if launch_policy.get("sequential_lanes_per_thread", 1) > 1
-                  else "step_kernel<Acrobot,1,autoreset>"}.get(args.env, "step_kernel")
+        kernel = local.KernelName()          # the instantiation the launcher resolves to, printed by the library itself
         return {
             "metric": "env-steps/sec", "value": n * world * K / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,

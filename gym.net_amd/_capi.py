@@ -38,7 +38,7 @@ FLAG_FINAL_OBS = 0x10
 FLAG_DOUBLE_BUFFER = 0x20
 
 GATHER_NONE, GATHER_DIRECT, GATHER_RCCL = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Config(C.Structure):
@@ -56,7 +56,8 @@ class EnvInfo(C.Structure):
                 ("action_low", C.c_float), ("action_high", C.c_float),
                 ("obs_low", C.c_float * 8), ("obs_high", C.c_float * 8),
                 ("reward_low", C.c_float), ("reward_high", C.c_float),
-                ("algorithmic_bytes_per_step", C.c_int32)]
+                ("algorithmic_bytes_per_step", C.c_int32), ("traffic_bytes_per_step", C.c_int32),
+                ("state_row_in_obs", C.c_int32 * 8)]
 
 
 class DeviceView(C.Structure):
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),
     "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
+    "gymnet_vecenv_kernel_name": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_set_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_get_steps_beyond_done": (C.c_int, [_H, _P]),

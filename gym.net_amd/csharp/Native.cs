@@ -38,6 +38,7 @@ namespace Gym.Envs.Amd {
         public float action_low; public float action_high;
         public fixed float obs_low[8]; public fixed float obs_high[8];
         public float reward_low; public float reward_high; public int algorithmic_bytes_per_step;
+        public int traffic_bytes_per_step; public fixed int state_row_in_obs[8];
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -104,6 +105,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_sync(IntPtr h);
         [DllImport(Lib)] public static extern int gymnet_vecenv_device_view(IntPtr h, out GymnetDeviceView view);
         [DllImport(Lib)] public static extern int gymnet_vecenv_launch_policy(IntPtr h, out int vec, out int block, out int nt, out int sequential_lanes);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_kernel_name(IntPtr h, byte[] buf, int capacity);
 
         // ---- state access / bookkeeping
         [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, float* state_soa);

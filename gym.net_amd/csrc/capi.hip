@@ -28,13 +28,13 @@ namespace gymnet {
 // Algorithmic bytes per env-step: SURVEY.md §8(a)/(d).
 const EnvDesc kEnvs[4] = {
     {"CartPole-v1", 4, 4, true, false, true, 2, 0.f, 0.f,
-     {-4.8000002f, -FMAX, -0.41887903f, -FMAX}, {4.8000002f, FMAX, 0.41887903f, FMAX}, 0.f, 1.f, 41},
+     {-4.8000002f, -FMAX, -0.41887903f, -FMAX}, {4.8000002f, FMAX, 0.41887903f, FMAX}, 0.f, 1.f, 41, 41, {-1, -1, -1, -1}},
     {"Pendulum-v1", 2, 3, false, true, false, 0, -2.f, 2.f,
-     {-1.f, -1.f, -8.f}, {1.f, 1.f, 8.f}, -16.2736044f, 0.f, 37},
+     {-1.f, -1.f, -8.f}, {1.f, 1.f, 8.f}, -16.2736044f, 0.f, 37, 33, {-1, 2, -1, -1}},
     {"MountainCar-v0", 2, 2, true, false, false, 3, 0.f, 0.f,
-     {-1.2f, -0.07f}, {0.6f, 0.07f}, -1.f, -1.f, 25},
+     {-1.2f, -0.07f}, {0.6f, 0.07f}, -1.f, -1.f, 25, 25, {-1, -1, -1, -1}},
     {"Acrobot-v1", 4, 6, false, false, false, 3, 0.f, 0.f,
-     {-1.f, -1.f, -1.f, -1.f, -4.f * PI_F, -9.f * PI_F}, {1.f, 1.f, 1.f, 1.f, 4.f * PI_F, 9.f * PI_F}, -1.f, 0.f, 65},
+     {-1.f, -1.f, -1.f, -1.f, -4.f * PI_F, -9.f * PI_F}, {1.f, 1.f, 1.f, 1.f, 4.f * PI_F, 9.f * PI_F}, -1.f, 0.f, 65, 57, {-1, -1, 4, 5}},
 };
 
 void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
@@ -90,6 +90,7 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.state = h->d_state;
     a.state_out = (h->double_buffer && alias) ? h->d_state_alt : h->d_state;
     a.obs = (h->double_buffer && !alias) ? h->d_obs_alt : h->d_obs;
+    a.obs_in = h->d_obs;
     a.action = d_actions;
     a.reward = h->d_reward;
     a.done = h->d_done;
@@ -124,6 +125,12 @@ int compact_done(gymnet_vecenv *h, int32_t *d_out, uint32_t *d_count) {
     const uint32_t *counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
     HIP_TRY(h, launch_compact_done(counts, h->d_done_list, h->done_cap, d_out, d_count, h->stream));
     return GYMNET_OK;
+}
+
+// device address of state row k of the CURRENT state (its own row of d_state, or the observation row that holds it)
+float *state_row(gymnet_vecenv *h, int k) {
+    const int m = h->desc->alias ? -1 : h->desc->state_row_in_obs[k];
+    return m < 0 ? h->d_state + (size_t)k * h->sstride : h->d_obs + (size_t)m * h->ostride;
 }
 
 void recompute_extras(gymnet_vecenv *h) {
@@ -364,6 +371,8 @@ int gymnet_env_describe(int env_id, gymnet_env_info *out) {
     for (int k = 0; k < 8; ++k) { out->obs_low[k] = d.obs_low[k]; out->obs_high[k] = d.obs_high[k]; }
     out->reward_low = d.reward_low; out->reward_high = d.reward_high;
     out->algorithmic_bytes_per_step = d.algorithmic_bytes;
+    out->traffic_bytes_per_step = d.traffic_bytes;
+    for (int k = 0; k < 8; ++k) out->state_row_in_obs[k] = (k < d.state_dim && !d.alias) ? d.state_row_in_obs[k] : -1;
     return GYMNET_OK;
     });
 }
@@ -545,6 +554,10 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
     if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
     if (const char *e = std::getenv("GYMNET_ITEMS")) { int v = std::atoi(e); if (v >= 1 && v <= 5) h->lcfg.items = v; }
+    // Wave-compacted fused reset (kernels.hip: reset_pending_wave) wherever the dwordx4 lean kernel of an env whose observation IS
+    // its state runs: the wave's finished sub-lanes are drawn in ONE Philox pass by its first lanes instead of 1.6 mostly idle
+    // passes.  CartPole at 2^20 lanes: 6.91 -> 6.52 us per launch, bit-identical (profiles/forms_probe_r03.txt).
+    h->lcfg.reset_form = (d.alias && h->lcfg.vec == 4) ? 1 : 0;
     if (const char *e = std::getenv("GYMNET_RESET_FORM")) { int v = std::atoi(e); if (v == 0 || v == 1) h->lcfg.reset_form = v; }
     if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
@@ -779,12 +792,21 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
     });
 }
 
+int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity) {
+    return guarded([&]() -> int {
+    if (!h || !buf || capacity < 1) return fail(h, GYMNET_ERR_INVALID_ARG, "null handle / buffer");
+    if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, buf, (size_t)capacity) < 0)
+        return fail(h, GYMNET_ERR_INVALID_ARG, "unknown env");
+    return GYMNET_OK;
+    });
+}
+
 int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
-    HIP_TRY(h, hipMemcpy2DAsync(state_soa, (size_t)h->n * 4, h->d_state, (size_t)h->sstride * 4, (size_t)h->n * 4,
-                                (size_t)h->desc->state_dim, hipMemcpyDeviceToHost, h->stream));
+    for (int k = 0; k < h->desc->state_dim; ++k)      // row by row: a row the observation repeats lives in the observation array
+        HIP_TRY(h, hipMemcpyAsync(state_soa + (size_t)k * h->n, state_row(h, k), (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
     });
@@ -794,8 +816,8 @@ int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
-    HIP_TRY(h, hipMemcpy2DAsync(h->d_state, (size_t)h->sstride * 4, state_soa, (size_t)h->n * 4, (size_t)h->n * 4,
-                                (size_t)h->desc->state_dim, hipMemcpyHostToDevice, h->stream));
+    for (int k = 0; k < h->desc->state_dim; ++k)
+        HIP_TRY(h, hipMemcpyAsync(state_row(h, k), state_soa + (size_t)k * h->n, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
     if (!h->desc->alias)
         HIP_TRY(h, launch_observe(h->cfg.env_id, h->d_state, h->sstride, h->d_obs, h->ostride, h->n, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

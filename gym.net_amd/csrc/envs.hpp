@@ -190,6 +190,7 @@ struct Pendulum {
     static constexpr int S = 2;              // theta, theta_dot
     static constexpr int O = 3;              // cos, sin, theta_dot
     static constexpr bool OBS_ALIASES_STATE = false;
+    static constexpr int OBS_ROW_OF_STATE[S] = {-1, 2};   // theta_dot IS obs[2]: stored once, in the observation array
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = true;
     static constexpr bool PACKED2 = false;
@@ -281,6 +282,7 @@ struct Acrobot {
     static constexpr int S = 4;              // theta1, theta2, dtheta1, dtheta2
     static constexpr int O = 6;              // cos1, sin1, cos2, sin2, dtheta1, dtheta2
     static constexpr bool OBS_ALIASES_STATE = false;
+    static constexpr int OBS_ROW_OF_STATE[S] = {-1, -1, 4, 5};   // dtheta1, dtheta2 ARE obs[4], obs[5]: stored once, in the observation array
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = true;    // step_observe_x2: two envs per thread on v_pk_*_f32

@@ -23,6 +23,8 @@ struct EnvDesc {
     float obs_low[8], obs_high[8];
     float reward_low, reward_high;
     int algorithmic_bytes;
+    int traffic_bytes;          // bytes one env-step really moves (< algorithmic where a state row is stored once, in the observation)
+    int state_row_in_obs[4];    // state row k lives in observation row state_row_in_obs[k] (-1: its own row of the state array)
 };
 extern const EnvDesc kEnvs[4];
 

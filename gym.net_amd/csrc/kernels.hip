@@ -15,6 +15,8 @@
 // Compiled with -ffp-contract=off (see envs.hpp).
 #include "kernels.hpp"
 
+#include <cstdio>
+
 #include "envs.hpp"
 
 namespace gymnet {
@@ -157,6 +159,21 @@ __device__ __forceinline__ void store_u8(uint8_t *__restrict__ p, int64_t i0, in
 
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Where state row k lives.  A state component that the observation repeats verbatim (Pendulum: theta_dot = obs[2]; Acrobot:
+// dtheta1, dtheta2 = obs[4], obs[5]; Env::OBS_ROW_OF_STATE) is stored ONCE, in the observation array: the step reads it from
+// there and never writes its row of the state array — 8 of Acrobot's 45 written bytes per env-step, 4 of Pendulum's 21.  At
+// 2^20 lanes both kernels are short of WRITE bandwidth, and the 18 % fewer written bytes are worth 10 % of the launch
+// (Acrobot 13.9 -> 12.6 us, Pendulum 6.68 -> 6.03 us, profiles/dedup_probe_r03.txt).
+template <class Env>
+__device__ __forceinline__ constexpr bool state_row_own(int k) {
+    if constexpr (Env::OBS_ALIASES_STATE) return true; else return Env::OBS_ROW_OF_STATE[k] < 0;
+}
+template <class Env>
+__device__ __forceinline__ const float *state_row_src(const float *state, int64_t state_stride, const float *obs_in, int64_t obs_stride, int k) {
+    if constexpr (Env::OBS_ALIASES_STATE) return state + k * state_stride;
+    else return Env::OBS_ROW_OF_STATE[k] < 0 ? state + k * state_stride : obs_in + Env::OBS_ROW_OF_STATE[k] * obs_stride;
 }
 
 // shard of the calling wave for the sharded counters / done list (StepArgs)
@@ -355,7 +372,8 @@ __device__ __forceinline__ void load_inputs(const StepArgs &a, const int64_t i0,
     constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
     const int64_t n = a.n;
 #pragma unroll
-    for (int k = 0; k < Env::S; ++k) load_f32<VEC, NT_SL, GUARD>(a.state + k * a.state_stride, i0, n, in.s[k]);
+    for (int k = 0; k < Env::S; ++k)
+        load_f32<VEC, NT_SL, GUARD>(state_row_src<Env>(a.state, a.state_stride, a.obs_in, a.obs_stride, k), i0, n, in.s[k]);
     if constexpr (Env::BOX_ACTION) load_f32<VEC, NT_A, GUARD>(static_cast<const float *>(a.action), i0, n, in.act);
     else load_i32<VEC, NT_A, GUARD>(static_cast<const int32_t *>(a.action), i0, n, in.act);
 #pragma unroll
@@ -435,7 +453,8 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
     else if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick);
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, NT_SS, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k)
+        if (state_row_own<Env>(k)) store_f32<VEC, NT_SS, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
         for (int k = 0; k < O; ++k) store_f32<VEC, NT_SS, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
@@ -516,7 +535,8 @@ __device__ __forceinline__ void store_lane(const StepArgs &a, int64_t i, const L
     st(a.reward + i, out.reward, NT_O);
     if constexpr (NT_O) __builtin_nontemporal_store(out.done, a.done + i); else a.done[i] = out.done;
 #pragma unroll
-    for (int k = 0; k < Env::S; ++k) st(a.state_out + k * a.state_stride + i, out.s[k], NT_SS);
+    for (int k = 0; k < Env::S; ++k)
+        if (state_row_own<Env>(k)) st(a.state_out + k * a.state_stride + i, out.s[k], NT_SS);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
         for (int k = 0; k < Env::O; ++k) st(a.obs + k * a.obs_stride + i, out.o[k], NT_SS);
@@ -605,7 +625,7 @@ __device__ __forceinline__ void rollout_body(const StepArgs &a, const RolloutArg
 
     float s[S][VEC];
 #pragma unroll
-    for (int k = 0; k < S; ++k) load_f32<VEC, true, GUARD>(a.state + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k) load_f32<VEC, true, GUARD>(state_row_src<Env>(a.state, a.state_stride, a.obs_in, a.obs_stride, k), i0, n, s[k]);
     int32_t sbd[VEC] = {};
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, true, GUARD>(a.sbd, i0, n, sbd);
 
@@ -678,7 +698,8 @@ __device__ __forceinline__ void rollout_body(const StepArgs &a, const RolloutArg
     }
 
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_f32<VEC, false, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
+    for (int k = 0; k < S; ++k)
+        if (state_row_own<Env>(k)) store_f32<VEC, false, GUARD>(a.state_out + k * a.state_stride, i0, n, s[k]);
     if constexpr (!Env::OBS_ALIASES_STATE) {
 #pragma unroll
         for (int k = 0; k < O; ++k) store_f32<VEC, false, GUARD>(a.obs + k * a.obs_stride, i0, n, o[k]);
@@ -712,7 +733,8 @@ __device__ __forceinline__ void reset_lane(const ResetArgs &a, int64_t i, uint64
     float s[S];
     Env::reset(s, r);
 #pragma unroll
-    for (int k = 0; k < S; ++k) a.state[k * a.state_stride + i] = s[k];
+    for (int k = 0; k < S; ++k)
+        if (state_row_own<Env>(k)) a.state[k * a.state_stride + i] = s[k];
     if constexpr (!Env::OBS_ALIASES_STATE) {
         float o[O];
         Env::observe_fresh(s, o);
@@ -745,13 +767,12 @@ __global__ __launch_bounds__(256) void reset_kernel(const ResetArgs a) {
 }
 
 template <class Env>
-__global__ __launch_bounds__(256) void observe_kernel(const float *__restrict__ state, int64_t sstride,
-                                                      float *__restrict__ obs, int64_t ostride, int64_t n) {
+__global__ __launch_bounds__(256) void observe_kernel(const float *state, int64_t sstride, float *obs, int64_t ostride, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s[Env::S], o[Env::O];
 #pragma unroll
-    for (int k = 0; k < Env::S; ++k) s[k] = state[k * sstride + i];
+    for (int k = 0; k < Env::S; ++k) s[k] = state_row_src<Env>(state, sstride, obs, ostride, k)[i];
     Env::observe(s, o);
 #pragma unroll
     for (int k = 0; k < Env::O; ++k) obs[k * ostride + i] = o[k];
@@ -921,20 +942,49 @@ __global__ __launch_bounds__(256) void push_obs_kernel(const PushArgs a) {
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
 
+// Which instantiation a step launch resolves to: ONE function decides, the launcher dispatches on it and
+// describe_step_kernel() prints it (gymnet_vecenv_kernel_name: tests and bench.py name the kernel they ran from the library,
+// not from a copy of this policy).
+struct StepVariant {
+    int pipe_items;     // > 1: step_kernel_pipe<Env, pipe_items, AUTORESET, 15>; else step_kernel
+    int vec, nt;        // step_kernel<Env, vec, AUTORESET, EXTRAS, nt, resetf>
+    int resetf;
+};
+
+static LaunchCfg normalized(LaunchCfg cfg) {
+    if (cfg.vec != 4 && cfg.vec != 2) cfg.vec = 1;
+    if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
+    if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
+    return cfg;
+}
+
+template <class Env>
+static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg) {
+    StepVariant v{1, 1, cfg.nt, 0};
+    if constexpr (Env::PIPELINED) {        // multi-lane kernel, cfg.items lanes per thread (2..5)
+        if (cfg.items > 1 && cfg.items <= 5 && !extras && cfg.vec == 1) { v.pipe_items = cfg.items; v.nt = 15; return v; }
+    }
+    // the wide form of an env: four lanes per thread on dwordx4 streams, or — for the env with a two-lane packed-FP32 form
+    // (Acrobot) — two lanes per thread on dwordx2 streams
+    if (cfg.vec > 1) v.vec = Env::PACKED2 ? 2 : 4;
+    // wave-compacted fused reset: lean dwordx4 variant of an env whose observation IS its state
+    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec == 4 && autoreset && !extras) v.resetf = 1;
+    return v;
+}
+
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
-    const int block = cfg.block;
-    if constexpr (Env::PIPELINED) {        // multi-lane kernel, cfg.items lanes per thread (2..5)
-        if (cfg.items > 1 && !extras && cfg.vec == 1) {
-            const int items = cfg.items;
-            const int64_t per_block = 256 * (int64_t)items;
+    const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg);
+    if constexpr (Env::PIPELINED) {
+        if (v.pipe_items > 1) {
+            const int64_t per_block = 256 * (int64_t)v.pipe_items;
             const dim3 pgrid(grid_for(a.n > 0 ? (a.n + per_block - 1) / per_block : 1, 1)), pblk(256);
 #define GYMNET_PIPE(I)                                                                                                  \
     case I:                                                                                                             \
         if (autoreset) hipLaunchKernelGGL((step_kernel_pipe<Env, I, true, 15>), pgrid, pblk, 0, st, a);                  \
         else hipLaunchKernelGGL((step_kernel_pipe<Env, I, false, 15>), pgrid, pblk, 0, st, a);                           \
         break;
-            switch (items) {
+            switch (v.pipe_items) {
                 GYMNET_PIPE(2) GYMNET_PIPE(3) GYMNET_PIPE(4) GYMNET_PIPE(5)
                 default: return hipErrorInvalidValue;
             }
@@ -942,23 +992,21 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
             return hipGetLastError();
         }
     }
-    // the wide form of an env: four lanes per thread on dwordx4 streams, or — for the env with a two-lane packed-FP32 form
-    // (Acrobot) — two lanes per thread on dwordx2 streams
     constexpr int WIDE = Env::PACKED2 ? 2 : 4;
-    const bool wide = cfg.vec > 1;
-    const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
-    const dim3 grid(grid_for(threads > 0 ? threads : 1, block)), blk(block);
+    const bool wide = v.vec > 1;
+    const int64_t threads = (a.n + v.vec - 1) / v.vec;
+    const dim3 grid(grid_for(threads > 0 ? threads : 1, cfg.block)), blk(cfg.block);
 #define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, (size_t)cfg.lds_bytes, st, a)
 #define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
     do {                                                              \
-        if (cfg.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);               \
-        else if (cfg.nt == 12) GYMNET_LAUNCH(V, AR, EX, 12);          \
+        if (v.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);                 \
+        else if (v.nt == 12) GYMNET_LAUNCH(V, AR, EX, 12);            \
         else GYMNET_LAUNCH(V, AR, EX, 0);                             \
     } while (0)
-    if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2) {   // wave-compacted fused reset (lean dwordx4 variant only)
-        if (cfg.reset_form == 1 && wide && autoreset && !extras) {
-            if (cfg.nt == 15) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 15, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
-            else if (cfg.nt == 12) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 12, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
+    if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2) {
+        if (v.resetf == 1) {
+            if (v.nt == 15) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 15, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
+            else if (v.nt == 12) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 12, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
             else hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 0, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
             return hipGetLastError();
         }
@@ -977,9 +1025,7 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
 }
 
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
-    if (cfg.vec != 4 && cfg.vec != 2) cfg.vec = 1;
-    if (cfg.block != 64 && cfg.block != 128) cfg.block = 256;
-    if (cfg.nt != 12 && cfg.nt != 15) cfg.nt = 0;
+    cfg = normalized(cfg);
     switch (env_id) {
         case 0: return launch_step_env<CartPole>(autoreset, extras, a, cfg, st);
         case 1: return launch_step_env<Pendulum>(autoreset, extras, a, cfg, st);
@@ -987,6 +1033,22 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
         case 3: return launch_step_env<Acrobot>(autoreset, extras, a, cfg, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, char *buf, size_t cap) {
+    cfg = normalized(cfg);
+    StepVariant v;
+    const char *env;
+    switch (env_id) {
+        case 0: v = resolve_variant<CartPole>(autoreset, extras, cfg); env = "CartPole"; break;
+        case 1: v = resolve_variant<Pendulum>(autoreset, extras, cfg); env = "Pendulum"; break;
+        case 2: v = resolve_variant<MountainCar>(autoreset, extras, cfg); env = "MountainCar"; break;
+        case 3: v = resolve_variant<Acrobot>(autoreset, extras, cfg); env = "Acrobot"; break;
+        default: return -1;
+    }
+    const char *ar = autoreset ? "true" : "false";
+    if (v.pipe_items > 1) return std::snprintf(buf, cap, "step_kernel_pipe<%s,%d,%s,15>", env, v.pipe_items, ar);
+    return std::snprintf(buf, cap, "step_kernel<%s,%d,%s,%s,%d,%d>", env, v.vec, ar, extras ? "true" : "false", v.nt, v.resetf);
 }
 
 template <class Env>

@@ -11,6 +11,8 @@ struct StepArgs {
     float *state_out;        // where the new state is written: == state, or the OTHER half of a double-buffered pair
                              // (GYMNET_FLAG_DOUBLE_BUFFER: step t+1 writes B while a gather of A is still in flight)
     float *obs;              // [O][obs_stride]    (unused when the env's observation aliases its state)
+    const float *obs_in;     // the CURRENT observation buffer (== obs unless double-buffered): state rows the observation repeats
+                             // (Env::OBS_ROW_OF_STATE) are read from here — they have no row of their own in `state`
     const void *action;      // int32[n] (Discrete) or float32[n] (Box)
     float *reward;           // [n]
     uint8_t *done;           // [n]
@@ -48,6 +50,10 @@ struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1;
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);
+
+// The template instantiation launch_step would run for this configuration, as text ("step_kernel<CartPole,4,true,false,15,1>");
+// returns the length, or < 0 for an unknown env.
+int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, char *buf, size_t cap);
 
 // Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
 struct RolloutArgs {

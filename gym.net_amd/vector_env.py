@@ -276,6 +276,13 @@ class VectorEnv:
         capi.check(self._lib.gymnet_vecenv_launch_policy(self._h, C.byref(v), C.byref(b), C.byref(nt), C.byref(sq)))
         return {"envs_per_thread": v.value, "block": b.value, "nontemporal_mask": nt.value, "sequential_lanes_per_thread": sq.value}
 
+    def KernelName(self):
+        """The template instantiation the next step launch runs, as the launcher itself resolves it
+        (e.g. "step_kernel<CartPole,4,true,false,15,1>")."""
+        buf = C.create_string_buffer(128)
+        capi.check(self._lib.gymnet_vecenv_kernel_name(self._h, buf, 128))
+        return buf.value.decode()
+
     # ---- state access / bookkeeping -----------------------------------------------------------------
     def GetState(self):
         s = np.empty((self.StateDim, self.NumberOfEnvironments), np.float32)

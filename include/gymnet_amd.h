@@ -45,7 +45,9 @@
 extern "C" {
 #endif
 
-#define GYMNET_ABI_VERSION 2   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups */
+#define GYMNET_ABI_VERSION 3   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
+                                  3: gymnet_env_info.{traffic_bytes_per_step,state_row_in_obs}, per-element Box sampling, compact
+                                     terminal observations, pinned host staging */
 
 typedef enum gymnet_status {
     GYMNET_OK = 0,
@@ -116,6 +118,13 @@ typedef struct gymnet_env_info {
     float    obs_low[8], obs_high[8];/* ObservationSpace bounds (CartPoleEnv.cs:46-48) */
     float    reward_low, reward_high;
     int32_t  algorithmic_bytes_per_step; /* bytes one env-step must move (CartPole: 41) */
+    int32_t  traffic_bytes_per_step;     /* ABI 3: bytes one env-step really moves: less than the algorithmic figure where a state
+                                            component the observation repeats verbatim is stored once (Pendulum 33 of 37,
+                                            Acrobot 57 of 65) */
+    int32_t  state_row_in_obs[8];        /* ABI 3: state component k is held in row state_row_in_obs[k] of the OBSERVATION array
+                                            (Pendulum theta_dot = obs[2]; Acrobot dtheta1, dtheta2 = obs[4], obs[5]); -1 = in its
+                                            own row of the state array.  Only matters to readers of gymnet_device_view.d_state;
+                                            gymnet_vecenv_get_state / _set_state assemble the full [state_dim][num_envs] array */
 } gymnet_env_info;
 
 /* Device-side view of a handle: zero-copy access for a GPU-resident policy / trainer. */
@@ -123,7 +132,8 @@ typedef struct gymnet_device_view {
     uint32_t struct_size;
     int32_t  state_dim, obs_dim, obs_aliases_state;
     int64_t  num_envs, state_stride, obs_stride;
-    float   *d_state;          /* [state_dim][state_stride] */
+    float   *d_state;          /* [state_dim][state_stride]; rows listed in gymnet_env_info.state_row_in_obs are NOT kept here
+                                  (they are rows of d_obs) */
     float   *d_obs;            /* [obs_dim][obs_stride] (== d_state when obs_aliases_state) */
     float   *d_reward;         /* [num_envs] */
     uint8_t *d_done;           /* [num_envs] */
@@ -225,6 +235,11 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
  * kernel that loads all of a thread's lanes first and then computes / stores them one after another (Acrobot; 1 = the
  * one-shot kernel).  Any out pointer may be NULL. */
 int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *sequential_lanes);
+/* ABI 3.  The kernel instantiation the handle's NEXT step launch runs, as text — e.g. "step_kernel<CartPole,4,true,false,15,1>"
+ * (env, lanes per thread, AUTORESET, EXTRAS, non-temporal mask, reset form) or "step_kernel_pipe<Acrobot,4,true,15>".  It is
+ * printed by the same function the launcher dispatches on, so a profile, a bench line or a parity test can name what ran
+ * without copying the launch policy.  Diagnostic only: the spelling is not a stable interface. */
+int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity);
 
 /* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
 /* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */

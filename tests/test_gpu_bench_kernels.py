@@ -2,7 +2,8 @@
 the bench drives them: GYMNET_FLAG_AUTORESET, a device-sampled action ring, `RolloutDevice(acts, K, n, ring)`
 (one eager kernel launch per step at this size).  Each test
 
-  1. asserts the launch policy, so it cannot silently run another instantiation;
+  1. asserts the kernel instantiation the launcher resolves to (gymnet_vecenv_kernel_name), so it cannot silently run
+     another one;
   2. replays the whole K-step call on the CPU with the oracle's float32 kernel-semantics step + its Philox reset
      draw (oracle.env_autoreset_step) — state, observation, reward and done flags must agree BIT FOR BIT;
   3. teacher-forces one more launch of the same kernel against the float64 restatement (the reference's own
@@ -39,9 +40,10 @@ def _ring(env, oracle, name, n):
     return acts, host
 
 
-def _pin(gpu_pkg, oracle, name, policy, steps, init=None, min_done_frac=0.0):
+def _pin(gpu_pkg, oracle, name, kernel, steps, init=None, min_done_frac=0.0):
     with gpu_pkg.VectorEnv(name, N, seed=SEED, auto_reset=True) as env:
-        assert env.LaunchPolicy() == policy, env.LaunchPolicy()
+        # the launcher's own resolution of (env, batch size, flags) -> template instantiation
+        assert env.KernelName() == kernel, env.KernelName()
         acts, a_host = _ring(env, oracle, name, N)
         env.ResetDevice()
         env.Sync()
@@ -79,10 +81,11 @@ def _pin(gpu_pkg, oracle, name, policy, steps, init=None, min_done_frac=0.0):
 
 
 def test_step_kernel_CartPole_vec4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
-    """BENCH's kernel: step_kernel<CartPole, 4, AUTORESET=true, EXTRAS=false, NT=15>.  48 free-running steps from the
+    """BENCH's kernel: step_kernel<CartPole, 4, AUTORESET=true, EXTRAS=false, NT=15, RESETF=1> (dwordx4 lanes, every stream
+    non-temporal, fused auto-reset drawn by the wave-compacted reset_pending_wave).  48 free-running steps from the
     reset (≈4.5 % of lanes finish per step once episodes are ~10 steps old), then the float64 bar of north_star."""
-    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
-    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "CartPole-v1", pol, 48, min_done_frac=0.02)
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "CartPole-v1", "step_kernel<CartPole,4,true,false,15,1>", 48,
+                                               min_done_frac=0.02)
     keep = ~out.Done
     assert np.abs(got1[:, keep] - s64[:, keep]).max() <= 1e-5                      # north_star: 1e-5 abs on float32 state
     xt, tt = float(np.float32(2.4)), float(np.float32(0.20943951606750488))
@@ -95,8 +98,7 @@ def test_step_kernel_CartPole_vec4_autoreset_nt15_at_2p20_lanes_matches_the_orac
 def test_step_kernel_Pendulum_vec4_autoreset_nt15_at_2p20_lanes_matches_the_oracle(gpu_pkg, oracle):
     """BASELINE config 3's kernel: step_kernel<Pendulum, 4, true, false, 15> (never terminates: the reset path is compiled
     in and never taken)."""
-    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
-    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Pendulum-v1", pol, 12)
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Pendulum-v1", "step_kernel<Pendulum,4,true,false,15,0>", 12)
     assert not out.Done.any() and not d64.any()
     assert np.abs(got1 - s64).max() <= 1e-5
     assert np.abs(out.Observation.astype(np.float64) - o64.T).max() <= 1e-5
@@ -108,8 +110,8 @@ def test_step_kernel_MountainCar_vec4_autoreset_nt15_at_2p20_lanes_matches_the_o
     goal per step and take the fused reset."""
     rng = np.random.default_rng(52)
     init = np.stack([rng.uniform(-1.2, 0.6, N), rng.uniform(-0.07, 0.07, N)]).astype(np.float32)
-    pol = {"envs_per_thread": 4, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 1}
-    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "MountainCar-v0", pol, 12, init=init, min_done_frac=0.002)
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "MountainCar-v0", "step_kernel<MountainCar,4,true,false,15,1>", 12,
+                                               init=init, min_done_frac=0.002)
     keep = ~out.Done
     assert np.abs(got1[:, keep] - s64[:, keep]).max() <= 1e-6
     near = np.abs(s64[0] - 0.5) < 1e-6
@@ -123,8 +125,8 @@ def test_step_kernel_pipe_Acrobot_items4_autoreset_nt15_at_2p20_lanes_matches_th
     divergent fused reset runs in nearly every wave."""
     rng = np.random.default_rng(53)
     init = np.stack([rng.uniform(-3.1, 3.1, N), rng.uniform(-3.1, 3.1, N), rng.uniform(-4, 4, N), rng.uniform(-9, 9, N)]).astype(np.float32)
-    pol = {"envs_per_thread": 1, "block": 256, "nontemporal_mask": 15, "sequential_lanes_per_thread": 4}
-    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Acrobot-v1", pol, 10, init=init, min_done_frac=0.01)
+    got0, got1, out, s64, o64, r64, d64 = _pin(gpu_pkg, oracle, "Acrobot-v1", "step_kernel_pipe<Acrobot,4,true,15>", 10,
+                                               init=init, min_done_frac=0.01)
     keep = ~out.Done
     dang = np.abs(np.angle(np.exp(1j * (got1[:2] - s64[:2]))))[:, keep]            # angles wrap at +-pi: compare on the circle
     dvel = np.abs(got1[2:] - s64[2:])[:, keep]

@@ -406,11 +406,14 @@ def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
     rng = np.random.default_rng(13)
     acts = rng.integers(0, 2, (steps, n)).astype(np.int32)
     results = []
-    for vec, nt in ((1, 0), (1, 12), (1, 15), (4, 0), (4, 12), (4, 15)):
+    # (lanes per thread, non-temporal mask, reset form: 0 = per-thread drain loop, 1 = wave-compacted through LDS)
+    for vec, nt, rf in ((1, 0, 0), (1, 12, 0), (1, 15, 0), (4, 0, 0), (4, 12, 0), (4, 15, 0), (4, 0, 1), (4, 12, 1), (4, 15, 1)):
         monkeypatch.setenv("GYMNET_VEC", str(vec))
         monkeypatch.setenv("GYMNET_NT", str(nt))
+        monkeypatch.setenv("GYMNET_RESET_FORM", str(rf))
         for auto in (True, False):
             with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto) as env:
+                assert env.KernelName() == f"step_kernel<CartPole,{vec},{str(auto).lower()},false,{nt},{rf if auto else 0}>"
                 env.Reset()
                 dones = 0
                 for t in range(steps):
@@ -418,7 +421,7 @@ def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
                 results.append((auto, env.GetState(), dones))
     for auto in (True, False):
         same = [r for r in results if r[0] == auto]
-        assert len(same) == 6 and same[0][2] > 0
+        assert len(same) == 9 and same[0][2] > 0
         for r in same[1:]:
             assert np.array_equal(r[1], same[0][1], equal_nan=True) and r[2] == same[0][2]
 

@@ -21,7 +21,7 @@ def test_header_symbols_are_all_exported(gymnet):
     assert not missing, missing
     # and the ctypes binding covers exactly the declared set
     assert declared == set(gymnet._capi.PROTOTYPES)
-    assert lib.gymnet_abi_version() == 2 == gymnet._capi.ABI_VERSION
+    assert lib.gymnet_abi_version() == 3 == gymnet._capi.ABI_VERSION
 
 
 def abi_manifest():
@@ -65,6 +65,10 @@ def test_env_descriptions_match_the_reference_ctor(gymnet):
     assert np.array_equal(np.array(i.obs_low[:4], dtype=np.float32), -high)
     assert i.algorithmic_bytes_per_step == 41
     assert [gymnet.env_describe(k).algorithmic_bytes_per_step for k in (1, 2, 3)] == [37, 25, 65]
+    # a state component the observation repeats verbatim is stored once, in the observation array (ABI 3)
+    assert [gymnet.env_describe(k).traffic_bytes_per_step for k in (0, 1, 2, 3)] == [41, 33, 25, 57]
+    assert list(gymnet.env_describe(3).state_row_in_obs) == [-1, -1, 4, 5, -1, -1, -1, -1]
+    assert list(gymnet.env_describe(1).state_row_in_obs)[:2] == [-1, 2] and set(gymnet.env_describe(0).state_row_in_obs) == {-1}
     assert gymnet.env_describe(1).action_is_box == 1 and gymnet.env_describe(3).obs_dim == 6
     with pytest.raises(ValueError):
         gymnet.env_describe(9)

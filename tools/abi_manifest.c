@@ -25,7 +25,7 @@ int main(void) {
     F(gymnet_env_info, obs_dim); F(gymnet_env_info, obs_aliases_state); F(gymnet_env_info, action_is_box);
     F(gymnet_env_info, action_n); F(gymnet_env_info, action_low); F(gymnet_env_info, action_high);
     F(gymnet_env_info, obs_low); F(gymnet_env_info, obs_high); F(gymnet_env_info, reward_low); F(gymnet_env_info, reward_high);
-    F(gymnet_env_info, algorithmic_bytes_per_step);
+    F(gymnet_env_info, algorithmic_bytes_per_step); F(gymnet_env_info, traffic_bytes_per_step); F(gymnet_env_info, state_row_in_obs);
     END();
     BEGIN(gymnet_device_view);
     F(gymnet_device_view, struct_size); F(gymnet_device_view, state_dim); F(gymnet_device_view, obs_dim);
