@@ -86,6 +86,39 @@ __device__ __forceinline__ void sincos_bounded(T x, T &s_out, T &c_out) {
     }
 }
 
+// sin/cos for SMALL arguments, |x| < 24 (|n| <= 15): Acrobot's wrapped angles and RK4 stage angles (|x| < 12 for every state
+// the dynamics can produce).  Two instructions shorter than sincos_bounded, per call: a TWO-constant Cody-Waite reduction —
+// with n at most 4 bits wide, C1 = pi/2 cut to 20 bits makes n*C1 exact, and the one remaining constant carries the next 24
+// bits (|r - (x - n pi/2)| < 2^-40) — and the cosine polynomial in Horner form (4 fma instead of 3 fma + 2 mul).  Same
+// minimax coefficients; |error| <= 1.2e-7 against float64 over |x| <= 16 (tests/test_oracle.py).  Its results differ from
+// sincos_bounded's in the last bit for some arguments, so the CPU twin has its own restatement (ref_sincos_f32_small).
+template <class T>
+__device__ __forceinline__ void sincos_small(T x, T &s_out, T &c_out) {
+    T n;
+    const T xs = x * vm::splat(x, 0.636619772367581343f);
+    if constexpr (sizeof(T) == sizeof(float)) n = rintf(xs);
+    else n = T{rintf(xs.x), rintf(xs.y)};
+    T r = vm::fmak(-0x1.921fap+0f, n, x);                 // pi/2 to 20 bits: n * C1 is exact for |n| <= 15
+    r = vm::fmak(-0x1.54442ep-20f, n, r);                 // pi/2 - C1
+    const T z = r * r;
+    T ps = vm::fmac(vm::splat(z, -1.9515295891e-4f), z, 8.3321608736e-3f);
+    ps = vm::fmac(ps, z, -1.6666654611e-1f);
+    const T s = vm::fma(r * z, ps, r);
+    T pc = vm::fmac(vm::splat(z, 2.443315711809948e-5f), z, -1.388731625493765e-3f);
+    pc = vm::fmac(pc, z, 4.166664568298827e-2f);
+    pc = vm::fmac(pc, z, -0.5f);
+    const T c = vm::fmac(pc, z, 1.0f);
+    if constexpr (sizeof(T) == sizeof(float)) {
+        sincos_quadrant(s, c, n, s_out, c_out);
+    } else {
+        float s0, c0, s1, c1;
+        sincos_quadrant(s.x, c.x, n.x, s0, c0);
+        sincos_quadrant(s.y, c.y, n.y, s1, c1);
+        s_out = T{s0, s1};
+        c_out = T{c0, c1};
+    }
+}
+
 // BOUNDED = true drops the OCML fallback: for callers whose argument is bounded by construction (Acrobot's wrapped
 // angles and RK4 stage angles, |x| < 16).  Same bits as the full version for every |x| <= 65536; beyond that the result
 // is unspecified (finite garbage or NaN, never a hang).  It exists because the ten inlined Payne-Hanek fallbacks made the
@@ -323,8 +356,8 @@ struct Acrobot {
     __device__ __forceinline__ static void dsdt(const T (&s)[4], T torque, T (&d)[4]) {
         const T th1 = s[0], th2 = s[1], A = s[2], B = s[3];
         T s1, c1, s2, c2;
-        sincos_bounded<T>(th1, s1, c1);
-        sincos_bounded<T>(th2, s2, c2);
+        sincos_small<T>(th1, s1, c1);
+        sincos_small<T>(th2, s2, c2);
         const T d1 = c2 + vm::splat(c2, 3.5f);                                    // 0.25 + (1.25 + c2) + 2
         const T d2 = vm::fmak(0.5f, c2, vm::splat(c2, 1.25f));                    // 0.25 + 0.5 c2 + 1
         const T phi2 = vm::splat(s1, 4.9f) * vm::fma(s1, c2, c1 * s2);            // m2 lc2 g sin(th1 + th2)
@@ -338,16 +371,19 @@ struct Acrobot {
         d[0] = A; d[1] = B; d[2] = ddth1; d[3] = ddth2;
     }
 
-    // upstream loops `while x > M: x -= diff` / `while x < m: x += diff`.  One RK4 step of dt = 0.2 moves a clamped state by at
-    // most ~10 rad, i.e. two wraps; this is the same repeated subtraction, at most FOUR times per direction and written
-    // without a loop: identical results whenever four suffice (every state the dynamics can produce), a non-finite or
-    // absurd state cannot hang the GPU, and — no back-edge — the compiler's s_waitcnt bookkeeping stays exact across the
-    // step (a loop here made it fall back to vmcnt(0) after every lane of the software-pipelined kernel).
-    __device__ __forceinline__ static float wrap(float x, float m, float M) {
-        const float diff = M - m;
-        if (x > M) { x -= diff; if (x > M) { x -= diff; if (x > M) { x -= diff; if (x > M) x -= diff; } } }
-        if (x < m) { x += diff; if (x < m) { x += diff; if (x < m) { x += diff; if (x < m) x += diff; } } }
-        return x;
+    // upstream loops `while x > M: x -= diff` / `while x < m: x += diff` with m = -M.  One RK4 step of dt = 0.2 moves a clamped
+    // state by at most ~10 rad, i.e. two wraps; this is the same repeated subtraction, at most FOUR times and written without a
+    // loop: identical results whenever four suffice (every state the dynamics can produce), a non-finite or absurd state cannot
+    // hang the GPU, and — no back-edge — the compiler's s_waitcnt bookkeeping stays exact across the step.  Only one of the two
+    // upstream loops can ever run, and x + diff == -(|x| - diff) bit for bit, so the magnitude is wrapped and the sign put
+    // back (the subtraction of a magnitude in (M, M + diff] lands in (-M, M]: the sign of the RESULT may flip, which is why
+    // the sign is applied by multiplication-free xor of the original sign bit): 14 instructions per angle instead of 24.
+    __device__ __forceinline__ static float wrap(float x, float M) {
+        const float diff = M + M;
+        const uint32_t sign = __float_as_uint(x) & 0x80000000u;
+        float ax = fabsf(x);
+        if (ax > M) { ax -= diff; if (ax > M) { ax -= diff; if (ax > M) { ax -= diff; if (ax > M) ax -= diff; } } }
+        return __uint_as_float(__float_as_uint(ax) ^ sign);
     }
 
     // One RK4 step of dt = 0.2 with the torque held constant: y <- s + dt/6 (k1 + 2 k2 + 2 k3 + k4), 4 fma per component.
@@ -372,10 +408,11 @@ struct Acrobot {
     // wrap the angles, clamp the velocities (per element: compares and selects have no packed form)
     __device__ __forceinline__ static void wrap_clamp(float (&y)[4]) {
         constexpr float mv1 = 4.0f * PI, mv2 = 9.0f * PI;
-        y[0] = wrap(y[0], -PI, PI);
-        y[1] = wrap(y[1], -PI, PI);
-        y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
-        y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+        y[0] = wrap(y[0], PI);
+        y[1] = wrap(y[1], PI);
+        // v_med3_f32: the clamp in one instruction; identical to the compare/select pair for every non-NaN velocity
+        y[2] = __builtin_amdgcn_fmed3f(y[2], -mv1, mv1);
+        y[3] = __builtin_amdgcn_fmed3f(y[3], -mv2, mv2);
     }
 
     // One env: RK4, wrap / clamp; the sin/cos of the new angles serve both the termination test and the observation.
@@ -391,8 +428,8 @@ struct Acrobot {
         for (int i = 0; i < 4; ++i) s[i] = y[i];
         // done = -cos(th1) - cos(th2 + th1) > 1, with cos(th1 + th2) = c1*c2 - s1*s2
         float s1, c1, s2, c2;
-        sincos_bounded<float>(y[0], s1, c1);
-        sincos_bounded<float>(y[1], s2, c2);
+        sincos_small<float>(y[0], s1, c1);
+        sincos_small<float>(y[1], s2, c2);
         done = (-c1 - fmaf(c1, c2, -(s1 * s2))) > 1.0f;
         reward = done ? 0.0f : -1.0f;
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = y[2]; o[5] = y[3];
@@ -414,8 +451,8 @@ struct Acrobot {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s[i][0] = y0[i]; s[i][1] = y1[i]; }
         f2 s1, c1, s2, c2;
-        sincos_bounded<f2>(f2{y0[0], y1[0]}, s1, c1);
-        sincos_bounded<f2>(f2{y0[1], y1[1]}, s2, c2);
+        sincos_small<f2>(f2{y0[0], y1[0]}, s1, c1);
+        sincos_small<f2>(f2{y0[1], y1[1]}, s2, c2);
         const f2 t = -c1 - vm::fma(c1, c2, -(s1 * s2));
         done[0] = t.x > 1.0f; done[1] = t.y > 1.0f;
         reward[0] = done[0] ? 0.0f : -1.0f; reward[1] = done[1] ? 0.0f : -1.0f;
@@ -440,11 +477,11 @@ struct Acrobot {
         sincos_f32(s[1], s2, c2);
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
     }
-    // a freshly reset state: angles in [-0.1, 0.1) — same bits as observe(), without the fallback code
+    // a freshly reset state: angles in [-0.1, 0.1) — the step's own small-argument sin/cos
     __device__ __forceinline__ static void observe_fresh(const float (&s)[S], float (&o)[O]) {
         float s1, c1, s2, c2;
-        sincos_f32<true>(s[0], s1, c1);
-        sincos_f32<true>(s[1], s2, c2);
+        sincos_small<float>(s[0], s1, c1);
+        sincos_small<float>(s[1], s2, c2);
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
     }
 };

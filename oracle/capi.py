@@ -44,6 +44,7 @@ def lib():
     L.ref_cartpole_step_batch_f64.argtypes = [_f64p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
     L.ref_cartpole_step_batch_f32.argtypes = [_f32p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
     L.ref_sincos_f32_kernel.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ref_sincos_f32_small.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ref_div_total_mass_kernel.argtypes = [C.c_float]
     L.ref_div_total_mass_kernel.restype = C.c_float
     L.ref_check_div_total_mass.argtypes = [_i32p, C.c_int32]
@@ -108,14 +109,16 @@ def cartpole_step(state, action, sbd=None, dtype=np.float64):
     return s, reward, done, b
 
 
-def sincos_kernel(x):
-    """The kernels' sin/cos restated on the CPU (bit-identical to the GPU for |x| <= 65536)."""
+def sincos_kernel(x, small=False):
+    """The kernels' sin/cos restated on the CPU (bit-identical to the GPU for |x| <= 65536); small=True: the
+    two-constant small-argument form of the Acrobot kernel (|x| < 24)."""
     x = np.asarray(x, dtype=np.float32).reshape(-1)
     s = np.empty_like(x); c = np.empty_like(x)
     fs, fc = C.c_float(), C.c_float()
     L = lib()
+    fn = L.ref_sincos_f32_small if small else L.ref_sincos_f32_kernel
     for i, v in enumerate(x):
-        L.ref_sincos_f32_kernel(float(v), C.byref(fs), C.byref(fc))
+        fn(float(v), C.byref(fs), C.byref(fc))
         s[i], c[i] = fs.value, fc.value
     return s, c
 

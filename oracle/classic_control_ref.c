@@ -109,6 +109,26 @@ void ref_sincos_f32_kernel(float x, float *s_out, float *c_out) {
     *s_out = (q & 2) ? -ss : ss;
     *c_out = ((q + 1) & 2) ? -cc : cc;
 }
+/* The small-argument sin/cos of the Acrobot kernel (envs.hpp: sincos_small), operation for operation: two-constant
+ * Cody-Waite reduction (pi/2 cut to 20 bits, so n * C1 is exact for |n| <= 15) + the same minimax polynomials with the
+ * cosine in Horner form.  Meant for |x| < 24; Acrobot's arguments stay below 12. */
+void ref_sincos_f32_small(float x, float *s_out, float *c_out) {
+    const float n = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-0x1.921fap+0f, n, x);
+    r = fmaf(-0x1.54442ep-20f, n, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc, z, -0.5f);
+    const float c = fmaf(pc, z, 1.0f);
+    const int q = (int)n & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *s_out = (q & 2) ? -ss : ss;
+    *c_out = ((q + 1) & 2) ? -cc : cc;
+}
 static inline float ksin(float x) { float s, c; ref_sincos_f32_kernel(x, &s, &c); return s; }
 static inline float kcos(float x) { float s, c; ref_sincos_f32_kernel(x, &s, &c); return c; }
 
@@ -441,8 +461,8 @@ static void acrobot_dsdt_f32(const float s[4], float tau, float d[4]) {
      * ddth2 multiplied through by d1 so that ONE reciprocal R = 1/(d1*det) serves both accelerations; every a*b+c is an fmaf */
     float th1 = s[0], th2 = s[1], A = s[2], B = s[3];
     float s1, c1, s2, c2;
-    ref_sincos_f32_kernel(th1, &s1, &c1);
-    ref_sincos_f32_kernel(th2, &s2, &c2);
+    ref_sincos_f32_small(th1, &s1, &c1);
+    ref_sincos_f32_small(th2, &s2, &c2);
     float d1 = c2 + 3.5f;
     float d2 = fmaf(0.5f, c2, 1.25f);
     float phi2 = 4.9f * fmaf(s1, c2, c1 * s2);
@@ -480,7 +500,7 @@ int ref_acrobot_step_f32(float *state, int a, float *obs6, float *reward) {
     y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
     y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
     for (int i = 0; i < 4; ++i) state[i] = y[i];
-    ref_sincos_f32_kernel(y[0], &obs6[1], &obs6[0]); ref_sincos_f32_kernel(y[1], &obs6[3], &obs6[2]);
+    ref_sincos_f32_small(y[0], &obs6[1], &obs6[0]); ref_sincos_f32_small(y[1], &obs6[3], &obs6[2]);
     int done = (-obs6[0] - fmaf(obs6[0], obs6[2], -(obs6[1] * obs6[3]))) > 1.0f;
     *reward = done ? 0.0f : -1.0f;
     obs6[4] = y[2]; obs6[5] = y[3];
@@ -510,7 +530,7 @@ static void observe_f32(int env_id, const float *s, float *o) {
         case 0: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; break;             /* CartPoleEnv.cs:166,185 */
         case 1: ref_sincos_f32_kernel(s[0], &o[1], &o[0]); o[2] = s[1]; break;
         case 2: o[0] = s[0]; o[1] = s[1]; break;
-        default: ref_sincos_f32_kernel(s[0], &o[1], &o[0]); ref_sincos_f32_kernel(s[1], &o[3], &o[2]); o[4] = s[2]; o[5] = s[3]; break;
+        default: ref_sincos_f32_small(s[0], &o[1], &o[0]); ref_sincos_f32_small(s[1], &o[3], &o[2]); o[4] = s[2]; o[5] = s[3]; break;   /* a FRESH state: the step's own sin/cos */
     }
 }
 

@@ -286,6 +286,24 @@ def test_kernel_sincos_accuracy(oracle):
     assert np.isnan(s).all() and np.isnan(c).all()
 
 
+def test_small_argument_sincos_of_the_acrobot_kernel(oracle):
+    """envs.hpp sincos_small (two-constant Cody-Waite, Horner cosine; Acrobot's RK4 stage angles, |x| < 12): accuracy against
+    float64 over its whole intended range and beyond, exact odd / even symmetry, and the reduction's premise — n * C1 is
+    exact for every |n| <= 15."""
+    rng = np.random.default_rng(44)
+    x = np.concatenate([rng.uniform(-16, 16, 60_000), rng.uniform(-3.2, 3.2, 60_000), np.linspace(-24, 24, 4001)]).astype(f32)
+    s, c = oracle.sincos_kernel(x, small=True)
+    xs = x.astype(np.float64)
+    assert np.abs(s - np.sin(xs)).max() <= 1.2e-7 and np.abs(c - np.cos(xs)).max() <= 1.2e-7
+    s2, c2 = oracle.sincos_kernel(-x, small=True)
+    assert np.array_equal(s, -s2) and np.array_equal(c, c2)
+    c1 = np.float32(float.fromhex("0x1.921fap+0"))
+    for n in range(-15, 16):
+        assert float(np.float32(n) * c1) == n * float(c1)                       # exact product: 20 + 4 bits
+    rest = np.pi / 2 - float(c1)
+    assert abs(float(np.float32(float.fromhex("0x1.54442ep-20"))) - rest) <= 2.0 ** -44          # half an ulp of C2
+
+
 def test_restatement_against_exact_rational_arithmetic(oracle):
     """Third, evaluation-order-independent anchor: the CartPoleEnv.Step formulas (CartPoleEnv.cs:146-157) evaluated
     in EXACT rational arithmetic (sin/cos by Taylor series on Fractions, 40 terms) with the float32-valued
