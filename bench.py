@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 MIN_TIMED_SECONDS = 0.05   # repeat the K-step region until this much has been timed
 MAX_REPEATS = 2000
+WATCHDOG_EXIT = 3          # exit status of every rank when a collective section hung and the watchdog fired
 
 
 def parse():
@@ -61,6 +62,9 @@ def parse():
                    "(exercises the collective code path on a 1-GPU box)")
     p.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
     p.add_argument("--no-overlap", action="store_true", help="N > 1: single observation buffer (no gather/step overlap)")
+    p.add_argument("--no-group-leg", action="store_true", help="N > 1: skip the single-process gymnet_group_* leg")
+    p.add_argument("--no-host-boundary", action="store_true", help="skip the NDArray-shaped host path figure (gymnet_vecenv_step)")
+    p.add_argument("--group-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run the gymnet_group_* leg over this many members
     return p.parse_args()
 
 
@@ -216,8 +220,133 @@ def median(xs):
     return s[m] if len(s) % 2 else 0.5 * (s[m - 1] + s[m])
 
 
+def measure_host_boundary(pkg, env_name, n, device, seed, algorithmic_bytes, steps=20):
+    """ms per host-boundary step (actions in, observations / reward / done out over PCIe), median of `steps` calls."""
+    import numpy as np
+    out = {"num_envs": n, "unit": "ms/step", "note": "PCIe-inclusive; never `value` (inputs are NOT resident in HBM)"}
+    with pkg.VectorEnv(env_name, n, device=device, seed=seed, auto_reset=True) as e:
+        e.Reset()
+        obs_dim = e.ObsDim
+        boundary_bytes = n * (4 + 4 * obs_dim + 4 + 1)           # actions in; obs + reward + done out
+        for label in ("pageable_caller_buffers", "pinned_library_buffers"):
+            try:
+                if label.startswith("pinned"):
+                    a, o, r, d = e.HostBuffers()
+                else:
+                    a = np.empty(n, e._adtype); o = np.empty((n, obs_dim), np.float32)
+                    r = np.empty(n, np.float32); d = np.empty(n, np.uint8)
+                    o.fill(0); r.fill(0); d.fill(0)             # touch the pages: no first-use faults inside the timing
+                a[:] = e.SampleActions(seed=seed + 1, tick=0)
+                for _ in range(3):
+                    e.StepInto(a, o, r, d)
+                ts = []
+                for _ in range(steps):
+                    t0 = time.perf_counter()
+                    e.StepInto(a, o, r, d)
+                    ts.append(time.perf_counter() - t0)
+                ms = median(ts) * 1e3
+                out[label] = {"ms_per_step": ms, "env_steps_per_sec": n / (ms * 1e-3), "pcie_GBps": boundary_bytes / (ms * 1e-3) / 1e9}
+            except Exception as ex:                               # noqa: BLE001
+                out[label] = {"error": repr(ex)[:200]}
+    out["boundary_bytes_per_step"] = boundary_bytes
+    return out
+
+
+def group_leg(args, members):
+    """The multi-GPU entry a P/Invoking host has (the reference has no torch.distributed): ONE process driving `members`
+    GPUs through gymnet_group_* (csrc/group.hip) — step-only, then a step + observation all-gather per step with the
+    hand-written direct push (serial, and overlapped with the next step through double-buffered observations) and with
+    RCCL (ncclCommInitAll inside the library).  Runs in a FRESH child process (started with subprocess, never exec'd from a
+    process that touched the GPU); prints one JSON object.  With fewer devices than members the members are logical
+    (several per device): plumbing only, labelled."""
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    ndev = pkg.device_count()
+    G, n, ring = members, args.num_envs, 8
+    devices = [m % ndev for m in range(G)]
+    res = {"members": G, "devices_visible": ndev, "device_of_member": devices, "lanes_per_member": n,
+           "real_multi_gpu": ndev >= G,
+           "note": ("one process, one device per member" if ndev >= G else
+                    "FEWER DEVICES THAN MEMBERS: members are logical and share devices — plumbing check, not a multi-GPU measurement")}
+    adtype = torch.float32 if args.env == "Pendulum-v1" else torch.int32
+    acts = [torch.empty((ring, n), dtype=adtype, device=f"cuda:{d}") for d in devices]
+    K = max(args.steps, 64)
+
+    def timed(fn, sync, reps=5):
+        ts = []
+        for _ in range(reps):
+            sync()
+            t0 = time.perf_counter()
+            fn()
+            sync()
+            ts.append(time.perf_counter() - t0)
+        return median(ts)
+
+    for label, gather, overlap in (("step_only", "none", False), ("direct", "direct", False), ("direct_overlapped", "direct", True),
+                                   ("rccl", "rccl", False)):
+        if gather == "rccl" and ndev < G:
+            res[label] = {"skipped": "RCCL needs one device per member"}
+            continue
+        try:
+            with pkg.GroupVectorEnv(args.env, n * G, G, devices=devices, seed=0x5EED, auto_reset=True, gather=gather, overlap=overlap) as grp:
+                for m, mem in enumerate(grp.Members):
+                    for t in range(ring):
+                        mem.SampleActionsDevice(acts[m][t].data_ptr(), seed=0x5EED + 1, tick=t)
+                grp.ResetDevice()
+                grp.Sync()
+                if gather == "none":
+                    ptrs = [a.data_ptr() for a in acts]
+                    grp.RolloutDevice(ptrs, K, n, ring)
+                    wall = timed(lambda: grp.RolloutDevice(ptrs, K, n, ring), grp.Sync)
+                    steps = K
+                else:
+                    steps = 64
+                    slices = [[acts[m][t].data_ptr() for m in range(G)] for t in range(ring)]
+
+                    def loop():
+                        for t in range(steps):
+                            grp.StepDevice(slices[t % ring])
+                            grp.AllGatherObs()
+                        grp.WaitGather()
+                    loop()
+                    wall = timed(loop, grp.Sync)
+                    rep = grp.ReadReplica(G - 1)             # [G, D, n]: the LAST member's view of everyone's observations
+                    ok = bool((abs(rep).reshape(G, -1).sum(axis=1) > 0).all()) and bool((rep == rep).all())
+                res[label] = {"value": n * G * steps / wall, "unit": "env-steps/s", "us_per_step": wall / steps * 1e6, "steps": steps}
+                if gather != "none":
+                    res[label]["every_member_slice_arrived"] = ok
+                    res[label]["allgather_bytes_per_member_per_step"] = grp.ObsDim * n * 4
+        except Exception as e:                                   # noqa: BLE001 - the leg is optional; report, never hide
+            res[label] = {"error": repr(e)[:300]}
+    print(json.dumps(res), flush=True)
+
+
+def run_group_child(args, members, timeout=300):
+    """Starts the gymnet_group_* leg as a fresh child process and returns its JSON (or an error record)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-child", str(members), "--env", args.env,
+           "--num-envs", str(args.num_envs), "--steps", str(args.steps)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout} s"}
+    except Exception as e:                                       # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def main():
     args = parse()
+    # the host driver only supports dmabuf IPC: without this, RCCL and the HIP-IPC peer buffers fail with
+    # "hipIpcGetMemHandle: invalid argument" — set before anything loads the HIP runtime, in every launch form
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.group_child:
+        return group_leg(args, args.group_child)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     # lower completion latency of the closing synchronize: ROCr polls its signals instead of sleeping on an interrupt
@@ -345,6 +474,7 @@ def main():
             reps = int(tr[0])
         # odd repeats carry the HIP events (kernel-duration figure), even repeats are the bare wall-clock bracket
         rows = [first] + [timed_region(fn, events=(i % 2 == 0)) for i in range(reps - 1)]
+        own_rows[:] = rows                                       # this rank's own clocks, before the MAX over ranks
         if use_dist:
             tw = torch.tensor(rows, dtype=torch.float64, device=red_dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -354,7 +484,9 @@ def main():
     run(W)
     torch.cuda.synchronize(dev)
     steps_before = local.Counters()["lane_steps"]
+    own_rows = []
     rows = repeat_until(lambda: run(K), args.min_seconds)
+    headline_rows = list(own_rows)                               # the headline's regions (later repeat_until calls overwrite own_rows)
     bare = [r[0] for r in rows if r[1] < 0] or [r[0] for r in rows]          # regions without event records
     walls = bare
     wall = median(bare)
@@ -419,6 +551,25 @@ def main():
     out = headline() if rank == 0 else {}
     emitted = threading.Lock()
 
+    # N > 1: what each rank ran on and measured by itself, and proof that the collective backend really spans `world` ranks
+    if use_dist:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "pid": os.getpid(), "kernel": local.KernelName(),
+                "events_us_per_step": median([r[1] for r in headline_rows if r[1] >= 0]) * 1e3 / K,
+                "wall_us_per_step": median([r[0] for r in headline_rows if r[1] < 0] or [r[0] for r in headline_rows]) * 1e6 / K}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        probe = torch.tensor([rank + 1], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)            # every rank contributes rank + 1: sum = N (N + 1) / 2
+        if rank == 0:
+            out["ranks"] = everyone
+            out["collective"] = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl",
+                                 "world_size": dist.get_world_size(),
+                                 "allreduce_sum_of_rank_plus_1": int(probe[0]), "expected": world * (world + 1) // 2,
+                                 "distinct_devices": len({(e["uuid"], e["pci_bus_id"], e["device"]) for e in everyone})}
+
     def emit_and_exit_on_timeout(section, seconds):
         """Watchdog for a secondary section that could hang rather than fail (a collective waiting for a peer): after `seconds`
         rank 0 prints the headline it already has, with the section marked as timed out, and every rank leaves."""
@@ -430,7 +581,7 @@ def main():
                 if rank == 0:
                     out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(WATCHDOG_EXIT)          # non-zero: a deadlocked section must be visible to the caller (never exec)
         t = threading.Timer(seconds, fire)
         t.daemon = True
         t.start()
@@ -466,6 +617,13 @@ def main():
         fused_us = f0.elapsed_time(f1) * 1e3 / fsteps
         fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
                  "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
+
+    # Secondary figure, NEVER `value`: the NDArray-shaped host boundary a C# VectorEnv.Step(NDArray) reaches — gymnet_vecenv_step
+    # with caller-owned host buffers, PCIe both ways inside the call (VecEnvWrapper.cs:22-24, Step.cs:8-10): (a) ordinary
+    # pageable caller memory, (b) the library's pinned, device-mapped buffers (gymnet_vecenv_host_buffers: zero staging).
+    host_boundary = None
+    if extras and not args.no_host_boundary:
+        host_boundary = measure_host_boundary(pkg, args.env, n, dev_index, seed, local.AlgorithmicBytesPerStep)
 
     # Secondary figures for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
     # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
@@ -568,23 +726,37 @@ def main():
         except Exception as e:
             big = {"error": repr(e)[:200]}
 
-    if rank == 0 and emitted.acquire(blocking=False):
+    if rank == 0:
         out["roofline"]["isolated_launch_us_median"] = single_us
         out["roofline"]["measured_copy_GBps"] = copy_bw
         if big:
             out["hbm_resident_2p27"] = big
         if fused:
             out["fused_rollout"] = fused
+        if host_boundary:
+            out["host_boundary"] = host_boundary
         if gathered:
             out["with_obs_allgather"] = gathered
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     if use_dist:
+        # the process group goes away BEFORE the legs below: ranks other than 0 leave (rc 0), so the single-process group
+        # leg and the CPU baseline have the GPUs and the host cores to themselves.  Guarded: a teardown that hangs still
+        # yields the line (and a non-zero exit).
+        watchdog = emit_and_exit_on_timeout("teardown", 60)
         dist.barrier()
         if node_barrier is not None:
             node_barrier.close()
         dist.destroy_process_group()
+        watchdog.cancel()
+    if rank == 0 and emitted.acquire(blocking=False):
+        if world > 1:
+            time.sleep(1.0)                                      # the other ranks are exiting
+            if not args.no_group_leg and not gather_in_region:
+                out["group_single_process"] = run_group_child(args, world)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+            if world > 1:
+                out["cpu_baseline"]["when"] = "on rank 0's host after the other ranks had exited (no GPU timing live)"
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
     "gymnet_vecenv_kernel_name": (C.c_int, [_H, C.c_char_p, C.c_int32]),
+    "gymnet_vecenv_host_buffers": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_set_state": (C.c_int, [_H, _P]),
     "gymnet_vecenv_get_steps_beyond_done": (C.c_int, [_H, _P]),

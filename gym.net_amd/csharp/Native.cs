@@ -106,6 +106,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_device_view(IntPtr h, out GymnetDeviceView view);
         [DllImport(Lib)] public static extern int gymnet_vecenv_launch_policy(IntPtr h, out int vec, out int block, out int nt, out int sequential_lanes);
         [DllImport(Lib)] public static extern int gymnet_vecenv_kernel_name(IntPtr h, byte[] buf, int capacity);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_host_buffers(IntPtr h, out IntPtr actions, out IntPtr obs, out IntPtr reward, out IntPtr done);
 
         // ---- state access / bookkeeping
         [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, float* state_soa);

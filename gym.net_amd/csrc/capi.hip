@@ -194,6 +194,13 @@ int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t 
 // copy the current results to host buffers (any may be NULL); blocks
 int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
+    if (h->pin_block && (obs_out || reward_out || done_out) && (!obs_out || obs_out == h->pin_obs) &&
+        (!reward_out || reward_out == h->pin_reward) && (!done_out || done_out == h->pin_done)) {
+        // the caller reads the library's pinned buffers: ONE kernel writes the results across PCIe, no staging, no memcpy calls
+        HIP_TRY(h, launch_export_host(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, obs_out, reward_out, done_out, h->n, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return GYMNET_OK;
+    }
     if (h->hm_block) {   // latency path for small batches: one export kernel into host-mapped memory, one sync, host memcpy
         if (obs_out || reward_out || done_out)
             HIP_TRY(h, launch_export_small(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, h->hm_obs,
@@ -386,6 +393,7 @@ int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     drop_graphs(h);
     for (void *p : h->owned) (void)hipFree(p);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
+    if (h->pin_block) (void)hipHostFree(h->pin_block);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GYMNET_OK;
@@ -637,6 +645,29 @@ int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_
     }
     ST_TRY(launch_reset_lanes(h, mask ? h->d_mask : h->d_done));
     return copy_out(h, obs_out, nullptr, nullptr);
+    });
+}
+
+int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, float **obs, float **reward, uint8_t **done) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!h->pin_block) {
+        const EnvDesc &d = *h->desc;
+        auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };          // every buffer on its own page
+        const size_t a_b = up((size_t)h->n * 4), o_b = up((size_t)h->n * d.obs_dim * 4), r_b = up((size_t)h->n * 4), d_b = up((size_t)h->n);
+        void *blk = nullptr;
+        hipError_t e = hipHostMalloc(&blk, a_b + o_b + r_b + d_b, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, GYMNET_ERR_OOM, "hipHostMalloc(%zu bytes, mapped) failed: %s", a_b + o_b + r_b + d_b, hipGetErrorString(e)); }
+        std::memset(blk, 0, a_b + o_b + r_b + d_b);
+        char *b = static_cast<char *>(blk);
+        h->pin_block = blk; h->pin_actions = b; h->pin_obs = reinterpret_cast<float *>(b + a_b);
+        h->pin_reward = reinterpret_cast<float *>(b + a_b + o_b); h->pin_done = reinterpret_cast<uint8_t *>(b + a_b + o_b + r_b);
+    }
+    if (actions) *actions = h->pin_actions;
+    if (obs) *obs = h->pin_obs;
+    if (reward) *reward = h->pin_reward;
+    if (done) *done = h->pin_done;
+    return GYMNET_OK;
     });
 }
 

@@ -74,6 +74,11 @@ struct gymnet_vecenv {
     float *hm_obs = nullptr, *hm_reward = nullptr;
     uint8_t *hm_done = nullptr;
     void *hm_block = nullptr;
+    // gymnet_vecenv_host_buffers: library-owned page-locked, device-mapped host buffers for the host-boundary path (any batch
+    // size); the step's export kernel writes results straight into them, actions are DMA'd out of them
+    void *pin_block = nullptr, *pin_actions = nullptr;
+    float *pin_obs = nullptr, *pin_reward = nullptr;
+    uint8_t *pin_done = nullptr;
     uint32_t *d_bad = nullptr;
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
     int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)

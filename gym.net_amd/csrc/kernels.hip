@@ -834,6 +834,41 @@ __global__ __launch_bounds__(256) void export_small_kernel(const float *__restri
     if (out_done) out_done[i] = done[i];
 }
 
+// The host boundary without staging: observations (SoA -> row-major [n][O]), rewards and done flags written STRAIGHT into
+// page-locked, device-mapped host memory (gymnet_vecenv_host_buffers) — the stores themselves are the PCIe transfer, no
+// device-side pack buffer, no memcpy calls.  A thread owns 4 consecutive lanes: it transposes their 4 x O observation words in
+// registers and writes them as O 16-byte stores to 16 * O contiguous bytes, so a wave writes one contiguous 1 KiB * O block
+// (full PCIe write payloads for any O, including the 3- and 6-wide observations).
+template <int O>
+__global__ __launch_bounds__(256) void export_host_kernel(const float *__restrict__ obs, int64_t stride, const float *__restrict__ reward,
+                                                          const uint8_t *__restrict__ done, float *__restrict__ out_obs,
+                                                          float *__restrict__ out_reward, uint8_t *__restrict__ out_done, int64_t n,
+                                                          int vec_ok) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    if (vec_ok && i0 + 4 <= n) {
+        if (out_obs) {
+            float row[4 * O];
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(obs + k * stride + i0);
+                row[0 * O + k] = t.x; row[1 * O + k] = t.y; row[2 * O + k] = t.z; row[3 * O + k] = t.w;
+            }
+            f32x4 *dst = reinterpret_cast<f32x4 *>(out_obs + i0 * O);
+#pragma unroll
+            for (int q = 0; q < O; ++q) { f32x4 t; t.x = row[4 * q]; t.y = row[4 * q + 1]; t.z = row[4 * q + 2]; t.w = row[4 * q + 3]; dst[q] = t; }
+        }
+        if (out_reward) *reinterpret_cast<f32x4 *>(out_reward + i0) = *reinterpret_cast<const f32x4 *>(reward + i0);
+        if (out_done) *reinterpret_cast<uint32_t *>(out_done + i0) = *reinterpret_cast<const uint32_t *>(done + i0);
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + 4; ++i) {
+            if (out_obs) for (int k = 0; k < O; ++k) out_obs[i * O + k] = obs[k * stride + i];
+            if (out_reward) out_reward[i] = reward[i];
+            if (out_done) out_done[i] = done[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_i32_kernel(int32_t *p, int32_t v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1124,6 +1159,23 @@ hipError_t launch_export_small(int obs_dim, const float *obs, int64_t stride, co
         case 3: hipLaunchKernelGGL(export_small_kernel<3>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
         case 4: hipLaunchKernelGGL(export_small_kernel<4>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
         case 6: hipLaunchKernelGGL(export_small_kernel<6>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_export_host(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
+                              float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    const int vec_ok = al(obs, 16) && stride % 4 == 0 && al(reward, 16) && al(done, 4) && (!out_obs || al(out_obs, 16)) &&
+                       (!out_reward || al(out_reward, 16)) && (!out_done || al(out_done, 4));
+    const dim3 grid(grid_for((n + 3) / 4, 256)), blk(256);
+    switch (obs_dim) {
+        case 2: hipLaunchKernelGGL(export_host_kernel<2>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n, vec_ok); break;
+        case 3: hipLaunchKernelGGL(export_host_kernel<3>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n, vec_ok); break;
+        case 4: hipLaunchKernelGGL(export_host_kernel<4>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n, vec_ok); break;
+        case 6: hipLaunchKernelGGL(export_host_kernel<6>, grid, blk, 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n, vec_ok); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

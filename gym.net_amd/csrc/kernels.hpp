@@ -84,6 +84,10 @@ hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float 
 // [n*O floats | n floats | n bytes] by a single kernel — no device-to-host memcpy calls on the latency path
 hipError_t launch_export_small(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
                                float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
+// any batch size: obs (row-major), reward, done written straight into page-locked device-mapped HOST memory (the stores are the
+// PCIe transfer); any out pointer may be NULL
+hipError_t launch_export_host(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
+                              float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
 // recompute obs from state (after set_state) for envs whose observation is derived
 hipError_t launch_observe(int env_id, const float *state, int64_t state_stride, float *obs, int64_t obs_stride,
                           int64_t n, hipStream_t st);

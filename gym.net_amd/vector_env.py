@@ -130,6 +130,7 @@ class VectorEnv:
     # ---- lifecycle ------------------------------------------------------------------------------
     def Close(self):                                                                 # VecEnvWrapper.cs:26-30
         if getattr(self, "_h", None) is not None and self._h:
+            self._pinned = None                     # views over memory the handle owns
             if self._owns_handle:
                 self._lib.gymnet_vecenv_destroy(self._h)
             self._h = C.c_void_p()
@@ -192,6 +193,35 @@ class VectorEnv:
             a = self._actions(action)
             capi.check(self._lib.gymnet_vecenv_step(self._h, _host(a), _host(obs), _host(rew), _host(done)))
         return BatchStep(obs, rew, done.astype(bool), None)
+
+    def HostBuffers(self):
+        """(actions, obs, reward, done): numpy views over the library's page-locked, device-mapped host buffers
+        (gymnet_vecenv_host_buffers).  Passing them to StepInto / ResetInto runs the host boundary without staging copies."""
+        if getattr(self, "_pinned", None) is None:
+            a, o, r, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            capi.check(self._lib.gymnet_vecenv_host_buffers(self._h, C.byref(a), C.byref(o), C.byref(r), C.byref(d)))
+            n, D = self.NumberOfEnvironments, self.ObsDim
+
+            def view(ptr, ctype, count, dtype, shape):
+                return np.frombuffer((ctype * count).from_address(ptr.value), dtype=dtype).reshape(shape)
+            self._pinned = (view(a, C.c_int32, n, self._adtype, (n,)), view(o, C.c_float, n * D, np.float32, (n, D)),
+                            view(r, C.c_float, n, np.float32, (n,)), view(d, C.c_uint8, n, np.uint8, (n,)))
+        return self._pinned
+
+    def StepInto(self, actions, obs_out, reward_out, done_out):
+        """gymnet_vecenv_step with CALLER-OWNED buffers (what a C# host with long-lived NDArrays does): actions [N] of the
+        action dtype, obs_out float32 [N, D], reward_out float32 [N], done_out uint8 [N]; nothing is allocated."""
+        n = self.NumberOfEnvironments
+        if (actions.dtype != self._adtype or obs_out.dtype != np.float32 or reward_out.dtype != np.float32 or done_out.dtype != np.uint8
+                or actions.shape != (n,) or obs_out.shape != (n, self.ObsDim) or reward_out.shape != (n,) or done_out.shape != (n,)
+                or not (actions.flags.c_contiguous and obs_out.flags.c_contiguous and reward_out.flags.c_contiguous and done_out.flags.c_contiguous)):
+            raise ValueError("StepInto needs C-contiguous buffers of the exact dtypes and shapes")
+        capi.check(self._lib.gymnet_vecenv_step(self._h, _host(actions), _host(obs_out), _host(reward_out), _host(done_out)))
+
+    def ResetInto(self, obs_out):
+        if obs_out.dtype != np.float32 or obs_out.shape != (self.NumberOfEnvironments, self.ObsDim) or not obs_out.flags.c_contiguous:
+            raise ValueError("ResetInto needs a C-contiguous float32 [N, D] buffer")
+        capi.check(self._lib.gymnet_vecenv_reset(self._h, _host(obs_out)))
 
     def StepAsync(self, action):                                                     # VecEnv.cs:63-65
         if isinstance(action, enum.Enum):

@@ -200,6 +200,14 @@ int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions);
 /* step_wait(): block until the queued step finished and copy its results out.  Without a pending
  * gymnet_vecenv_step_async -> GYMNET_ERR_NOT_STEPPING. */
 int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
+/* ABI 3.  Library-owned HOST buffers for this path, for a caller that can keep its NDArrays over unmanaged memory: actions
+ * (int32 / float32 [num_envs]), obs (float32 [num_envs, obs_dim]), reward (float32 [num_envs]), done (uint8 [num_envs]) —
+ * page-locked and mapped into the device, valid until gymnet_vecenv_destroy, allocated on the first call.  When the pointers
+ * handed to gymnet_vecenv_step / _reset / _reset_where / _step_wait / _read ARE these buffers, the call runs without staging:
+ * the actions are DMA'd straight out of the pinned buffer and ONE kernel writes observations (row-major), rewards and done flags
+ * across PCIe into the others (no device-side pack buffer, no per-array memcpy).  Ordinary caller-owned memory keeps working
+ * (staged copies).  Any out pointer may be NULL. */
+int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, float **obs, float **reward, uint8_t **done);
 /* Copy the results of the most recent step/reset again (Step record, Step.cs:8-10). */
 int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
 

@@ -215,3 +215,31 @@ def test_batched_epsilon_greedy_composer(gpu_pkg, oracle):
             env.ComposeActionsDevice(policy, 1.5, out)
     with gpu_pkg.VectorEnv("Pendulum-v1", 8) as env, pytest.raises(NotImplementedError):
         env.ComposeActionsDevice(policy, 0.1, out)
+
+
+@pytest.mark.parametrize("name,n", [("CartPole-v1", 1 << 18), ("CartPole-v1", 1003), ("Pendulum-v1", 40_002), ("Acrobot-v1", 70_001),
+                                    ("MountainCar-v0", 4096)])
+def test_pinned_host_buffers_give_the_same_results_as_caller_memory(gpu_pkg, name, n):
+    """gymnet_vecenv_host_buffers (ABI 3): stepping through the library's page-locked, device-mapped buffers (one export kernel
+    writes obs / reward / done across PCIe) returns exactly what the staged path returns into ordinary memory — every env
+    (2-, 3-, 4- and 6-wide observations), batch sizes with ragged tails, small (host-mapped) and large batches, reset and async."""
+    rng = np.random.default_rng(3)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as a, gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as b:
+        pa, po, pr, pd = a.HostBuffers()
+        assert a.HostBuffers()[1] is po and po.shape == (n, a.ObsDim) and pd.dtype == np.uint8
+        a.ResetInto(po)
+        want = b.Reset()
+        assert np.array_equal(po, want)
+        for t in range(6):
+            act = rng.uniform(-2, 2, n).astype(np.float32) if name == "Pendulum-v1" else rng.integers(0, 3 if name != "CartPole-v1" else 2, n).astype(np.int32)
+            pa[:] = act
+            a.StepInto(pa, po, pr, pd)
+            out = b.Step(act)
+            assert np.array_equal(po, out.Observation) and np.array_equal(pr, out.Reward) and np.array_equal(pd.astype(bool), out.Done), t
+        # mixing is allowed: pinned actions, ordinary outputs (staged copies)
+        o2, r2, d2 = np.empty_like(po), np.empty_like(pr), np.empty_like(pd)
+        a.StepInto(pa, o2, r2, d2)
+        out = b.Step(np.array(pa))
+        assert np.array_equal(o2, out.Observation) and np.array_equal(r2, out.Reward)
+        with pytest.raises(ValueError):
+            a.StepInto(pa.astype(np.int64), po, pr, pd)

@@ -309,6 +309,27 @@ def test_plain_bench_gpus_2_spawns_its_own_ranks(gpu_pkg):
     g = j["with_obs_allgather"]                       # two ranks, HIP IPC peer buffers, hand-written push: the direct gather ran
     for k in ("direct_ipc", "direct_ipc_overlapped"):
         assert g[k].get("gathered_obs_finite_and_nonzero") is True and g[k]["value"] > 1e8, g
+    _check_multi_rank_evidence(j, 2)
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 1e6 and "after the other ranks had exited" in j["cpu_baseline"]["when"]
+
+
+def _check_multi_rank_evidence(j, world):
+    """What the first real multi-GPU lease must carry in ONE line: who ran where, proof that the collective
+    backend spans `world` ranks, each rank's own events-based step time, and the single-process gymnet_group_* leg."""
+    import torch
+    ranks = j["ranks"]
+    assert [e["rank"] for e in ranks] == list(range(world)) and len({e["pid"] for e in ranks}) == world
+    for e in ranks:
+        assert e["kernel"].startswith("step_kernel<CartPole") and 0.5 < e["events_us_per_step"] < 1e4 and e["name"]
+    c = j["collective"]
+    assert c["world_size"] == world and c["allreduce_sum_of_rank_plus_1"] == c["expected"] == world * (world + 1) // 2
+    assert c["is_rccl"] == (torch.cuda.device_count() >= world) and c["distinct_devices"] == min(world, torch.cuda.device_count())
+    g = j["group_single_process"]
+    assert g["members"] == world and g["real_multi_gpu"] == (torch.cuda.device_count() >= world)
+    assert g["step_only"]["value"] > 1e8
+    for k in ("direct", "direct_overlapped"):
+        assert g[k]["every_member_slice_arrived"] is True and g[k]["value"] > 1e8, g
+    assert ("skipped" in g["rccl"]) == (torch.cuda.device_count() < world)
 
 
 @pytest.mark.gpu
@@ -329,6 +350,7 @@ def test_bench_under_the_launcher_the_driver_uses(gpu_pkg):
     assert j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 5 and j["scaling"] == "weak" and j["value"] > 1e8
     import torch
     assert ("gloo" in j["config"]["backend"]) == (torch.cuda.device_count() < 2)
+    _check_multi_rank_evidence(j, 2)                 # the launcher form carries the same evidence (rank 0 starts the group leg)
 
 
 DIRECT_CHILD = r"""
