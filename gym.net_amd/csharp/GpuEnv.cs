@@ -1,0 +1,131 @@
+// GpuEnv.cs — the reference's SINGLE-INSTANCE environments (Env, src/Gym/Envs/Env.cs:13-41) on the HIP engine: a 1-lane handle
+// behind the same members, so the reference's own loops run unmodified with `new GpuCartPoleEnv()` in place of
+// `new CartPoleEnv(...)`:
+//     README.md:32-52                                       Reset(); Step(i % 2); if (done) Reset(); Close
+//     tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35   1000 x (Reset-if-done else Step(i % 2))
+// UNVERIFIED: never compiled (no .NET toolchain in the build image).  tests/test_host_api.py lexes it, checks every native
+// call against the header's arity, and that the four classes derive from Env and override every abstract member.
+//
+// What is NOT here: rendering (Render returns null — NullEnvViewer semantics; the viewers are out of scope) and the
+// float64 observation the reference actually returns (SURVEY F5): observations are float32, the DECLARED dtype of
+// ObservationSpace (CartPoleEnv.cs:48).
+using System;
+using System.Threading.Tasks;
+using Gym.Collections;
+using Gym.Observations;
+using Gym.Spaces;
+using NumSharp;
+using SixLabors.ImageSharp;
+
+namespace Gym.Envs.Amd {
+    /// Env (Env.cs:13-41) over ONE lane of the engine.  Reference-faithful mode: no auto-reset, so Step after done returns
+    /// reward 0 like CartPoleEnv.cs:176-183 (the console warning is a counter: gymnet_vecenv_counters).
+    public abstract unsafe class GpuEnv : Env {
+        private IntPtr _h;
+        private readonly int _obsDim;
+        private readonly bool _boxAction;
+        private readonly float[] _obs;                       // reused: one observation row
+        private readonly float[] _rew = new float[1];
+        private readonly byte[] _done = new byte[1];
+
+        /// maxEpisodeSteps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; the reference has none,
+        /// SURVEY F6): the step that reaches the limit returns Done = true with Information["TimeLimit.truncated"] = true.
+        protected GpuEnv(GymnetEnvId env, int device, ulong seed, int maxEpisodeSteps, bool validateActions) {
+            Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo info));
+            _obsDim = info.obs_dim; _boxAction = info.action_is_box != 0;
+            _obs = new float[_obsDim];
+            var lo = new float[_obsDim]; var hi = new float[_obsDim];
+            for (int k = 0; k < _obsDim; k++) { lo[k] = info.obs_low[k]; hi[k] = info.obs_high[k]; }
+            ObservationSpace = new Box(np.array(lo), np.array(hi), np.float32);                                   // CartPoleEnv.cs:46-48
+            ActionSpace = _boxAction ? (Space) new Box(info.action_low, info.action_high, new Shape(1), np.float32) : new Discrete(info.action_n);
+            Metadata = new Dict("render.modes", new[] {"human", "rgb_array"}, "video.frames_per_second", 50);     // CartPoleEnv.cs:51
+            RewardRange = (info.reward_low, info.reward_high);
+            GymnetFlags flags = GymnetFlags.None;
+            if (validateActions) flags |= GymnetFlags.ValidateActions;
+            if (maxEpisodeSteps > 0) flags |= GymnetFlags.EpisodeStats;
+            var cfg = new GymnetConfig {
+                struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = 1, lane_offset = 0,
+                device = device, flags = (uint) flags, seed = seed, max_episode_steps = maxEpisodeSteps
+            };
+            Native.Check(Native.gymnet_vecenv_create(ref cfg, out _h));
+        }
+
+        public override NDArray Reset() {                                                                         // CartPoleEnv.cs:63-67
+            fixed (float* p = _obs) Native.Check(Native.gymnet_vecenv_reset(_h, p));
+            return np.array((float[]) _obs.Clone());                                                              // a COPY, like :66
+        }
+
+        private Step Result() {
+            bool truncated = (_done[0] & 2) != 0;
+            Dict info = truncated ? new Dict("TimeLimit.truncated", true) : null;
+            return new Step(np.array((float[]) _obs.Clone()), _rew[0], _done[0] != 0, info);                      // Step.cs:15-20
+        }
+
+        /// One boxed action, cast like the reference: a Discrete env does `(int) action` (InvalidCastException for anything that
+        /// is not a boxed int, CartPoleEnv.cs:138); a Box env takes an NDArray, a float or an int (LunarLanderEnv.cs:581 idiom).
+        private void Stage(object action, int* ia, float* fa) {
+            if (_boxAction) {
+                if (action is NDArray nd) *fa = nd.astype(np.float32).GetSingle(0);
+                else *fa = Convert.ToSingle(action);
+            } else {
+                *ia = action is Enum ? (int) Convert.ChangeType(action, typeof(int)) : (int) action;
+            }
+        }
+
+        public override Step Step(object action) {                                                                // CartPoleEnv.cs:137-186
+            int ia = 0; float fa = 0f;
+            Stage(action, &ia, &fa);
+            fixed (float* po = _obs) fixed (float* pr = _rew) fixed (byte* pd = _done) {
+                if (_boxAction) Native.Check(Native.gymnet_vecenv_step(_h, &fa, po, pr, pd));
+                else Native.Check(Native.gymnet_vecenv_step(_h, &ia, po, pr, pd));
+            }
+            return Result();
+        }
+
+        /// Env.StepAsync (Env.cs:23-25) on the engine's own queue: the step is queued on the handle's stream before this
+        /// returns; the Task completes in gymnet_vecenv_step_wait.  A second StepAsync before the first finished throws the
+        /// reference's AlreadySteppingError (AlreadySteppingError.cs:8-10).
+        public override Task<Step> StepAsync(object action) {
+            int ia = 0; float fa = 0f;
+            Stage(action, &ia, &fa);
+            if (_boxAction) Native.Check(Native.gymnet_vecenv_step_async(_h, &fa));
+            else Native.Check(Native.gymnet_vecenv_step_async(_h, &ia));
+            return Task.Run(() => {
+                fixed (float* po = _obs) fixed (float* pr = _rew) fixed (byte* pd = _done)
+                    Native.Check(Native.gymnet_vecenv_step_wait(_h, po, pr, pd));
+                return Result();
+            });
+        }
+
+        public override Image Render(string mode = "human") => null;              // viewers are out of scope for the engine
+
+        public override void CloseEnvironment() {                                                                 // CartPoleEnv.cs:189-194
+            if (_h != IntPtr.Zero) { Native.gymnet_vecenv_destroy(_h); _h = IntPtr.Zero; }
+        }
+
+        public override void Seed(int seed) => Native.Check(Native.gymnet_vecenv_seed(_h, (ulong) seed));          // CartPoleEnv.cs:196-198
+    }
+
+    /// CartPoleEnv (src/Gym.Environments/Envs/Classic/CartPoleEnv.cs) on the GPU engine.  The viewer-delegate ctor argument of
+    /// the reference (CartPoleEnv.cs:54-61) has no counterpart: nothing is rendered.
+    public sealed class GpuCartPoleEnv : GpuEnv {
+        public GpuCartPoleEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
+            : base(GymnetEnvId.CartPole, device, seed, maxEpisodeSteps, validateActions) { }
+    }
+
+    /// Pendulum-v1 / MountainCar-v0 / Acrobot-v1: unchecked roadmap items of the reference (README.md:69-76), upstream gym semantics.
+    public sealed class GpuPendulumEnv : GpuEnv {
+        public GpuPendulumEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0)
+            : base(GymnetEnvId.Pendulum, device, seed, maxEpisodeSteps, false) { }
+    }
+
+    public sealed class GpuMountainCarEnv : GpuEnv {
+        public GpuMountainCarEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
+            : base(GymnetEnvId.MountainCar, device, seed, maxEpisodeSteps, validateActions) { }
+    }
+
+    public sealed class GpuAcrobotEnv : GpuEnv {
+        public GpuAcrobotEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
+            : base(GymnetEnvId.Acrobot, device, seed, maxEpisodeSteps, validateActions) { }
+    }
+}

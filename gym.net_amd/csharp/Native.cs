@@ -1,4 +1,4 @@
-// Native.cs — P/Invoke declarations for include/gymnet_amd.h (libgymnet_amd.so), ABI version 2.
+// Native.cs — P/Invoke declarations for include/gymnet_amd.h (libgymnet_amd.so), ABI version 3.
 // UNVERIFIED: no .NET toolchain exists in the build image, so this file has never been compiled.
 // It is the binding a Gym.NET maintainer would add next to src/Gym/Envs/VecEnv.cs.  What CAN be checked here is checked by
 // tests/test_host_api.py: one [DllImport] per header entry point (no exceptions), and every [StructLayout(Sequential)]

@@ -47,6 +47,9 @@ int fail(gymnet_vecenv *h, int status, const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     if (h) h->err = buf;
+    // HIP keeps the last error of the calling thread until somebody reads it, and the launchers end with `return
+    // hipGetLastError()`: a failure reported here must not make the NEXT (valid) launch on this thread fail too
+    (void)hipGetLastError();
     return status;
 }
 
@@ -141,6 +144,16 @@ void recompute_extras(gymnet_vecenv *h) {
 }  // namespace
 
 namespace gymnet {
+
+// Env.Seed(int) on a handle the caller has ENTERed
+int seed_handle(gymnet_vecenv *h, uint64_t seed) {
+    h->seed = seed;
+    h->tick = 0;
+    drop_graphs(h);   // the seed is a (frozen) kernel argument of captured launches
+    h->d_lane_seed = nullptr;   // back to one key for all lanes (d_lane_seed_buf is kept for the next Seed(int[]))
+    recompute_extras(h);
+    return write_tick(h);
+}
 
 // one vector step = one kernel launch; bumps the host mirrors of the device-side counters
 int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
@@ -579,12 +592,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 int gymnet_vecenv_seed(gymnet_vecenv *h, uint64_t seed) {
     return guarded([&]() -> int {
     ENTER(h);
-    h->seed = seed;
-    h->tick = 0;
-    drop_graphs(h);   // the seed is a (frozen) kernel argument of captured launches
-    h->d_lane_seed = nullptr;   // back to one key for all lanes (d_lane_seed_buf is kept for the next Seed(int[]))
-    recompute_extras(h);
-    return write_tick(h);
+    return seed_handle(h, seed);
     });
 }
 
@@ -595,6 +603,12 @@ int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t co
     if (count != h->n)   // VecEnv.cs:49
         return fail(h, GYMNET_ERR_INVALID_ARG, "Number of seeds passed should be equals to number of environments (%lld != %lld)",
                     (long long)count, (long long)h->n);
+    // VecEnv.Seed(int) reaches a VecEnv-typed caller's lanes as N EQUAL seeds (VecEnv.cs:44-46 -> Environments[i].Seed(seed)).
+    // With one key for every lane the per-lane-key kernel variant would compute exactly what the lean one does (the Philox
+    // counter carries the lane id either way) — only slower, and without the fused rollout.  So an all-equal vector IS Seed(int).
+    bool all_equal = true;
+    for (int64_t i = 1; i < count && all_equal; ++i) all_equal = seeds[i] == seeds[0];
+    if (all_equal) return seed_handle(h, seeds[0]);
     // one allocation, reused by every later Seed(int[]) (it used to grow by N*8 bytes per call); the stream is drained
     // first so no launch still in flight reads the keys being overwritten
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -84,13 +84,39 @@ struct gymnet_group {
 
 namespace {
 
+// Takes the busy flag of every member for the duration of a group call (released in reverse on exit): while the group
+// steps / gathers, a caller holding a borrowed member handle gets GYMNET_ERR_ALREADY_STEPPING instead of desynchronising
+// the group's buffer bookkeeping.
+struct MembersBusy {
+    gymnet_group *g;
+    size_t taken = 0;
+    bool ok = true;
+    explicit MembersBusy(gymnet_group *gg) : g(gg) {
+        for (auto *h : g->members) {
+            if (!h) { ++taken; continue; }
+            bool expect = false;
+            if (!h->busy.compare_exchange_strong(expect, true)) { ok = false; break; }
+            ++taken;
+        }
+        if (!ok) release();
+    }
+    void release() {
+        for (size_t m = 0; m < taken && m < g->members.size(); ++m) if (g->members[m]) g->members[m]->busy.store(false);
+        taken = 0;
+    }
+    ~MembersBusy() { release(); }
+};
+
 #define GROUP_ENTER(g)                                                                                         \
     if (!(g)) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null group");                                      \
     bool expect_ = false;                                                                                      \
     if (!(g)->busy.compare_exchange_strong(expect_, true))                                                     \
         return fail(nullptr, GYMNET_ERR_ALREADY_STEPPING, "group is in use by another call");                  \
     struct Release_ { gymnet_group *p; ~Release_() { p->busy.store(false); } } release_{g};                     \
-    DeviceScope dev_scope_
+    MembersBusy members_busy_(g);   /* a borrowed member handle (gymnet_group_member) cannot be stepped concurrently */ \
+    if (!members_busy_.ok) return fail(nullptr, GYMNET_ERR_ALREADY_STEPPING, "a member handle of this group is in use by another call"); \
+    DeviceScope dev_scope_;                                                                                    \
+    (void)hipGetLastError()
 
 #define RCCL_TRY(g, expr)                                                                                       \
     do {                                                                                                        \
@@ -185,7 +211,7 @@ void destroy_group(gymnet_group *g) {
     for (auto c : g->comms) if (c && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(c);
     for (auto *h : g->members) if (h) (void)gymnet_vecenv_destroy(h);
     for (int m = 0; m < g->G; ++m) {
-        if (m >= (int)g->devices.size()) break;
+        if (m >= (int)g->devices.size() || m >= (int)g->gstream.size()) break;   // nothing was created yet (e.g. a rejected ordinal)
         (void)hipSetDevice(g->devices[m]);
         for (int b = 0; b < 2; ++b) {
             if (m < (int)g->replica[b].size() && g->replica[b][m]) (void)hipFree(g->replica[b][m]);
@@ -194,7 +220,7 @@ void destroy_group(gymnet_group *g) {
         if (m < (int)g->ev_step.size() && g->ev_step[m]) (void)hipEventDestroy(g->ev_step[m]);
         if (m < (int)g->gstream.size() && g->gstream[m]) (void)hipStreamDestroy(g->gstream[m]);
     }
-    if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+    if (!g->devices.empty() && !g->gstream.empty()) (void)hipSetDevice(g->devices[0]);
     if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
     for (int b = 0; b < 2; ++b) if (g->ev_done[b]) (void)hipEventDestroy(g->ev_done[b]);
     if (g->join_stream) (void)hipStreamDestroy(g->join_stream);
@@ -440,7 +466,10 @@ int gymnet_group_member(gymnet_group *g, int32_t member, gymnet_vecenv **out) {
 int gymnet_group_seed(gymnet_group *g, uint64_t seed) {
     return guarded([&]() -> int {
     GROUP_ENTER(g);
-    for (auto *h : g->members) ST_TRY(gymnet_vecenv_seed(h, seed));
+    for (int m = 0; m < g->G; ++m) {            // members are held busy by GROUP_ENTER: the internal form, per device
+        HIP_TRY(nullptr, hipSetDevice(g->devices[m]));
+        ST_TRY(seed_handle(g->members[m], seed));
+    }
     return GYMNET_OK;
     });
 }

@@ -136,6 +136,7 @@ struct BusyGuard {
     ::gymnet::BusyGuard guard_(h);                                                                                 \
     if (!guard_.ok) return ::gymnet::fail(h, GYMNET_ERR_ALREADY_STEPPING, "handle is in use by another call");      \
     ::gymnet::DeviceScope dev_scope_;                                                                              \
+    (void)hipGetLastError();   /* a stale error left on this thread by anyone must not fail this call's launches */ \
     HIP_TRY(h, hipSetDevice((h)->device))
 
 // Nothing may throw across the C ABI: every entry point body runs inside this guard.
@@ -168,5 +169,6 @@ int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_
 // graph_mode: -1 = by batch size (replay only while launch-bound), 0 = eager launches, 1 = always replay a captured graph
 int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode = -1);
 int write_tick(gymnet_vecenv *h);
+int seed_handle(gymnet_vecenv *h, uint64_t seed);                    // Env.Seed(int): new key, tick 0, captured graphs dropped
 
 }  // namespace gymnet

@@ -64,6 +64,11 @@ def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_ob
 class ShardedVectorEnv:
     """This rank's shard of a global batch + the optional observation all-gather.
 
+    gather="direct" pushes this rank's slice into every peer's replica (HIP IPC peer buffers).  Its cross-process ordering is
+    stream synchronize -> `barrier` -> push -> stream synchronize -> `barrier`: `barrier` is any HOST barrier over the ranks
+    (default: the process group's) and is only ever called right after the main stream has been drained, so "every rank
+    passed the barrier" means every rank's queued readers of the old replicas have finished.
+
     overlap=True double-buffers the observation arrays (GYMNET_FLAG_DOUBLE_BUFFER): there are two gather buffers, step
     t+1 writes the other one while the all-gather of step t's buffer is still in flight on a side stream, so a
     consumer that wants every rank to see all observations pays max(step, gather) per step instead of step + gather.
@@ -245,6 +250,12 @@ class ShardedVectorEnv:
         if self.gather == "direct":
             tc = self._torch.cuda
             main = tc.current_stream(self.tensor_device)
+            # The barrier is a HOST barrier (`barrier` may be a shared-memory spin barrier or gloo): it says nothing about work
+            # still queued on this rank's stream — e.g. a policy kernel reading the replica a peer is about to push into.  So
+            # the stream is drained first: once every rank has passed the barrier, every rank's readers of the old slices have
+            # FINISHED (a cross-process write-after-read race otherwise).  Contract for a custom `barrier`: it is
+            # always called right after a stream synchronize.
+            main.synchronize()
             self._barrier()                                   # every rank is done reading the replicas about to be overwritten
             if overlap and self.overlap:
                 self._ev_step.record(main)

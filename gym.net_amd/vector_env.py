@@ -93,6 +93,8 @@ class VectorEnv:
                           d_ext_obs_alt=_ptr(ext_obs_alt))
         self._h = C.c_void_p()
         self._owns_handle = True
+        self._bookkeeping = bool(episode_stats or max_episode_steps)
+        self._lane_seeds = False
         capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
         self._describe(env_id, num_envs, auto_reset)
 
@@ -104,6 +106,7 @@ class VectorEnv:
         self._info = capi.env_describe(env_id)
         self._h = handle
         self._owns_handle = False
+        self._bookkeeping, self._lane_seeds = True, False     # a group member: flags unknown here, Checkpoint() refuses
         self._describe(env_id, num_envs, auto_reset)
         return self
 
@@ -152,9 +155,11 @@ class VectorEnv:
     def Seed(self, seed):                                                            # VecEnv.cs:44-53
         if isinstance(seed, (int, np.integer)):
             capi.check(self._lib.gymnet_vecenv_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+            self._lane_seeds = False
         else:
             s = np.ascontiguousarray(np.asarray(seed, dtype=np.int64).astype(np.uint64))
             capi.check(self._lib.gymnet_vecenv_seed_lanes(self._h, _host(s), s.shape[0]))
+            self._lane_seeds = True
 
     # ---- host-boundary path ---------------------------------------------------------------------
     def _outs(self):
@@ -376,9 +381,17 @@ class VectorEnv:
 
     # ---- checkpoint / resume (an extension: the reference has none; everything the engine needs to continue bit for bit) ----
     def Checkpoint(self):
-        """State SoA, engine tick (the Philox counter word) and, without auto-reset, steps_beyond_done.  Together with the
-        seed the caller already holds this determines every later step and reset draw: Restore() + the same actions
-        reproduce the continuation bit for bit (tests/test_gpu_cartpole.py::test_checkpoint_resume_is_bit_exact)."""
+        """State SoA, engine tick (the Philox counter word) and, without auto-reset, steps_beyond_done.  For a handle WITHOUT
+        episode bookkeeping (episode_stats / max_episode_steps) and without per-lane seeds, together with the seed the caller
+        already holds this determines every later step and reset draw: Restore() + the same actions reproduce the
+        continuation bit for bit (tests/test_gpu_cartpole.py::test_checkpoint_resume_is_bit_exact).  Other configurations
+        raise NotImplementedError rather than return a record that would not reproduce them.  (The done flags of the step
+        before the checkpoint are not part of it either: call ResetWhere() before Checkpoint(), not after Restore().)"""
+        if self._bookkeeping or self._lane_seeds:
+            # episode return / length (which drive max_episode_steps truncation), per-lane keys and the done flags ResetWhere(None)
+            # consumes are NOT in this record: a restored handle would truncate / draw differently (ADVICE r2)
+            raise NotImplementedError("Checkpoint() covers the plain configuration only: no episode_stats / max_episode_steps, "
+                                      "no Seed(int[]) keys")
         ck = {"env_id": self.EnvId, "num_envs": self.NumberOfEnvironments, "state": self.GetState(), "tick": self.Tick}
         if not self.AutoReset and self.EnvId == capi.ENV_CARTPOLE:
             ck["steps_beyond_done"] = self.GetStepsBeyondDone()

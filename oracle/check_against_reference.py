@@ -88,6 +88,32 @@ def restatement_step(text):
     return stmts, tokens(re.sub(r"[{};]", " ", machine), C_RENAME)
 
 
+def _arith(expr):
+    """Value (binary64) of a constant arithmetic expression taken from the reference text: numeric literals, Math.PI,
+    + - * /, unary minus and parentheses — and NOTHING else.  The text is untrusted public content, so it is never
+    handed to eval(): it is parsed and walked, and any other construct (a name, a call, an attribute, a subscript ...)
+    raises."""
+    import ast
+    import operator
+    ops = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv}
+    tree = ast.parse(expr.strip().replace("Math.PI", "PI"), mode="eval")
+
+    def walk(node):
+        if isinstance(node, ast.Expression):
+            return walk(node.body)
+        if isinstance(node, ast.Constant) and type(node.value) in (int, float):
+            return float(node.value)
+        if isinstance(node, ast.Name) and node.id == "PI":
+            return float(np.pi)
+        if isinstance(node, ast.BinOp) and type(node.op) in ops:
+            return ops[type(node.op)](walk(node.left), walk(node.right))
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            v = walk(node.operand)
+            return -v if isinstance(node.op, ast.USub) else v
+        raise ValueError(f"unsupported construct in a constant initialiser: {ast.dump(node)[:80]}")
+    return walk(tree)
+
+
 def reference_constants(text):
     """The C# `const float` initialisers evaluated in binary32 (C# folds float-typed constant expressions in float)."""
     text = strip_comments(text)
@@ -95,8 +121,7 @@ def reference_constants(text):
     for name, expr in re.findall(r"private const float (\w+) = ([^;]+);", text):
         e = expr.strip()
         if e.startswith("(float)"):                           # (float) (12 * 2 * Math.PI / 360): double arithmetic, one cast
-            inner = e[len("(float)"):].replace("Math.PI", repr(np.pi))
-            vals[name] = np.float32(eval(inner, {"__builtins__": {}}))
+            vals[name] = np.float32(_arith(e[len("(float)"):]))
             continue
         toks = tokens(e, {})
         acc, op = None, None

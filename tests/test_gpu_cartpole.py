@@ -582,3 +582,33 @@ def test_checkpoint_resume_is_bit_exact(gpu_pkg, name, auto):
     for x, y in zip(tail_a, tail_b):
         assert np.array_equal(x.Observation, y.Observation) and np.array_equal(x.Reward, y.Reward) and np.array_equal(x.Done, y.Done)
     assert name != "CartPole-v1" or any(x.Done.any() for x in tail_a)       # random-action Acrobot does not finish in 90 steps
+
+
+def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg):
+    """VecEnv.Seed(int) reaches a VecEnv-typed C# caller's lanes as N equal seeds (VecEnv.cs:44-46 walks Environments); round 2
+    turned that into the per-lane-key kernel variant (slower, no fused rollout) although it computes the same bits.  An
+    all-equal vector now IS Seed(int): same kernel, same draws, fused rollout available; a genuinely per-lane vector still
+    selects the keyed variant."""
+    import torch
+    n = 6000
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 2, (30, n)).astype(np.int32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as a, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as b:
+        lean = a.KernelName()
+        assert ",false," in lean
+        a.Seed(7)
+        b.Seed([7] * n)                                     # gymnet_vecenv_seed_lanes with N equal keys
+        assert b.KernelName() == lean == a.KernelName()
+        assert np.array_equal(a.Reset(), b.Reset())
+        for t in range(30):
+            x, y = a.Step(acts[t]), b.Step(acts[t])
+            assert np.array_equal(x.Observation, y.Observation) and np.array_equal(x.Done, y.Done)
+        d = torch.from_numpy(acts[:4]).cuda().contiguous()
+        b.RolloutFusedDevice(d, 8, n, 4); a.RolloutFusedDevice(d, 8, n, 4)    # GYMNET_ERR_UNSUPPORTED in round 2
+        assert np.array_equal(a.GetState(), b.GetState())
+        b.Seed(np.arange(n))                                # per-lane keys: the keyed (EXTRAS) variant, fused rollout refused
+        assert ",true," in b.KernelName().split("<")[1].split(",", 3)[3]
+        with pytest.raises(NotImplementedError):
+            b.RolloutFusedDevice(d, 8, n, 4)
+        b.Seed(np.full(n, 7))                               # and back
+        assert b.KernelName() == lean

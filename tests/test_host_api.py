@@ -200,7 +200,7 @@ CS_STRUCT_OF = {"gymnet_config": "GymnetConfig", "gymnet_env_info": "GymnetEnvIn
 
 
 def _csharp_sources():
-    return {f: open(os.path.join(ROOT, "gym.net_amd", "csharp", f)).read() for f in ("Native.cs", "VectorEnv.cs")}
+    return {f: open(os.path.join(ROOT, "gym.net_amd", "csharp", f)).read() for f in ("Native.cs", "VectorEnv.cs", "GpuEnv.cs")}
 
 
 def _cs_struct_layout(text, name):
@@ -245,7 +245,7 @@ def test_csharp_binding_sources_lex_cleanly_and_cover_the_header():
     assert declared - imported == set(), sorted(declared - imported)
     assert imported - declared == set(), sorted(imported - declared)
     # every native call the managed wrapper makes is one of the declared imports
-    used = set(re.findall(r"Native\.(gymnet_[a-z_0-9]+)\(", srcs["VectorEnv.cs"]))
+    used = set(re.findall(r"Native\.(gymnet_[a-z_0-9]+)\(", srcs["VectorEnv.cs"] + srcs["GpuEnv.cs"]))
     assert used and used <= imported, sorted(used - imported)
     man = abi_manifest()
     for cname, csname in CS_STRUCT_OF.items():
@@ -302,7 +302,7 @@ def test_csharp_imports_and_call_sites_have_the_headers_arity():
     assert cs_arity.keys() == c_arity.keys()
     wrong = {k: (cs_arity[k], c_arity[k]) for k in c_arity if cs_arity[k] != c_arity[k]}
     assert not wrong, wrong
-    managed = re.sub(r"//.*", "", srcs["VectorEnv.cs"])
+    managed = re.sub(r"//.*", "", srcs["VectorEnv.cs"] + srcs["GpuEnv.cs"])
     calls = 0
     for m in re.finditer(r"Native\.(gymnet_[a-z_0-9]+)\(", managed):
         got = len(_split_args(_call_args(managed, m.end() - 1)))
@@ -364,6 +364,30 @@ def test_csharp_vectorenv_is_a_drop_in_through_the_reference_interface():
         vec = open("/root/reference/src/Gym/Envs/VecEnv.cs", encoding="utf-8-sig").read()
         assert "public void Seed(int seed)" in vec and "public void Seed(int[] seed)" in vec            # non-virtual: cannot be overridden
         assert "public Task<Step[]> StepAsync(int action)" in vec and "public IList<IEnv> Environments { get; set; }" in vec
+
+
+def test_csharp_single_instance_envs_derive_from_env_and_override_every_abstract_member():
+    """SURVEY §8(f)-3 / VERDICT r2: `GpuCartPoleEnv : Env` (+ Pendulum / MountainCar / Acrobot) over a 1-lane handle, so that the
+    reference's README loop (README.md:32-52) has a C# drop-in.  Source-text checks (no .NET here): the base derives from Env,
+    overrides exactly the abstract members Env declares (Env.cs:20-30) plus the virtual StepAsync on the native async pair,
+    returns a COPY from Reset like CartPoleEnv.cs:66, casts a Discrete action with `(int) action` (InvalidCastException like
+    :138), and the optional TimeLimit reports truncation through Step.Information."""
+    code = re.sub(r"//.*", "", _csharp_sources()["GpuEnv.cs"])
+    assert re.search(r"public abstract unsafe class GpuEnv\s*:\s*Env\s*\{", code)
+    for cls, env in (("GpuCartPoleEnv", "CartPole"), ("GpuPendulumEnv", "Pendulum"), ("GpuMountainCarEnv", "MountainCar"), ("GpuAcrobotEnv", "Acrobot")):
+        assert re.search(r"public sealed class %s\s*:\s*GpuEnv\s*\{[^}]*base\(GymnetEnvId\.%s," % (cls, env), code), cls
+    overrides = set(re.findall(r"public override ([\w<>\[\]]+ \w+)\(", code))
+    assert overrides == {"NDArray Reset", "Step Step", "Task<Step> StepAsync", "Image Render", "void CloseEnvironment", "void Seed"}
+    assert "(int) action" in code and ".Clone()" in code and "TimeLimit.truncated" in code and "max_episode_steps = maxEpisodeSteps" in code
+    sa = code[code.index("public override Task<Step> StepAsync"):code.index("public override Image Render")]
+    assert "gymnet_vecenv_step_async" in sa and "gymnet_vecenv_step_wait" in sa and "DistributedScheduler" not in sa
+    ref = "/root/reference/src/Gym/Envs/Env.cs"
+    if os.path.exists(ref):                                      # the abstract members really are these (build container only)
+        text = open(ref, encoding="utf-8-sig").read()
+        text = text[:text.index("public abstract class Env<TAction>")]
+        abstract = set(re.findall(r"public abstract ([\w<>\[\]]+ \w+)\(", text))
+        assert abstract == {"NDArray Reset", "Step Step", "Image Render", "void CloseEnvironment", "void Seed"}, abstract
+        assert "public virtual Task<Step> StepAsync(object action)" in text
 
 
 def test_mirror_exposes_the_reference_member_names(gymnet):

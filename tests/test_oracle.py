@@ -377,3 +377,21 @@ def test_restatement_token_stream_equals_the_reference_text():
         assert a in c
         got, _ = chk.restatement_step(c.replace(a, b))
         assert [v for v in chk.STEP_VARS if want[v] != got[v]] == [var], (a, b)
+
+
+def test_reference_constant_initialisers_are_parsed_not_evaluated():
+    """the text under /root/reference is untrusted, so the `(float)(...)` initialisers are walked as an AST of
+    literals, Math.PI, + - * / and parentheses — nothing else is accepted, in particular nothing eval() would run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_against_reference", os.path.join(ROOT, "oracle", "check_against_reference.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    assert chk._arith("(12 * 2 * Math.PI / 360)") == 12 * 2 * np.pi / 360
+    assert chk._arith("-(1 + 2) * 0.5") == -1.5
+    got = chk.reference_constants("private const float a = 0.1f; private const float b = a * 0.5f; private const float c = (float) (12 * 2 * Math.PI / 360);")
+    assert got["b"] == np.float32(0.1) * np.float32(0.5) and got["c"] == np.float32(12 * 2 * np.pi / 360)
+    for hostile in ("().__class__.__base__.__subclasses__()", "__import__('os').system('true')", "[1][0]", "(lambda: 1)()", "x + 1",
+                    "Math.E", "1 if 1 else 2", "2 ** 3"):
+        with pytest.raises((ValueError, SyntaxError)):
+            chk._arith(hostile)
+    assert "eval(" not in open(os.path.join(ROOT, "oracle", "check_against_reference.py")).read().replace("to eval()", "")
