@@ -136,6 +136,8 @@ PROTOTYPES = {
     "gymnet_vecenv_done_lanes_device": (C.c_int, [_H, _P, _P]),
     "gymnet_vecenv_episode_stats": (C.c_int, [_H, _P, _P]),
     "gymnet_vecenv_final_obs": (C.c_int, [_H, _P]),
+    "gymnet_vecenv_done_records": (C.c_int, [_H, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "gymnet_vecenv_done_records_device": (C.c_int, [_H, _P, _P, _P, _P, C.c_int64, _P]),
     "gymnet_sample_discrete_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32,
                                                 C.c_uint64, C.c_uint64, C.c_uint64]),
     "gymnet_sample_discrete_masked_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64,

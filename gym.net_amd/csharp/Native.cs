@@ -120,6 +120,8 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes_device(IntPtr h, IntPtr d_lanes_out, IntPtr d_count_out);
         [DllImport(Lib)] public static extern int gymnet_vecenv_episode_stats(IntPtr h, float* finished_return, int* finished_length);
         [DllImport(Lib)] public static extern int gymnet_vecenv_final_obs(IntPtr h, float* final_obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_done_records(IntPtr h, int* lanes_out, float* return_out, int* length_out, float* final_obs_out, long capacity, out long count);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_done_records_device(IntPtr h, IntPtr d_lanes, IntPtr d_return, IntPtr d_length, IntPtr d_final_obs, long capacity, IntPtr d_count);
 
         // ---- batched space sampling
         [DllImport(Lib)] public static extern int gymnet_sample_discrete_device(int device, IntPtr stream, IntPtr d_out, long count, int n, int start, ulong seed, ulong lane_offset, ulong tick);

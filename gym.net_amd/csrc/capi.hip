@@ -104,6 +104,7 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.done_count2 = h->d_done_count2;
     a.done_cap = h->done_cap;
     a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
+    a.rec_ret = h->d_rec_ret; a.rec_len = h->d_rec_len; a.rec_obs = h->d_rec_obs;
     a.lane_seed = h->d_lane_seed;
     a.after_done = h->d_after_done;
     a.n = h->n; a.state_stride = h->sstride; a.obs_stride = h->ostride;
@@ -123,10 +124,18 @@ void swap_buffers(gymnet_vecenv *h) {
     h->cur ^= 1;
 }
 
-// gathers the sharded done list of the most recent step into one compact list (stream-ordered, non-blocking)
-int compact_done(gymnet_vecenv *h, int32_t *d_out, uint32_t *d_count) {
-    const uint32_t *counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
-    HIP_TRY(h, launch_compact_done(counts, h->d_done_list, h->done_cap, d_out, d_count, h->stream));
+// Gathers the sharded done list of the most recent step — and the records written beside it — into compact arrays
+// (stream-ordered, non-blocking); with `dense`, also applies the records to the dense per-lane arrays.  NULL outputs are skipped.
+int compact_done(gymnet_vecenv *h, int32_t *d_list, float *d_ret, int32_t *d_len, float *d_obs, int64_t capacity, uint32_t *d_count,
+                 bool dense = false) {
+    CompactArgs c{};
+    c.counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
+    c.list = h->d_done_list; c.cap = h->done_cap;
+    c.rec_ret = h->d_rec_ret; c.rec_len = h->d_rec_len; c.rec_obs = h->d_rec_obs; c.obs_dim = h->desc->obs_dim;
+    c.out_list = d_list; c.out_ret = d_ret; c.out_len = d_len; c.out_obs = d_obs; c.out_capacity = capacity; c.out_count = d_count;
+    if (dense) { c.dense_ret = h->d_rec_ret ? h->d_fin_ret : nullptr; c.dense_len = h->d_fin_len; c.dense_obs = h->d_rec_obs ? h->d_final_obs : nullptr; }
+    c.n = h->n;
+    HIP_TRY(h, launch_compact_done(c, h->stream));
     return GYMNET_OK;
 }
 
@@ -520,6 +529,12 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         CREATE_HIP(hipMemsetAsync(h->d_done_count2, 0, (size_t)2 * kShards * kCountStride * sizeof(uint32_t), h->stream));
         CREATE_HIP(hipMemsetAsync(h->d_done_total, 0, sizeof(uint32_t), h->stream));
     }
+    if ((cfg->flags & GYMNET_FLAG_DONE_LIST) && (cfg->flags & GYMNET_FLAG_EPISODE_STATS)) {
+        CREATE_TRY(dalloc(h, &h->d_rec_ret, (size_t)kShards * (size_t)h->done_cap));
+        CREATE_TRY(dalloc(h, &h->d_rec_len, (size_t)kShards * (size_t)h->done_cap));
+    }
+    if ((cfg->flags & GYMNET_FLAG_DONE_LIST) && (cfg->flags & GYMNET_FLAG_FINAL_OBS))
+        CREATE_TRY(dalloc(h, &h->d_rec_obs, (size_t)kShards * (size_t)h->done_cap * d.obs_dim));
     if (cfg->flags & GYMNET_FLAG_EPISODE_STATS) {
         CREATE_TRY(dalloc(h, &h->d_ep_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_ep_len, (size_t)padded));
         CREATE_TRY(dalloc(h, &h->d_fin_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_fin_len, (size_t)padded));
@@ -943,7 +958,7 @@ int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capac
     if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
     if (!count || capacity < 0 || (capacity > 0 && !lanes_out)) return fail(h, GYMNET_ERR_INVALID_ARG, "bad count/capacity/lanes_out");
     if (h->last_cparity < 0) { *count = 0; return GYMNET_OK; }
-    ST_TRY(compact_done(h, h->d_done_compact, h->d_done_total));
+    ST_TRY(compact_done(h, h->d_done_compact, nullptr, nullptr, nullptr, h->padded, h->d_done_total));
     uint32_t c32 = 0;
     HIP_TRY(h, hipMemcpyAsync(&c32, h->d_done_total, sizeof c32, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -961,7 +976,50 @@ int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint
     if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
     if (!d_count_out) return fail(h, GYMNET_ERR_INVALID_ARG, "d_count_out is null");
     if (h->last_cparity < 0) { HIP_TRY(h, hipMemsetAsync(d_count_out, 0, sizeof(uint32_t), h->stream)); return GYMNET_OK; }
-    return compact_done(h, d_lanes_out ? d_lanes_out : h->d_done_compact, d_count_out);
+    return compact_done(h, d_lanes_out ? d_lanes_out : h->d_done_compact, nullptr, nullptr, nullptr, h->padded, d_count_out);
+    });
+}
+
+int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, float *d_final_obs,
+                                      int64_t capacity, uint32_t *d_count) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
+    if (capacity < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "capacity < 0");
+    if ((d_return || d_length) && !h->d_rec_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "episode records need GYMNET_FLAG_EPISODE_STATS");
+    if (d_final_obs && !h->d_rec_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "terminal observations need GYMNET_FLAG_FINAL_OBS");
+    if (h->last_cparity < 0) { if (d_count) HIP_TRY(h, hipMemsetAsync(d_count, 0, sizeof(uint32_t), h->stream)); return GYMNET_OK; }
+    return compact_done(h, d_lanes, d_return, d_length, d_final_obs, capacity, d_count);
+    });
+}
+
+int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, float *final_obs_out,
+                               int64_t capacity, int64_t *count) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!h->d_done_list) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_DONE_LIST");
+    if (!count || capacity < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad count/capacity");
+    if ((return_out || length_out) && !h->d_rec_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "episode records need GYMNET_FLAG_EPISODE_STATS");
+    if (final_obs_out && !h->d_rec_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "terminal observations need GYMNET_FLAG_FINAL_OBS");
+    if (h->last_cparity < 0) { *count = 0; return GYMNET_OK; }
+    const int O = h->desc->obs_dim;
+    if ((return_out || length_out) && !h->d_rec_ret_c) { ST_TRY(dalloc(h, &h->d_rec_ret_c, (size_t)h->padded)); ST_TRY(dalloc(h, &h->d_rec_len_c, (size_t)h->padded)); }
+    if (final_obs_out && !h->d_rec_obs_c) ST_TRY(dalloc(h, &h->d_rec_obs_c, (size_t)h->padded * O));
+    ST_TRY(compact_done(h, h->d_done_compact, (return_out || length_out) ? h->d_rec_ret_c : nullptr, (return_out || length_out) ? h->d_rec_len_c : nullptr,
+                        final_obs_out ? h->d_rec_obs_c : nullptr, h->padded, h->d_done_total));
+    uint32_t c32 = 0;
+    HIP_TRY(h, hipMemcpyAsync(&c32, h->d_done_total, sizeof c32, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *count = (int64_t)c32;
+    const size_t m = (size_t)((int64_t)c32 < capacity ? (int64_t)c32 : capacity);
+    if (m > 0) {
+        if (lanes_out) HIP_TRY(h, hipMemcpyAsync(lanes_out, h->d_done_compact, m * 4, hipMemcpyDeviceToHost, h->stream));
+        if (return_out) HIP_TRY(h, hipMemcpyAsync(return_out, h->d_rec_ret_c, m * 4, hipMemcpyDeviceToHost, h->stream));
+        if (length_out) HIP_TRY(h, hipMemcpyAsync(length_out, h->d_rec_len_c, m * 4, hipMemcpyDeviceToHost, h->stream));
+        if (final_obs_out) HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_rec_obs_c, m * O * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return GYMNET_OK;
     });
 }
 
@@ -969,6 +1027,8 @@ int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_
     return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_fin_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_EPISODE_STATS");
+    // with a done list the step writes compact records only: bring the dense view up to date for the most recent step
+    if (h->d_rec_ret && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
     if (finished_return) HIP_TRY(h, hipMemcpyAsync(finished_return, h->d_fin_ret, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     if (finished_length) HIP_TRY(h, hipMemcpyAsync(finished_length, h->d_fin_len, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -981,6 +1041,7 @@ int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
     ENTER(h);
     if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
     if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
+    if (h->d_rec_obs && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
     ST_TRY(ensure_staging(h, false, true, false));
     HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_final_obs, h->n, h->d_pack, h->n, h->stream));
     HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));

@@ -66,6 +66,9 @@ struct gymnet_vecenv {
     int64_t done_cap = 0;
     float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
     int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
+    // compact per-step records beside the sharded done list (DONE_LIST + EPISODE_STATS / FINAL_OBS), and their gathered copies
+    float *d_rec_ret = nullptr, *d_rec_obs = nullptr, *d_rec_ret_c = nullptr, *d_rec_obs_c = nullptr;
+    int32_t *d_rec_len = nullptr, *d_rec_len_c = nullptr;
     uint64_t *d_lane_seed = nullptr;       // active per-lane keys (NULL = one key for all lanes)
     uint64_t *d_lane_seed_buf = nullptr;   // the one allocation Seed(int[]) reuses
     unsigned long long *d_after_done = nullptr;

@@ -274,7 +274,8 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, float (&s)[Env::
     }
 }
 
-// Wave-compacted form of the fused auto-reset (RESETF = 1; envs whose observation aliases the state, VEC > 1).
+// Wave-compacted form of the fused auto-reset (RESETF = 1; envs whose observation aliases the state, dwordx4 lanes; lean and
+// bookkeeping variants alike).
 // reset_pending() above makes every wave pay max-over-lanes Philox passes (1.6 on average for CartPole) with ~3 of 64 lanes
 // active in each.  Here the wave's finished (lane, sub-lane) slots — 11.5 on average at 2^20 CartPole lanes — are ranked by
 // ballot + mbcnt, handed to the FIRST `total` lanes through a wave-private LDS table, drawn in ONE Philox pass with those
@@ -391,12 +392,16 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
     typename Env::Action (&act)[VEC] = in.act;
     int32_t (&sbd)[VEC] = in.sbd;
 
-    float ep_ret[VEC];
-    int32_t ep_len[VEC];
+    constexpr bool NT_SL = (NT & 1) != 0;
+    float ep_ret[VEC], fin_ret[VEC];
+    int32_t ep_len[VEC], fin_len[VEC];
     bool stats = false;
     if constexpr (EXTRAS) {
         stats = a.ep_ret != nullptr;
-        if (stats) { load_f32<VEC, false, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, false, GUARD>(a.ep_len, i0, n, ep_len); }
+        // running return / length: read-modify-write streams like the state, same non-temporal policy
+        if (stats) { load_f32<VEC, NT_SL, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, NT_SL, GUARD>(a.ep_len, i0, n, ep_len); }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { fin_ret[j] = 0.0f; fin_len[j] = 0; }
     }
 
     float reward[VEC];
@@ -429,13 +434,16 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
         reward[j] = rw;
 
         if constexpr (EXTRAS) {
-            if (fin && a.final_obs && (!GUARD || i0 + j < n)) {
+            // Without a done list the finished lanes' records go to the dense per-lane arrays (scattered 4-byte stores, one
+            // cache line each).  With one (below) they are written COMPACTED at the lane's position in the list instead.
+            if (!a.done_list && fin && a.final_obs && (!GUARD || i0 + j < n)) {
 #pragma unroll
                 for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
             }
             if (stats && fin && (!GUARD || i0 + j < n)) {
-                a.fin_ret[i0 + j] = ep_ret[j];
-                a.fin_len[i0 + j] = ep_len[j];
+                fin_ret[j] = ep_ret[j];
+                fin_len[j] = ep_len[j];
+                if (!a.done_list) { a.fin_ret[i0 + j] = ep_ret[j]; a.fin_len[i0 + j] = ep_len[j]; }
                 if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
             }
         }
@@ -448,6 +456,46 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
     // reward / done do not depend on the reset draw: get them on their way before the Philox rounds
     store_f32<VEC, NT_O, GUARD>(a.reward, i0, n, reward);
     store_u8<VEC, NT_O, GUARD>(a.done, i0, n, done);
+
+    if constexpr (EXTRAS) {
+        if (a.done_list) {
+            // wave64 compaction (before the reset overwrites the terminal state): ballot per sub-lane, one atomic per wave into
+            // the wave's shard, order inside the list unspecified.  Everything known about a finished lane is written at ITS
+            // POSITION in the list — lane id, and with the corresponding flags its episode return / length and its terminal
+            // observation: a wave's ~11 finished lanes write one or two contiguous cache lines per array instead of one
+            // scattered line each (compacted (lane, return, length) records, BasePlaySession.cs:58-69).
+            const uint32_t lane = lane_id();
+            uint32_t off[VEC];
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint64_t m = __ballot(finished[j]);
+                off[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                total += (uint32_t)__popcll(m);
+            }
+            if (total) {   // wave-uniform
+                const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+                const uint32_t shard = wave_shard();
+                uint32_t base = 0;
+                if ((int)lane == leader)
+                    base = atomicAdd(&a.done_count2[a.cparity * (kShards * kCountStride) + shard * kCountStride], total);
+                base = __shfl(base, leader);
+                const int64_t seg0 = (int64_t)shard * a.done_cap;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (!finished[j]) continue;
+                    const int64_t pos = seg0 + base + off[j];
+                    a.done_list[pos] = (int32_t)(i0 + j);
+                    if (stats) { a.rec_ret[pos] = fin_ret[j]; a.rec_len[pos] = fin_len[j]; }
+                    if (a.rec_obs) {
+#pragma unroll
+                        for (int k = 0; k < O; ++k)
+                            a.rec_obs[((int64_t)shard * O + k) * a.done_cap + base + off[j]] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
+                    }
+                }
+            }
+        }
+    }
 
     if constexpr (AUTORESET && RESETF == 1) reset_pending_wave<Env, VEC, EXTRAS>(pending, s, a, i0, n, tick, sc);
     else if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick);
@@ -462,32 +510,7 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
     if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, NT_SS, GUARD>(a.sbd, i0, n, sbd);
 
     if constexpr (EXTRAS) {
-        if (stats) { store_f32<VEC, false, GUARD>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, false, GUARD>(a.ep_len, i0, n, ep_len); }
-        if (a.done_list) {
-            // wave64 compaction: ballot per sub-lane, one atomic per wave, order inside the list is unspecified
-            const uint32_t lane = lane_id();
-            const uint64_t below = (1ull << lane) - 1ull;
-            uint32_t off[VEC];
-            uint32_t total = 0;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const uint64_t m = __ballot(finished[j]);
-                off[j] = total + (uint32_t)__popcll(m & below);
-                total += (uint32_t)__popcll(m);
-            }
-            if (total) {   // wave-uniform
-                const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
-                const uint32_t shard = wave_shard();
-                uint32_t base = 0;
-                if ((int)lane == leader)
-                    base = atomicAdd(&a.done_count2[a.cparity * (kShards * kCountStride) + shard * kCountStride], total);
-                base = __shfl(base, leader);
-                int32_t *seg = a.done_list + (int64_t)shard * a.done_cap;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    if (finished[j]) seg[base + off[j]] = (int32_t)(i0 + j);
-            }
-        }
+        if (stats) { store_f32<VEC, NT_SS, GUARD>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, NT_SS, GUARD>(a.ep_len, i0, n, ep_len); }
     }
 }
 
@@ -799,13 +822,13 @@ __global__ __launch_bounds__(256) void pack_obs_kernel(const float *__restrict__
     }
 }
 
-// Gathers the kShards segments of one step's done list into one compact list.  One workgroup per shard; every
-// workgroup recomputes the (tiny) exclusive scan of the 256 shard counts in LDS, then copies its segment coalesced.
-__global__ __launch_bounds__(256) void compact_done_kernel(const uint32_t *__restrict__ counts, const int32_t *__restrict__ list,
-                                                           int64_t cap, int32_t *__restrict__ out, uint32_t *out_count) {
+// Gathers the kShards segments of one step's done list — and of the records written beside it — into compact arrays, and /
+// or applies the records to the dense per-lane arrays (the "last finished episode of every lane" view).  One workgroup per
+// shard; every workgroup recomputes the (tiny) exclusive scan of the 256 shard counts in LDS, then copies its segment coalesced.
+__global__ __launch_bounds__(256) void compact_done_kernel(const CompactArgs a) {
     __shared__ uint32_t scan[kShards];
     const int t = threadIdx.x;
-    const uint32_t mine = counts[t * kCountStride];
+    const uint32_t mine = a.counts[t * kCountStride];
     scan[t] = mine;
     __syncthreads();
     for (int d = 1; d < kShards; d <<= 1) {            // Hillis-Steele inclusive scan, 8 rounds
@@ -815,11 +838,31 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const uint32_t *__res
         __syncthreads();
     }
     const int shard = blockIdx.x;
-    const uint32_t cnt = counts[shard * kCountStride];
+    const uint32_t cnt = a.counts[shard * kCountStride];
     const uint32_t start = scan[shard] - cnt;
-    if (shard == 0 && t == 0) *out_count = scan[kShards - 1];
-    const int32_t *seg = list + (int64_t)shard * cap;
-    for (uint32_t k = t; k < cnt; k += 256) out[start + k] = seg[k];
+    if (shard == 0 && t == 0 && a.out_count) *a.out_count = scan[kShards - 1];
+    const int64_t seg0 = (int64_t)shard * a.cap;
+    const int O = a.obs_dim;
+    for (uint32_t k = t; k < cnt; k += 256) {
+        const int32_t lane = a.list[seg0 + k];
+        const uint32_t dst = start + k;
+        const bool fits = (int64_t)dst < a.out_capacity;
+        if (a.out_list && fits) a.out_list[dst] = lane;
+        if (a.rec_ret) {
+            const float r = a.rec_ret[seg0 + k];
+            const int32_t l = a.rec_len[seg0 + k];
+            if (a.out_ret && fits) a.out_ret[dst] = r;
+            if (a.out_len && fits) a.out_len[dst] = l;
+            if (a.dense_ret) { a.dense_ret[lane] = r; a.dense_len[lane] = l; }
+        }
+        if (a.rec_obs) {
+            for (int c = 0; c < O; ++c) {
+                const float v = a.rec_obs[((int64_t)shard * O + c) * a.cap + k];
+                if (a.out_obs && fits) a.out_obs[(int64_t)dst * O + c] = v;
+                if (a.dense_obs) a.dense_obs[(int64_t)c * a.n + lane] = v;
+            }
+        }
+    }
 }
 
 template <int O>
@@ -1003,7 +1046,7 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
     // (Acrobot) — two lanes per thread on dwordx2 streams
     if (cfg.vec > 1) v.vec = Env::PACKED2 ? 2 : 4;
     // wave-compacted fused reset: lean dwordx4 variant of an env whose observation IS its state
-    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec == 4 && autoreset && !extras) v.resetf = 1;
+    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec == 4 && autoreset) v.resetf = 1;
     return v;
 }
 
@@ -1040,9 +1083,14 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a
     } while (0)
     if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2) {
         if (v.resetf == 1) {
-            if (v.nt == 15) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 15, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
-            else if (v.nt == 12) hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 12, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
-            else hipLaunchKernelGGL((step_kernel<Env, 4, true, false, 0, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);
+#define GYMNET_LAUNCH_RF(EX)                                                                                                          \
+    do {                                                                                                                              \
+        if (v.nt == 15) hipLaunchKernelGGL((step_kernel<Env, 4, true, EX, 15, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);           \
+        else if (v.nt == 12) hipLaunchKernelGGL((step_kernel<Env, 4, true, EX, 12, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);      \
+        else hipLaunchKernelGGL((step_kernel<Env, 4, true, EX, 0, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);                       \
+    } while (0)
+            if (extras) GYMNET_LAUNCH_RF(true); else GYMNET_LAUNCH_RF(false);
+#undef GYMNET_LAUNCH_RF
             return hipGetLastError();
         }
     }
@@ -1187,8 +1235,8 @@ hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int64_t cap, int32_t *out, uint32_t *out_count, hipStream_t st) {
-    hipLaunchKernelGGL(compact_done_kernel, dim3(kShards), dim3(256), 0, st, counts, list, cap, out, out_count);
+hipError_t launch_compact_done(const CompactArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(compact_done_kernel, dim3(kShards), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -27,6 +27,9 @@ struct StepArgs {
     uint32_t *done_count2;   // [2][kShards * kCountStride]: this launch fills half [cparity] and zeroes half [cparity^1]
     int64_t done_cap;        // entries per shard segment
     float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;
+    // compact records, segmented like done_list (position p of shard s = the lane at done_list[s * done_cap + p]):
+    float *rec_ret; int32_t *rec_len;   // [kShards][done_cap]     finished episode's return / length   (EPISODE_STATS + DONE_LIST)
+    float *rec_obs;                     // [kShards][O][done_cap]  terminal observation                  (FINAL_OBS + DONE_LIST)
     const uint64_t *lane_seed;       // [n] per-lane Philox keys (VecEnv.Seed(int[])) or NULL
     unsigned long long *after_done;  // [kShards * kAfterStride] sharded counter: steps taken on already-done lanes (CartPoleEnv.cs:176-179)
     int64_t n, state_stride, obs_stride;
@@ -45,7 +48,7 @@ constexpr int kAfterStride = 8;     // uint64 words between after_done shards (6
 // lds_bytes: unused dynamic LDS requested per workgroup, for the ONE purpose of capping occupancy in probes (GYMNET_LDS)
 // items: lanes per thread of the fully unrolled software-pipelined kernel (envs with PIPELINED only; 1 = one-shot kernel)
 // reset_form: 1 = wave-compacted fused reset in the one-step kernel (reset_pending_wave: envs whose observation aliases the
-// state, dwordx4 lanes, lean variant)
+// state, dwordx4 lanes)
 struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
@@ -92,8 +95,18 @@ hipError_t launch_export_host(int obs_dim, const float *obs, int64_t stride, con
 hipError_t launch_observe(int env_id, const float *state, int64_t state_stride, float *obs, int64_t obs_stride,
                           int64_t n, hipStream_t st);
 hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st);
-// gathers the sharded done list of one step (counter half `counts`) into out[0 .. *out_count)
-hipError_t launch_compact_done(const uint32_t *counts, const int32_t *list, int64_t cap, int32_t *out, uint32_t *out_count, hipStream_t st);
+// Gathers the sharded done list of one step (counter half `counts`) and the records written beside it into compact arrays
+// out_*[0 .. *out_count) (entries beyond out_capacity are dropped; the count is the true one), and / or applies the records to
+// the dense per-lane arrays.  Every out / dense / rec pointer may be NULL.
+struct CompactArgs {
+    const uint32_t *counts; const int32_t *list; int64_t cap;
+    const float *rec_ret; const int32_t *rec_len; const float *rec_obs; int32_t obs_dim;
+    int32_t *out_list; float *out_ret; int32_t *out_len; float *out_obs;   // out_obs: row-major [count][obs_dim]
+    int64_t out_capacity;
+    uint32_t *out_count;
+    float *dense_ret; int32_t *dense_len; float *dense_obs; int64_t n;     // dense_obs: [obs_dim][n]
+};
+hipError_t launch_compact_done(const CompactArgs &a, hipStream_t st);
 // counts actions outside [0, nvals) into *bad
 hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,

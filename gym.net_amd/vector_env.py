@@ -94,6 +94,7 @@ class VectorEnv:
         self._h = C.c_void_p()
         self._owns_handle = True
         self._bookkeeping = bool(episode_stats or max_episode_steps)
+        self._final_obs = bool(final_obs)
         self._lane_seeds = False
         capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
         self._describe(env_id, num_envs, auto_reset)
@@ -107,6 +108,7 @@ class VectorEnv:
         self._h = handle
         self._owns_handle = False
         self._bookkeeping, self._lane_seeds = True, False     # a group member: flags unknown here, Checkpoint() refuses
+        self._final_obs = False
         self._describe(env_id, num_envs, auto_reset)
         return self
 
@@ -367,6 +369,32 @@ class VectorEnv:
     def DoneLanesDevice(self, d_lanes_out, d_count_out):
         """Compact list of the lanes that finished in the last step, left on the device (stream-ordered)."""
         capi.check(self._lib.gymnet_vecenv_done_lanes_device(self._h, _ptr(d_lanes_out), _ptr(d_count_out)))
+
+    def DoneRecords(self, episode=None, final_obs=None):
+        """Compact records of the lanes that finished in the most recent step (gymnet_vecenv_done_records): dict with
+        "lanes" int32 [c] and — by default whenever the handle keeps them — "return" float32 [c], "length" int32 [c],
+        "final_obs" float32 [c, D], all in the same (unspecified) order."""
+        n = self.NumberOfEnvironments
+        episode = self._bookkeeping if episode is None else episode
+        final_obs = self._final_obs if final_obs is None else final_obs
+        lanes = np.empty(n, np.int32)
+        ret = np.empty(n, np.float32) if episode else None
+        ln = np.empty(n, np.int32) if episode else None
+        fo = np.empty((n, self.ObsDim), np.float32) if final_obs else None
+        cnt = C.c_int64()
+        capi.check(self._lib.gymnet_vecenv_done_records(self._h, _host(lanes), None if ret is None else _host(ret), None if ln is None else _host(ln),
+                                                        None if fo is None else _host(fo), n, C.byref(cnt)))
+        c = cnt.value
+        out = {"lanes": lanes[:c].copy()}
+        if episode:
+            out["return"], out["length"] = ret[:c].copy(), ln[:c].copy()
+        if final_obs:
+            out["final_obs"] = fo[:c].copy()
+        return out
+
+    def DoneRecordsDevice(self, d_lanes, d_return, d_length, d_final_obs, capacity, d_count):
+        capi.check(self._lib.gymnet_vecenv_done_records_device(self._h, _ptr(d_lanes), _ptr(d_return), _ptr(d_length), _ptr(d_final_obs),
+                                                               int(capacity), _ptr(d_count)))
 
     def EpisodeStats(self):
         n = self.NumberOfEnvironments

@@ -268,9 +268,26 @@ int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capac
  * kernel the list is built per wave with ballot + one atomic into one of 256 shard counters; this call gathers the
  * shards.) */
 int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint32_t *d_count_out);
-/* Last finished episode's return and length per lane (0 length = none finished yet). Needs EPISODE_STATS. */
+/* ABI 3.  The RECORDS of the lanes that finished in the most recent step, compacted (unordered; all arrays in the same order):
+ * lane ids, with EPISODE_STATS the finished episode's return and length, with FINAL_OBS its terminal observation as rows
+ * [count][obs_dim] — what a trainer consumes per step (BasePlaySession.cs:58-69: accumulate reward, count steps per episode)
+ * without shipping num_envs flags to the host.  Inside the step kernel every finished lane's record is written AT ITS POSITION
+ * in the (sharded) done list, so a wave's ~11 finished lanes write a few contiguous cache lines instead of one scattered line
+ * per lane and array.  Any out pointer may be NULL; at most `capacity` records are copied, *count is the true number.
+ * Needs GYMNET_FLAG_DONE_LIST. */
+int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, float *final_obs_out,
+                               int64_t capacity, int64_t *count);
+/* Device-side form (stream-ordered, does not block): caller-owned device arrays of `capacity` records each (d_final_obs:
+ * [capacity][obs_dim] row-major); *d_count receives the true number.  Any array may be NULL. */
+int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, float *d_final_obs,
+                                      int64_t capacity, uint32_t *d_count);
+/* DENSE views, one row per lane.  Last finished episode's return and length per lane (0 length = none finished yet); needs
+ * EPISODE_STATS.  Terminal observations, host [num_envs, obs_dim], rows of lanes that never finished are 0; needs FINAL_OBS.
+ * Without GYMNET_FLAG_DONE_LIST the step kernel maintains these arrays itself (scattered stores).  WITH it the step writes the
+ * compact records only, and each call of these getters first applies the records of the MOST RECENT step to the dense arrays:
+ * a caller that reads them after every step sees the same values as before; records of steps it did not read are not in the
+ * dense view (use gymnet_vecenv_done_records). */
 int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length);
-/* Terminal observations, host [num_envs, obs_dim]; rows of lanes that never finished are 0. Needs FINAL_OBS. */
 int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out);
 
 /* ---- batched space sampling (the step BEFORE the path: ActionSpace.Sample(), TrainingPlaySession.cs:46-49) -- */

@@ -241,37 +241,61 @@ def test_sharding_invariance_bitwise(gpu_pkg):
     assert np.array_equal(np.concatenate(parts, axis=1), ref)
 
 
-def test_done_list_episode_stats_final_obs(gpu_pkg, oracle):
+@pytest.mark.parametrize("with_list,vec", [(True, 4), (True, 1), (False, 4)])
+def test_done_list_episode_stats_final_obs(gpu_pkg, oracle, with_list, vec, monkeypatch):
+    """Episode bookkeeping.  With the done list the step kernel writes COMPACT records — (lane, return, length,
+    terminal observation) at the lane's position in the list — checked per step against the host-side bookkeeping of
+    BasePlaySession.cs:58-69; the dense per-lane getters apply the latest step's records on each call, so a caller that reads
+    them every step sees every lane's last finished episode.  Without the list the kernel maintains the dense arrays itself
+    and they are complete even when read only at the end."""
     n, steps = 20_000, 60
     rng = np.random.default_rng(9)
     ret = np.zeros(n, np.float32); ln = np.zeros(n, np.int32)
     fin_ret = np.zeros(n, np.float32); fin_len = np.zeros(n, np.int32)
     fin_obs = np.zeros((n, 4), np.float32)
-    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, done_list=True, episode_stats=True,
+    monkeypatch.setenv("GYMNET_VEC", str(vec))          # 4: the dwordx4 bookkeeping kernel a 2^20-lane batch runs (wave-compacted reset)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, done_list=with_list, episode_stats=True,
                            final_obs=True) as env:
+        assert env.KernelName() == f"step_kernel<CartPole,{vec},true,true,15,{1 if vec == 4 else 0}>"
         env.Reset()
         for t in range(steps):
             s = env.GetState()
             a = rng.integers(0, 2, n).astype(np.int32)
             out = env.Step(a)
-            lanes = env.DoneLanes()
-            assert sorted(lanes.tolist()) == np.nonzero(out.Done)[0].tolist()       # wave-ballot compaction == mask
-            if t % 20 == 0:                                                         # device-side gather of the 256 shards
-                import torch
-                d_l = torch.full((n,), -1, dtype=torch.int32, device="cuda"); d_c = torch.zeros(1, dtype=torch.int32, device="cuda")
-                torch.cuda.synchronize()
-                env.DoneLanesDevice(d_l, d_c); env.Sync()
-                c = int(d_c.item())
-                assert c == len(lanes) and sorted(d_l[:c].cpu().tolist()) == sorted(lanes.tolist())
-            assert env.Counters()["last_done_count"] == int(out.Done.sum())
             term = oracle.cartpole_step(s, a, dtype=np.float32)[0]                  # terminal obs, kernel semantics
             ret += out.Reward; ln += 1
             d = out.Done
-            fin_ret[d] = ret[d]; fin_len[d] = ln[d]; ret[d] = 0; ln[d] = 0
+            fin_ret[d] = ret[d]; fin_len[d] = ln[d]
             fin_obs[d] = term.T[d]
+            if with_list:
+                lanes = env.DoneLanes()
+                assert sorted(lanes.tolist()) == np.nonzero(d)[0].tolist()           # wave-ballot compaction == mask
+                rec = env.DoneRecords()
+                order = np.argsort(rec["lanes"])
+                assert np.array_equal(rec["lanes"][order], np.nonzero(d)[0])
+                assert np.array_equal(rec["length"][order], ln[d]) and np.array_equal(rec["return"][order], ret[d])   # integer counts exact
+                assert np.array_equal(rec["final_obs"][order], term.T[d])
+                if t % 20 == 0:                                                     # device-side gathers of the 256 shards
+                    import torch
+                    d_l = torch.full((n,), -1, dtype=torch.int32, device="cuda"); d_c = torch.zeros(1, dtype=torch.int32, device="cuda")
+                    d_r = torch.zeros(n, dtype=torch.float32, device="cuda"); d_n = torch.zeros(n, dtype=torch.int32, device="cuda")
+                    d_o = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+                    torch.cuda.synchronize()
+                    env.DoneLanesDevice(d_l, d_c); env.Sync()
+                    c = int(d_c.item())
+                    assert c == len(lanes) and sorted(d_l[:c].cpu().tolist()) == sorted(lanes.tolist())
+                    env.DoneRecordsDevice(d_l, d_r, d_n, d_o, n, d_c); env.Sync()
+                    assert int(d_c.item()) == c
+                    o2 = np.argsort(d_l[:c].cpu().numpy())
+                    assert np.array_equal(d_n[:c].cpu().numpy()[o2], ln[d]) and np.array_equal(d_o[:c].cpu().numpy()[o2], term.T[d])
+                    env.DoneRecordsDevice(d_l, None, None, None, 3, d_c); env.Sync()      # a short buffer: true count, first records only
+                    assert int(d_c.item()) == c
+                assert env.Counters()["last_done_count"] == int(d.sum())
+                env.EpisodeStats(); env.FinalObs()                                    # dense views: the latest records are applied per call
+            ret[d] = 0; ln[d] = 0
         got_ret, got_len = env.EpisodeStats()
         assert np.array_equal(got_len, fin_len) and np.array_equal(got_ret, fin_ret)   # integer step counts exact
-        assert np.abs(env.FinalObs() - fin_obs).max() <= 1e-6
+        assert np.array_equal(env.FinalObs(), fin_obs)
         assert 15 < fin_len[fin_len > 0].mean() < 30                                  # SURVEY App. C: mean 22.25
 
 
@@ -414,6 +438,8 @@ def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
         for auto in (True, False):
             with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto) as env:
                 assert env.KernelName() == f"step_kernel<CartPole,{vec},{str(auto).lower()},false,{nt},{rf if auto else 0}>"
+                with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, done_list=True, episode_stats=True) as ex:
+                    assert ex.KernelName() == f"step_kernel<CartPole,{vec},{str(auto).lower()},true,{nt},{rf if auto else 0}>"
                 env.Reset()
                 dones = 0
                 for t in range(steps):
@@ -595,7 +621,7 @@ def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg)
     acts = rng.integers(0, 2, (30, n)).astype(np.int32)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as a, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as b:
         lean = a.KernelName()
-        assert ",false," in lean
+        assert lean.split(",")[3] == "false"
         a.Seed(7)
         b.Seed([7] * n)                                     # gymnet_vecenv_seed_lanes with N equal keys
         assert b.KernelName() == lean == a.KernelName()
@@ -607,7 +633,7 @@ def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg)
         b.RolloutFusedDevice(d, 8, n, 4); a.RolloutFusedDevice(d, 8, n, 4)    # GYMNET_ERR_UNSUPPORTED in round 2
         assert np.array_equal(a.GetState(), b.GetState())
         b.Seed(np.arange(n))                                # per-lane keys: the keyed (EXTRAS) variant, fused rollout refused
-        assert ",true," in b.KernelName().split("<")[1].split(",", 3)[3]
+        assert b.KernelName().split(",")[3] == "true"      # step_kernel<Env, VEC, AUTORESET, EXTRAS, ...>
         with pytest.raises(NotImplementedError):
             b.RolloutFusedDevice(d, 8, n, 4)
         b.Seed(np.full(n, 7))                               # and back

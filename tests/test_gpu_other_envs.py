@@ -134,6 +134,7 @@ def test_episode_bookkeeping_on_every_env(gpu_pkg, name):
         env.Reset()
         ln = np.zeros(n, np.int32); ret = np.zeros(n, np.float64)
         fin_len = np.zeros(n, np.int32); fin_ret = np.zeros(n, np.float64)
+        got_len = np.zeros(n, np.int32); got_ret = np.zeros(n, np.float64)
         for t in range(steps):
             a = rng.uniform(-2, 2, n).astype(np.float32) if name == "Pendulum-v1" else rng.integers(0, 3, n).astype(np.int32)
             out = env.Step(a)
@@ -141,12 +142,18 @@ def test_episode_bookkeeping_on_every_env(gpu_pkg, name):
             d = out.Done
             assert sorted(env.DoneLanes().tolist()) == np.nonzero(d)[0].tolist()
             fin_len[d] = ln[d]; fin_ret[d] = ret[d]; ln[d] = 0; ret[d] = 0
-        got_ret, got_len = env.EpisodeStats()
+            rec = env.DoneRecords()                                                  # this step's compact records
+            assert sorted(rec["lanes"].tolist()) == np.nonzero(d)[0].tolist() and rec["final_obs"].shape == (int(d.sum()), env.ObsDim)
+            got_len[rec["lanes"]] = rec["length"]; got_ret[rec["lanes"]] = rec["return"]
+            assert np.isfinite(rec["final_obs"]).all()
+            if d.any():
+                assert np.array_equal(env.FinalObs()[rec["lanes"]], rec["final_obs"])   # dense view: the latest records applied
         assert np.array_equal(got_len, fin_len) and got_len.max() == limit       # truncation at the limit
         assert np.abs(got_ret - fin_ret).max() <= 1e-3 * max(1.0, np.abs(fin_ret).max())
         if name == "Pendulum-v1":
             assert set(np.unique(got_len)) == {limit}                                # Pendulum only ever ends by truncation
-        assert np.isfinite(env.FinalObs()).all()
+        d_ret, d_len = env.EpisodeStats()                                            # dense view after the last step's records
+        assert np.array_equal(d_len[rec["lanes"]], rec["length"])
 
 
 def test_long_fused_rollout_stays_deterministic_and_in_bounds(gpu_pkg):

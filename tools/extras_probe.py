@@ -1,4 +1,6 @@
-"""Times the bookkeeping (EXTRAS) variants of the step kernel at 2^20 CartPole lanes."""
+"""Times the bookkeeping (EXTRAS) variants of the step kernel at 2^20 CartPole lanes (HIP events over T back-to-back launches).
+   python tools/extras_probe.py            all variants, one JSON object
+   python tools/extras_probe.py all 200    ONE variant, 200 launches (the shape the rocprofv3 passes of tools/gpu_extras_r03.sh use)"""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,11 +8,18 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(dev); torch.cuda.set_stream(st)
-n, ring, T = 1 << 20, 64, 1024
+n, ring = 1 << 20, 64
+VARIANTS = {"lean": {}, "done_list": dict(done_list=True), "episode_stats": dict(episode_stats=True),
+            "done_list+stats": dict(done_list=True, episode_stats=True),
+            "all": dict(done_list=True, episode_stats=True, final_obs=True),
+            "stats+final_obs(dense)": dict(episode_stats=True, final_obs=True),
+            "no_autoreset(sbd)": dict(auto_reset=False)}
+only = sys.argv[1] if len(sys.argv) > 1 else None
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 out = {}
-for label, kw in (("lean", {}), ("done_list", dict(done_list=True)), ("episode_stats", dict(episode_stats=True)),
-                  ("done_list+stats", dict(done_list=True, episode_stats=True)),
-                  ("all", dict(done_list=True, episode_stats=True, final_obs=True)), ("no_autoreset(sbd)", dict(auto_reset=False))):
+for label, kw in VARIANTS.items():
+    if only and label != only:
+        continue
     a = dict(auto_reset=True); a.update(kw)
     env = pkg.VectorEnv("CartPole-v1", n, seed=1, stream=st.cuda_stream, **a)
     acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
@@ -19,9 +28,11 @@ for label, kw in (("lean", {}), ("done_list", dict(done_list=True)), ("episode_s
     env.ResetDevice(); env.RolloutDevice(acts, 128, n, ring); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st); env.RolloutDevice(acts, T, n, ring); e1.record(st); torch.cuda.synchronize()
-    out[label] = e0.elapsed_time(e1) * 1e3 / T
+    out[label] = {"us_per_step": round(e0.elapsed_time(e1) * 1e3 / T, 3), "kernel": env.KernelName()}
     env.Close()
 print(json.dumps(out))
+if only:
+    sys.exit(0)
 
 # the reference-faithful loop on the device: Step (no auto-reset) followed by the caller's `if (done) Reset()`
 env = pkg.VectorEnv("CartPole-v1", n, seed=1, stream=st.cuda_stream, auto_reset=False)
