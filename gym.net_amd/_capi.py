@@ -145,6 +145,7 @@ PROTOTYPES = {
     "gymnet_vecenv_sample_actions_masked_device": (C.c_int, [_H, _P, _P, C.c_int64, C.c_uint64, C.c_uint64]),
     "gymnet_sample_box_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_float, C.c_float,
                                            C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gymnet_sample_box_elementwise_device": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions_device": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_sample_actions": (C.c_int, [_H, _P, C.c_uint64, C.c_uint64]),
     "gymnet_vecenv_compose_actions_device": (C.c_int, [_H, _P, C.c_float, _P, C.c_uint64, C.c_uint64]),

@@ -127,6 +127,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_sample_discrete_device(int device, IntPtr stream, IntPtr d_out, long count, int n, int start, ulong seed, ulong lane_offset, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_sample_discrete_masked_device(int device, IntPtr stream, IntPtr d_out, long count, int n, int start, IntPtr d_mask, long mask_stride, ulong seed, ulong lane_offset, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_sample_box_device(int device, IntPtr stream, IntPtr d_out, long count, float low, float high, ulong seed, ulong lane_offset, ulong tick);
+        [DllImport(Lib)] public static extern int gymnet_sample_box_elementwise_device(int device, IntPtr stream, IntPtr d_out, long count, int dim, IntPtr d_low, IntPtr d_high, ulong seed, ulong lane_offset, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions_device(IntPtr h, IntPtr d_actions, ulong seed, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions_masked_device(IntPtr h, IntPtr d_actions, IntPtr d_mask, long mask_stride, ulong seed, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sample_actions(IntPtr h, void* actions_out, ulong seed, ulong tick);

@@ -1102,6 +1102,17 @@ int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t cou
     });
 }
 
+int gymnet_sample_box_elementwise_device(int device, void *stream, float *d_out, int64_t count, int32_t dim, const float *d_low,
+                                         const float *d_high, uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    return guarded([&]() -> int {
+    if (!d_out || !d_low || !d_high || count < 0 || dim <= 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad d_out/d_low/d_high/count/dim");
+    DeviceScope dev_scope;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_sample_box_elementwise(d_out, count, dim, d_low, d_high, seed, lane_offset, tick, static_cast<hipStream_t>(stream)));
+    return GYMNET_OK;
+    });
+}
+
 int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick) {
     return guarded([&]() -> int {
     ENTER(h);

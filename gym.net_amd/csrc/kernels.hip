@@ -995,6 +995,36 @@ __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out
     out[i] = v;
 }
 
+// Box.Sample() for a Box whose Low / High are ARRAYS (Box.cs:25-51): the regime is chosen PER ELEMENT from that element's own
+// bounds (Box.cs:74-85: unbounded / low-bounded / high-bounded / bounded masks), `dim` elements per lane, output row-major
+// [count][dim].  Element e of lane i draws from Philox(key = action-stream key + e * odd constant, counter = (lane, tick)):
+// element 0 uses exactly the words of the scalar sampler above, so a (1,)-shaped Box samples the same values either way.
+__global__ __launch_bounds__(256) void sample_box_elementwise_kernel(float *__restrict__ out, int64_t n, int32_t dim,
+                                                                     const float *__restrict__ low, const float *__restrict__ high,
+                                                                     uint64_t seed, uint64_t lane_offset, uint64_t tick) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per ELEMENT: coalesced row-major stores
+    if (idx >= n * dim) return;
+    const int64_t i = idx / dim;
+    const int32_t e = (int32_t)(idx - i * dim);
+    const PhiloxWords r = stream_words(kStreamAction, seed + (uint64_t)e * 0xD1B54A32D192ED03ull, lane_offset + (uint64_t)i, tick);
+    const float lo = low[e], hi = high[e];
+    const bool blo = lo > -INFINITY, bhi = hi < INFINITY;           // Box.CheckBounded (Box.cs:53-58)
+    const float u = u01_24(r.w[0]);
+    float v;
+    if (blo && bhi) {
+        v = lo + (hi - lo) * u;                                     // Box.cs:85 uniform(low, high)
+    } else if (blo) {
+        v = -logf(1.0f - u) + lo;                                   // Box.cs:83 exponential(1) + low
+    } else if (bhi) {
+        v = -logf(1.0f - u) + hi;                                   // Box.cs:84 exponential(1) + high (sic)
+    } else {
+        const float u1 = (float)((r.w[0] >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
+        const float u2 = u01_24(r.w[1]);
+        v = 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
+    }
+    out[idx] = v;
+}
+
 // Direct (full-mesh) all-gather of observations, push form: this member's slice [D][N/G] is stored into
 // the same offset of every peer's replica buffer.  blockIdx.y selects the peer, so all peers' links carry traffic
 // concurrently (xGMI is point-to-point: 7 links x ~153 GB/s, one per peer); each lane moves 16 bytes per trip.  Plain stores:
@@ -1269,6 +1299,14 @@ hipError_t launch_push_obs(const PushArgs &a, hipStream_t st) {
     if (per_peer > 256) per_peer = 256;
     if (per_peer < 1) per_peer = 1;
     hipLaunchKernelGGL(push_obs_kernel, dim3((unsigned)per_peer, (unsigned)a.npeers), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_box_elementwise(float *out, int64_t n, int32_t dim, const float *low, const float *high, uint64_t seed,
+                                         uint64_t lane_offset, uint64_t tick, hipStream_t st) {
+    if (n <= 0 || dim <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_box_elementwise_kernel, dim3(grid_for(n * dim, 256)), dim3(256), 0, st, out, n, dim, low, high, seed,
+                       lane_offset, tick);
     return hipGetLastError();
 }
 

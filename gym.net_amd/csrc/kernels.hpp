@@ -124,4 +124,8 @@ hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t 
 hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,
                              uint64_t tick, hipStream_t st);
 
+// Box.Sample() with per-element bounds (Box.cs:25-51,69-90): low / high device arrays of `dim` floats, out row-major [n][dim]
+hipError_t launch_sample_box_elementwise(float *out, int64_t n, int32_t dim, const float *low, const float *high, uint64_t seed,
+                                         uint64_t lane_offset, uint64_t tick, hipStream_t st);
+
 }  // namespace gymnet

@@ -306,6 +306,13 @@ int gymnet_sample_discrete_masked_device(int device, void *stream, int32_t *d_ou
  * low = -INFINITY / high = +INFINITY select the regime. */
 int gymnet_sample_box_device(int device, void *stream, float *d_out, int64_t count, float low, float high,
                              uint64_t seed, uint64_t lane_offset, uint64_t tick);
+/* ABI 3.  Box.Sample() for a Box built from Low / High ARRAYS (Box.cs:25-51: `new Box(NDArray low, NDArray high)`), e.g. an
+ * observation space whose velocity components are unbounded: `count` samples of `dim` elements each, row-major [count][dim];
+ * d_low / d_high are device arrays of `dim` floats and every element picks ITS OWN regime from its own bounds, like the
+ * reference's boolean masks (Box.cs:74-85).  gymnet_sample_box_device above is the scalar-bounds form (one pair for every
+ * element: the four envs' action spaces); for dim = 1 both draw the same values. */
+int gymnet_sample_box_elementwise_device(int device, void *stream, float *d_out, int64_t count, int32_t dim, const float *d_low,
+                                         const float *d_high, uint64_t seed, uint64_t lane_offset, uint64_t tick);
 /* ActionSpace.Sample() for every lane of a handle into d_actions (int32 / float32 [num_envs]). */
 int gymnet_vecenv_sample_actions_device(gymnet_vecenv *h, void *d_actions, uint64_t seed, uint64_t tick);
 int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t seed, uint64_t tick);

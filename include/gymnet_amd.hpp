@@ -234,6 +234,30 @@ public:
     }
     gymnet_counters Counters() const { gymnet_counters c{}; check(gymnet_vecenv_counters(h_, &c)); return c; }
 
+    // ---- ABI 3 ------------------------------------------------------------------------------------------------------
+    /// The kernel instantiation the next step launch runs, as the launcher itself resolves it.
+    std::string KernelName() const { char buf[128] = {0}; check(gymnet_vecenv_kernel_name(h_, buf, (int32_t)sizeof buf)); return buf; }
+    /// Library-owned page-locked, device-mapped host buffers (valid until Close): stepping THROUGH them needs no staging copies.
+    struct PinnedBuffers { void *actions; float *obs; float *reward; uint8_t *done; };
+    PinnedBuffers HostBuffers() { PinnedBuffers b{}; check(gymnet_vecenv_host_buffers(h_, &b.actions, &b.obs, &b.reward, &b.done)); return b; }
+    /// gymnet_vecenv_step with caller-owned buffers (nothing is allocated): the pinned ones above, or any host memory.
+    void StepInto(const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) { check(gymnet_vecenv_step(h_, actions, obs_out, reward_out, done_out)); }
+    /// Compact records of the lanes that finished in the most recent step (DONE_LIST [+ EPISODE_STATS] [+ FINAL_OBS]).
+    struct DoneRecordSet { std::vector<int32_t> lanes; std::vector<float> episode_return; std::vector<int32_t> episode_length; std::vector<float> final_obs; };
+    DoneRecordSet DoneRecords(bool episode, bool final_obs) {
+        DoneRecordSet r;
+        r.lanes.resize((size_t)n_);
+        if (episode) { r.episode_return.resize((size_t)n_); r.episode_length.resize((size_t)n_); }
+        if (final_obs) r.final_obs.resize((size_t)n_ * info_.obs_dim);
+        int64_t c = 0;
+        check(gymnet_vecenv_done_records(h_, r.lanes.data(), episode ? r.episode_return.data() : nullptr, episode ? r.episode_length.data() : nullptr,
+                                         final_obs ? r.final_obs.data() : nullptr, n_, &c));
+        r.lanes.resize((size_t)c);
+        if (episode) { r.episode_return.resize((size_t)c); r.episode_length.resize((size_t)c); }
+        if (final_obs) r.final_obs.resize((size_t)c * info_.obs_dim);
+        return r;
+    }
+
     // device-resident path
     void ResetDevice() { check(gymnet_vecenv_reset_device(h_)); }
     void StepDevice(const void *d_actions) { check(gymnet_vecenv_step_device(h_, d_actions)); }

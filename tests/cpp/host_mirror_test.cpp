@@ -114,6 +114,38 @@ static void gpu_tests() {
         CHECK(mean_len > 25.0 && mean_len < 50.0, "alternating-action episodes average ~37.5 steps (SURVEY App. C)");
         cp.CloseEnvironment();
     }
+    {   // ABI 3 through the compiled mirror: kernel name, pinned host buffers (no staging), compact done records
+        const int64_t n = 8192;
+        gymnet::VectorEnv a(GYMNET_ENV_CARTPOLE, n, 0, 5, GYMNET_FLAG_AUTORESET | GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS);
+        gymnet::VectorEnv b(GYMNET_ENV_CARTPOLE, n, 0, 5, GYMNET_FLAG_AUTORESET);
+        CHECK(a.KernelName().rfind("step_kernel<CartPole,", 0) == 0 && b.KernelName().find(",true,false,") != std::string::npos, "kernel names");
+        auto pin = a.HostBuffers();
+        CHECK(pin.actions && pin.obs && pin.reward && pin.done && a.HostBuffers().obs == pin.obs, "pinned buffers are stable");
+        a.Reset(); b.Reset();
+        std::vector<int32_t> acts((size_t)n);
+        std::vector<int32_t> len((size_t)n, 0);
+        long finished = 0;
+        for (int t = 0; t < 40; ++t) {
+            for (int64_t i = 0; i < n; ++i) acts[(size_t)i] = (int32_t)((i * 7 + t * 3) % 2);
+            std::memcpy(pin.actions, acts.data(), (size_t)n * 4);
+            a.StepInto(pin.actions, pin.obs, pin.reward, pin.done);
+            gymnet::BatchStep sb = b.Step(acts);
+            CHECK(std::memcmp(pin.obs, sb.Observation.data(), (size_t)n * 16) == 0 && std::memcmp(pin.done, sb.Done.data(), (size_t)n) == 0,
+                  "pinned-buffer step == staged step (bookkeeping variant == lean variant)");
+            auto rec = a.DoneRecords(true, true);
+            long want = 0;
+            for (int64_t i = 0; i < n; ++i) { len[(size_t)i] += 1; want += pin.done[i] != 0; }
+            CHECK((long)rec.lanes.size() == want && rec.final_obs.size() == rec.lanes.size() * 4, "one record per finished lane");
+            for (size_t k = 0; k < rec.lanes.size(); ++k) {
+                const int32_t lane = rec.lanes[k];
+                CHECK(pin.done[lane] != 0 && rec.episode_length[k] == len[(size_t)lane] && rec.episode_return[k] == (float)len[(size_t)lane], "record = (lane, return, length)");
+                CHECK(std::fabs(rec.final_obs[k * 4]) > 2.4f || std::fabs(rec.final_obs[k * 4 + 2]) > 0.2094f, "terminal observation is past a threshold");
+                len[(size_t)lane] = 0;
+            }
+            finished += want;
+        }
+        CHECK(finished > n / 2, "episodes finished during the run");
+    }
     {   // teacher-forced single steps vs the double closed form: |err| <= 1e-5, done exact (north_star bar)
         const int64_t n = 4096;
         gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, n, 0, 7);

@@ -40,6 +40,26 @@ def test_standalone_sampling_regimes(gpu_pkg, oracle):
     assert set(np.unique(d)) == {10, 11, 12} and abs(np.bincount(d - 10) / n - 1 / 3).max() < 0.005
     with pytest.raises(ValueError):
         capi.check(lib.gymnet_sample_box_device(0, None, C.c_void_p(out.data_ptr()), n, 3.0, 1.0, 0, 0, 0))
+    # Box(NDArray low, NDArray high) (Box.cs:25-51): every element picks its own regime — CartPole's ObservationSpace has two
+    # bounded and two (float.MaxValue-)bounded components; here one element of each of the four regimes
+    m = 100_000
+    lo = torch.tensor([-5.0, 2.0, -inf, -inf, -1.0], dtype=torch.float32, device="cuda")
+    hi = torch.tensor([5.0, inf, 7.0, inf, 1.0], dtype=torch.float32, device="cuda")
+    rows = torch.empty((m, 5), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    capi.check(lib.gymnet_sample_box_elementwise_device(0, None, C.c_void_p(rows.data_ptr()), m, 5, C.c_void_p(lo.data_ptr()),
+                                                        C.c_void_p(hi.data_ptr()), 7, 11, 1))
+    torch.cuda.synchronize()
+    r = rows.cpu().numpy().astype(np.float64)
+    assert np.array_equal(r[:, 0].astype(np.float32), u[:m].astype(np.float32))       # element 0 == the scalar sampler's draws (same seed / tick)
+    assert r[:, 1].min() >= 2.0 and abs(r[:, 1].mean() - 3.0) < 0.03                  # low + Exp(1)
+    assert r[:, 2].min() >= 7.0 and abs(r[:, 2].mean() - 8.0) < 0.03                  # high + Exp(1) (sic)
+    assert abs(r[:, 3].mean() - 0.5) < 0.02 and abs(r[:, 3].std() - 1.0) < 0.02       # Normal(0.5, 1) (sic)
+    assert r[:, 4].min() >= -1.0 and r[:, 4].max() <= 1.0 and abs(r[:, 4].std() - 2 / np.sqrt(12)) < 0.01
+    assert abs(np.corrcoef(r[:, 0], r[:, 4])[0, 1]) < 0.02                            # elements draw from different keys
+    with pytest.raises(ValueError):
+        capi.check(lib.gymnet_sample_box_elementwise_device(0, None, C.c_void_p(rows.data_ptr()), m, 0, C.c_void_p(lo.data_ptr()),
+                                                            C.c_void_p(hi.data_ptr()), 7, 11, 1))
 
 
 @pytest.mark.parametrize("name", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1"])
