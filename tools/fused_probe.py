@@ -13,7 +13,8 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(dev)
 torch.cuda.set_stream(st)
 out = {}
-for name in ("CartPole-v1", "Pendulum-v1", "MountainCar-v0", "Acrobot-v1"):
+ENVS = sys.argv[1:] or ["CartPole-v1", "Pendulum-v1", "MountainCar-v0", "Acrobot-v1"]
+for name in ENVS:
     n, ring, T = 1 << 20, 64, 1024
     env = pkg.VectorEnv(name, n, seed=1, auto_reset=True, stream=st.cuda_stream)
     adt = torch.float32 if name == "Pendulum-v1" else torch.int32
@@ -31,7 +32,8 @@ for name in ("CartPole-v1", "Pendulum-v1", "MountainCar-v0", "Acrobot-v1"):
             if mode == "stepwise":
                 env.RolloutDevice(acts, steps, n, ring)
             elif mode == "fused":
-                env.RolloutFusedDevice(acts, steps, n, ring)
+                for c in range(steps // ring):                       # `ring` steps per launch
+                    env.RolloutFusedDevice(acts, ring, n, ring)
             else:
                 for c in range(steps // ring):
                     env.RolloutFusedDevice(acts, ring, n, ring, rec_obs, rec_rew, rec_done)
