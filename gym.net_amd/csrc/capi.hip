@@ -595,6 +595,11 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     // passes.  CartPole at 2^20 lanes: 6.91 -> 6.52 us per launch, bit-identical (profiles/forms_probe_r03.txt).
     h->lcfg.reset_form = (d.alias && h->lcfg.vec == 4) ? 1 : 0;
     if (const char *e = std::getenv("GYMNET_RESET_FORM")) { int v = std::atoi(e); if (v == 0 || v == 1) h->lcfg.reset_form = v; }
+    // producer / consumer form of the multi-lane kernel: whole 512-lane tiles and 16-byte aligned rows only
+    const bool lds_ok = alu_bound && can_vec4 && (h->n % 512) == 0;
+    // Opt-in (GYMNET_LDS_PIPE=1): bit-identical and SLOWER at 2^20 lanes — 13.5-14.9 vs 11.7-12.7 us (profiles/acrobot_lds_r03.txt):
+    // the computing waves' waits on memory instructions drop from 34 % to 21 % of their cycles, the s_barrier per tile adds more.
+    if (const char *e = std::getenv("GYMNET_LDS_PIPE")) { if (std::atoi(e) == 1 && lds_ok) h->lcfg.lds_pipe = 1; }
     if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY

@@ -606,6 +606,108 @@ __global__ __launch_bounds__(256) void step_kernel_pipe(const StepArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Producer / consumer form of the multi-lane kernel: the COMPUTING waves never issue a store.  A workgroup
+// is 8 computing waves + 1 storing wave and walks TPB tiles of 512 lanes: a computing thread prefetches its lane of tile t + 1
+// (the only memory operations it ever has in flight are loads, so its in-order vmcnt means what it says: "tile t has landed"
+// while tile t + 1 is still on its way — the distance-1 software pipeline that loads and stores sharing one vmcnt forbids in
+// step_kernel_pipe), advances its lane of tile t and hands the results to the storing wave through LDS ([row][512] floats,
+// double-buffered, one s_barrier per tile); the storing wave drains tile t - 1 with 16-byte stores while tile t is computed.
+// The first request burst is ONE lane per thread instead of ITEMS, so the first arithmetic starts earlier, and no computing
+// wave ever stalls on the store path.  Same per-lane code and Philox counters as every other form: bit-identical.
+// Needs n % 512 == 0 and 16-byte aligned rows (the launcher falls back to step_kernel_pipe otherwise).
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsTileMax = 512;     // lanes per tile of the widest workgroup shape (8 computing waves)
+
+template <class Env>
+constexpr int own_state_rows() { int c = 0; for (int k = 0; k < Env::S; ++k) c += state_row_own<Env>(k) ? 1 : 0; return c; }
+
+template <class Env, int TPB, bool AUTORESET, int NT, int CW = 8>
+__global__ __launch_bounds__(CW * 64 + 64) void step_kernel_lds(const StepArgs a, const int64_t tiles) {
+    constexpr int kLdsComputeWaves = CW, kLdsTile = CW * 64;
+    constexpr int S = Env::S, O = Env::O;
+    constexpr int NOWN = own_state_rows<Env>();
+    constexpr int NROW = NOWN + (Env::OBS_ALIASES_STATE ? 0 : O) + 1;          // own state rows, observation rows, reward
+    constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
+    __shared__ float out_buf[2][NROW][kLdsTile];
+    __shared__ uint8_t done_buf[2][kLdsTile];
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int lane = threadIdx.x & 63;
+    const bool storer = (threadIdx.x >> 6) == kLdsComputeWaves;
+    const int cl = threadIdx.x;                                   // computing thread: its lane inside a tile
+    const int64_t t0 = (int64_t)blockIdx.x * TPB;
+    const int nt = (int)(tiles - t0 < TPB ? tiles - t0 : TPB);    // workgroup-uniform; >= 1 by the grid size
+
+    // LDS hand-off between the computing waves and the storing wave: LDS traffic only (lgkmcnt), never vmcnt — a
+    // __syncthreads() would also wait for the prefetched loads and for the storing wave's global stores
+    auto tile_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    LaneInputs<Env, 1> in[TPB + 1];
+    if (!storer) load_inputs<Env, 1, AUTORESET, NT, false>(a, t0 * kLdsTile + cl, in[0]);
+#pragma unroll
+    for (int s = 0; s <= TPB; ++s) {
+        if (!storer) {
+            if (s < TPB) {
+                // Loads are UNCONDITIONAL (past this workgroup's last tile the lane re-reads its current tile): a branch around
+                // a group of loads makes the compiler's waitcnt bookkeeping merge the two paths and wait for everything
+                const int64_t i = (t0 + (s < nt ? s : nt - 1)) * kLdsTile + cl;
+                const int64_t ip = (t0 + (s + 1 < nt ? s + 1 : nt - 1)) * kLdsTile + cl;
+                load_inputs<Env, 1, AUTORESET, NT, false>(a, ip, in[s + 1]);
+#pragma unroll
+                for (int c = 0; c < S; ++c) asm volatile("" : "+v"(in[s].s[c][0]));     // this tile's inputs are needed now ...
+                asm volatile("" : "+v"(in[s].act[0]));
+                LaneOutputs<Env> out;
+                compute_lane<Env, AUTORESET>(a, i, tick, in[s], out);
+                // ... and no use of the NEXT tile's inputs may be scheduled before this tile's results exist (the compiler would
+                // otherwise hoist e.g. the action's int -> float conversion and wait for the prefetch right after issuing it)
+#pragma unroll
+                for (int c = 0; c < S; ++c) asm volatile("" : "+v"(in[s + 1].s[c][0]), "+v"(out.s[S - 1]));
+                asm volatile("" : "+v"(in[s + 1].act[0]), "+v"(out.reward));
+                if (s < nt) {
+                    int r = 0;
+#pragma unroll
+                    for (int k = 0; k < S; ++k)
+                        if (state_row_own<Env>(k)) out_buf[s & 1][r++][cl] = out.s[k];
+                    if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                        for (int k = 0; k < O; ++k) out_buf[s & 1][r++][cl] = out.o[k];
+                    }
+                    out_buf[s & 1][r][cl] = out.reward;
+                    done_buf[s & 1][cl] = out.done;
+                }
+            }
+        } else if (s >= 1 && s - 1 < nt) {
+            const int b = (s - 1) & 1;
+            const int64_t base = (t0 + s - 1) * kLdsTile;
+            auto drain = [&](float *row, int r, bool nt_store) {
+#pragma unroll
+                for (int j = 0; j < kLdsTile / 256; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(&out_buf[b][r][j * 256 + lane * 4]);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(row + base + j * 256 + lane * 4);
+                    if (nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
+                }
+                static_assert(kLdsTile % 256 == 0, "the storing wave moves 256 floats per instruction");
+            };
+            int r = 0;
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+                if (state_row_own<Env>(k)) drain(a.state_out + k * a.state_stride, r++, NT_SS);
+            if constexpr (!Env::OBS_ALIASES_STATE) {
+#pragma unroll
+                for (int k = 0; k < O; ++k) drain(a.obs + k * a.obs_stride, r++, NT_SS);
+            }
+            drain(a.reward, r, NT_O);
+            if (lane < kLdsTile / 16) {
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&done_buf[b][lane * 16]);
+                i32x4 *dst = reinterpret_cast<i32x4 *>(a.done + base + lane * 16);
+                if constexpr (NT_O) __builtin_nontemporal_store(v, dst); else *dst = v;
+            }
+        }
+        tile_barrier();
+    }
+}
+
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, int RESETF = 0>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
@@ -1054,6 +1156,7 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 // describe_step_kernel() prints it (gymnet_vecenv_kernel_name: tests and bench.py name the kernel they ran from the library,
 // not from a copy of this policy).
 struct StepVariant {
+    int lds_tiles;      // > 1: step_kernel_lds<Env, lds_tiles, AUTORESET, 15> (producer / consumer form of the multi-lane kernel)
     int pipe_items;     // > 1: step_kernel_pipe<Env, pipe_items, AUTORESET, 15>; else step_kernel
     int vec, nt;        // step_kernel<Env, vec, AUTORESET, EXTRAS, nt, resetf>
     int resetf;
@@ -1068,9 +1171,13 @@ static LaunchCfg normalized(LaunchCfg cfg) {
 
 template <class Env>
 static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg) {
-    StepVariant v{1, 1, cfg.nt, 0};
+    StepVariant v{1, 1, 1, cfg.nt, 0};
     if constexpr (Env::PIPELINED) {        // multi-lane kernel, cfg.items lanes per thread (2..5)
-        if (cfg.items > 1 && cfg.items <= 5 && !extras && cfg.vec == 1) { v.pipe_items = cfg.items; v.nt = 15; return v; }
+        if (cfg.items > 1 && cfg.items <= 5 && !extras && cfg.vec == 1) {
+            v.nt = 15;
+            if (cfg.lds_pipe) v.lds_tiles = cfg.items; else v.pipe_items = cfg.items;
+            return v;
+        }
     }
     // the wide form of an env: four lanes per thread on dwordx4 streams, or — for the env with a two-lane packed-FP32 form
     // (Acrobot) — two lanes per thread on dwordx2 streams
@@ -1084,6 +1191,21 @@ template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
     const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg);
     if constexpr (Env::PIPELINED) {
+        if (v.lds_tiles > 1) {
+            const int64_t tiles = a.n / kLdsTileMax;
+            const dim3 lgrid(grid_for(tiles, v.lds_tiles)), lblk(kLdsTileMax + 64);
+#define GYMNET_LDS(I)                                                                                                   \
+    case I:                                                                                                             \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_lds<Env, I, true, 15>), lgrid, lblk, 0, st, a, tiles);            \
+        else hipLaunchKernelGGL((step_kernel_lds<Env, I, false, 15>), lgrid, lblk, 0, st, a, tiles);                     \
+        break;
+            switch (v.lds_tiles) {
+                GYMNET_LDS(2) GYMNET_LDS(3) GYMNET_LDS(4) GYMNET_LDS(5)
+                default: return hipErrorInvalidValue;
+            }
+#undef GYMNET_LDS
+            return hipGetLastError();
+        }
         if (v.pipe_items > 1) {
             const int64_t per_block = 256 * (int64_t)v.pipe_items;
             const dim3 pgrid(grid_for(a.n > 0 ? (a.n + per_block - 1) / per_block : 1, 1)), pblk(256);
@@ -1160,6 +1282,7 @@ int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg,
         default: return -1;
     }
     const char *ar = autoreset ? "true" : "false";
+    if (v.lds_tiles > 1) return std::snprintf(buf, cap, "step_kernel_lds<%s,%d,%s,15>", env, v.lds_tiles, ar);
     if (v.pipe_items > 1) return std::snprintf(buf, cap, "step_kernel_pipe<%s,%d,%s,15>", env, v.pipe_items, ar);
     return std::snprintf(buf, cap, "step_kernel<%s,%d,%s,%s,%d,%d>", env, v.vec, ar, extras ? "true" : "false", v.nt, v.resetf);
 }

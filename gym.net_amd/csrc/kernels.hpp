@@ -49,7 +49,8 @@ constexpr int kAfterStride = 8;     // uint64 words between after_done shards (6
 // items: lanes per thread of the fully unrolled software-pipelined kernel (envs with PIPELINED only; 1 = one-shot kernel)
 // reset_form: 1 = wave-compacted fused reset in the one-step kernel (reset_pending_wave: envs whose observation aliases the
 // state, dwordx4 lanes)
-struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; };
+// lds_pipe: 1 = the multi-lane kernel in its producer / consumer form (step_kernel_lds: `items` tiles per workgroup)
+struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; int lds_pipe = 0; };
 
 // env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);

@@ -245,6 +245,7 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
     for vec, items in ((1, 1), (2, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
         monkeypatch.setenv("GYMNET_VEC", str(vec))
         monkeypatch.setenv("GYMNET_ITEMS", str(items))
+        monkeypatch.setenv("GYMNET_LDS_PIPE", "0")
         res = []
         for auto, stats in ((True, False), (False, False), (True, True)):
             with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats) as env:
@@ -290,3 +291,43 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
             if a[4] is not None:
                 assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1]), key
     assert ref[0][3].any() or ref[1][3].any()
+
+
+@pytest.mark.parametrize("tiles", [2, 3, 4, 5])
+def test_acrobot_producer_consumer_kernel_is_bit_identical(gpu_pkg, monkeypatch, tiles):
+    """step_kernel_lds (GYMNET_LDS_PIPE=1): computing waves prefetch the next tile and hand results to a storing wave through
+    LDS.  Same per-lane code and Philox counters as the one-shot kernel, so states, observations, rewards and done flags must
+    agree bit for bit — workgroups with fewer tiles than TPB (ragged grid), with and without auto-reset, energetic states so the
+    fused reset runs."""
+    import torch
+    n, ring = 512 * 37, 6                       # 37 tiles: the last workgroup of every TPB owns fewer tiles than the others
+    rng = np.random.default_rng(4)
+    s0 = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
+    res = {}
+    for form in ("one-shot", "lds"):
+        monkeypatch.setenv("GYMNET_VEC", "1")
+        monkeypatch.setenv("GYMNET_ITEMS", "1" if form == "one-shot" else str(tiles))
+        monkeypatch.setenv("GYMNET_LDS_PIPE", "0" if form == "one-shot" else "1")
+        out = []
+        for auto in (True, False):
+            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto) as env:
+                want = f"step_kernel_lds<Acrobot,{tiles},{str(auto).lower()},15>" if form == "lds" else f"step_kernel<Acrobot,1,{str(auto).lower()},false,15,0>"
+                assert env.KernelName() == want, env.KernelName()
+                acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                for t in range(ring):
+                    env.SampleActionsDevice(acts[t], seed=5, tick=t)
+                env.ResetDevice()
+                env.SetState(s0)
+                env.RolloutDevice(acts, 25, n, ring)
+                env.Sync()
+                r = env.Read()
+                out.append((env.GetState(), r.Observation, r.Reward, r.Done))
+                assert r.Done.any() or not auto
+        res[form] = out
+    for x, y in zip(res["one-shot"], res["lds"]):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v, equal_nan=True)
+    monkeypatch.setenv("GYMNET_ITEMS", "4")
+    with gpu_pkg.VectorEnv("Acrobot-v1", 512 * 8 + 3, seed=SEED, auto_reset=True) as env:      # not whole tiles: falls back
+        assert env.KernelName() == "step_kernel_pipe<Acrobot,4,true,15>"
