@@ -543,7 +543,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel,
-                         "algorithmic_bytes_per_launch": bytes_per_step * n, "launch_us": launch_us,
+                         "algorithmic_bytes_per_launch": bytes_per_step * n, "moved_bytes_per_launch": local.TrafficBytesPerStep * n,
+                         "launch_us": launch_us,
                          "frac_by_wall": bytes_per_step * n / (wall / K) / 1e9 / HBM_PEAK_GBPS,
                          "note": "at 2^20 lanes the working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
         }

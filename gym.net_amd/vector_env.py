@@ -131,6 +131,7 @@ class VectorEnv:
         self.RewardRange = (float(i.reward_low), float(i.reward_high))
         self.Environments = []          # VecEnv.cs:17 — deliberately empty, see module docstring
         self.AlgorithmicBytesPerStep = int(i.algorithmic_bytes_per_step)
+        self.TrafficBytesPerStep = int(i.traffic_bytes_per_step)      # < algorithmic where a state row is stored once, in the observation
 
     # ---- lifecycle ------------------------------------------------------------------------------
     def Close(self):                                                                 # VecEnvWrapper.cs:26-30
