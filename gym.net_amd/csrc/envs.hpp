@@ -231,9 +231,26 @@ struct Pendulum {
     using Action = float;                    // Box(-2, 2, (1,))
     static constexpr float PI = 3.14159265358979323846f;
 
-    __device__ __forceinline__ static float floored_mod(float a, float m) {
-        float r = fmodf(a, m);
-        if (r < 0.0f) r += m;
+    // fmodf(a, m) for the ONE modulus the env uses (m = 2 pi), in ~11 instructions instead of OCML's iterative reduction, and
+    // EXACT like fmod itself (so the CPU restatement keeps calling libm's fmodf and the bits agree): q = trunc(|a| * RN(1/m)) is
+    // the true truncated quotient up to +-1 for |a| < 2^22 m (relative error of the product 2^-23, so absolute error < 1/2);
+    // r = fma(-q, m, |a|) is exact for the true q (the remainder of an IEEE fmod is representable) and, for a q off by one,
+    // lands below 0 or at / above m — rounding cannot move it across either bound, m being representable — so one compare pair
+    // repairs q and a second fma gives the exact remainder.  Larger, infinite or NaN arguments take fmodf.
+    __device__ __forceinline__ static float fmod_2pi(float a) {
+        constexpr float m = 2.0f * PI, inv_m = 1.0f / m;
+        const float ax = fabsf(a);
+        if (__builtin_expect(!(ax < 4194304.0f * m), 0)) return fmodf(a, m);
+        float q = truncf(ax * inv_m);
+        float r = fmaf(-q, m, ax);
+        q = r < 0.0f ? q - 1.0f : (r >= m ? q + 1.0f : q);
+        r = fmaf(-q, m, ax);
+        return copysignf(r, a);
+    }
+
+    __device__ __forceinline__ static float floored_mod_2pi(float a) {
+        float r = fmod_2pi(a);
+        if (r < 0.0f) r += 2.0f * PI;
         return r;
     }
 
@@ -241,7 +258,7 @@ struct Pendulum {
         const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f;
         const float th = s[0], thdot = s[1];
         const float u = a < -max_torque ? -max_torque : (a > max_torque ? max_torque : a);
-        const float nrm = floored_mod(th + PI, 2.0f * PI) - PI;
+        const float nrm = floored_mod_2pi(th + PI) - PI;
         const float costs = nrm * nrm + 0.1f * (thdot * thdot) + 0.001f * (u * u);
         float newthdot = thdot + (15.0f * sin_f32(th) + 3.0f * u) * dt;     // 3g/(2l) = 15, 3/(m l^2) = 3
         newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);

@@ -49,6 +49,10 @@ def lib():
     L.ref_div_total_mass_kernel.restype = C.c_float
     L.ref_check_div_total_mass.argtypes = [_i32p, C.c_int32]
     L.ref_check_div_total_mass.restype = C.c_int64
+    L.ref_fmod_2pi_kernel.argtypes = [C.c_float]
+    L.ref_fmod_2pi_kernel.restype = C.c_float
+    L.ref_check_fmod_2pi.argtypes = [C.c_uint32, C.c_int32]
+    L.ref_check_fmod_2pi.restype = C.c_int64
     L.ref_discrete_contains.argtypes = [C.c_int, C.c_int]
     L.ref_discrete_contains.restype = C.c_int
     L.ref_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
@@ -126,6 +130,11 @@ def sincos_kernel(x, small=False):
 def check_div_total_mass(biased_exponents):
     e = np.ascontiguousarray(np.asarray(biased_exponents, dtype=np.int32))
     return int(lib().ref_check_div_total_mass(e, e.shape[0]))
+
+
+def check_fmod_2pi(stride, multiples):
+    """Number of arguments for which the Pendulum kernel's fast fmod(., 2 pi) differs from libm's fmodf (must be 0)."""
+    return int(lib().ref_check_fmod_2pi(stride, multiples))
 
 
 def philox4x32_10(ctr, key):

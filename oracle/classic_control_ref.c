@@ -26,6 +26,7 @@
  * the float32 "kernel semantics" functions round after every operation like the HIP kernels).
  */
 #include <math.h>
+#include <string.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -331,6 +332,46 @@ void ref_box_uniform_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, 
 /* Pendulum-v1.  state = (theta, theta_dot); obs = (cos th', sin th', thdot'); never terminates. */
 static inline double floored_mod_d(double a, double m) { double r = fmod(a, m); if (r < 0.0) r += m; return r; }
 static inline float floored_mod_f(float a, float m) { float r = fmodf(a, m); if (r < 0.0f) r += m; return r; }
+
+/* The Pendulum kernel's fmodf(a, 2 pi) (envs.hpp Pendulum::fmod_2pi), restated: truncated quotient from one multiply, exact
+ * remainder by fma, one repair step.  It is EXACT — identical to libm's fmodf for every finite |a| < 2^22 * 2 pi — which is why
+ * ref_pendulum_step_f32 below may keep calling fmodf; ref_check_fmod_2pi counts the arguments for which that fails. */
+float ref_fmod_2pi_kernel(float a) {
+    const float m = 2.0f * PI_F, inv_m = 1.0f / m;
+    const float ax = fabsf(a);
+    if (!(ax < 4194304.0f * m)) return fmodf(a, m);
+    float q = truncf(ax * inv_m);
+    float r = fmaf(-q, m, ax);
+    q = r < 0.0f ? q - 1.0f : (r >= m ? q + 1.0f : q);
+    r = fmaf(-q, m, ax);
+    return copysignf(r, a);
+}
+
+/* every `stride`-th binary32 bit pattern below 2^22 * 2 pi (both signs), and the 7 floats around each of the first `multiples`
+ * multiples of 2 pi — the arguments where a quotient off by one would show */
+int64_t ref_check_fmod_2pi(uint32_t stride, int32_t multiples) {
+    const float m = 2.0f * PI_F;
+    int64_t bad = 0;
+    for (uint64_t bits = 0; bits < 0x4c000000ull; bits += stride) {
+        const uint32_t b = (uint32_t)bits;
+        float a;
+        memcpy(&a, &b, 4);
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const float x = sgn ? -a : a, w = fmodf(x, m), g = ref_fmod_2pi_kernel(x);
+            if (memcmp(&w, &g, 4) != 0) ++bad;
+        }
+    }
+    for (int32_t k = 1; k <= multiples; ++k) {
+        const float f = (float)((double)k * (double)m);
+        for (int d = -3; d <= 3; ++d) {
+            float a = f;
+            for (int t = 0; t < (d < 0 ? -d : d); ++t) a = nextafterf(a, d < 0 ? 0.0f : INFINITY);
+            const float w = fmodf(a, m), g = ref_fmod_2pi_kernel(a);
+            if (memcmp(&w, &g, 4) != 0) ++bad;
+        }
+    }
+    return bad;
+}
 
 void ref_pendulum_step_f64(double *state, double a, double *obs3, double *reward) {
     const double g = 10.0, m = 1.0, l = 1.0, dt = 0.05, max_speed = 8.0, max_torque = 2.0;

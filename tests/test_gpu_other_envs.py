@@ -101,6 +101,12 @@ def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name, n):
     rng = np.random.default_rng(31)
     if name == "Pendulum-v1":
         s = np.stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n)]).astype(np.float32)
+        # a free-running Pendulum never wraps theta: large angles of both signs (the kernel's exact fast fmod), the neighbourhood of
+        # multiples of 2 pi (a quotient off by one would show there) and angles beyond 2^22 * 2 pi (the fmodf fallback)
+        s[0, ::5] = rng.uniform(-6e4, 6e4, s[0, ::5].shape).astype(np.float32)
+        k = rng.integers(-4000, 4000, s[0, 1::7].shape)
+        s[0, 1::7] = (k * (2 * np.pi) - np.pi + rng.uniform(-1e-3, 1e-3, k.shape)).astype(np.float32)
+        s[0, 2::97] = rng.uniform(-4e8, 4e8, s[0, 2::97].shape).astype(np.float32)
         a = rng.uniform(-2.5, 2.5, n).astype(np.float32)
         want = oracle.pendulum_step(s, a, dtype=np.float32)
         ws, wo, wr, wd = want
@@ -119,8 +125,12 @@ def test_kernels_bit_identical_to_float32_restatement(gpu_pkg, oracle, name, n):
             assert pol["sequential_lanes_per_thread"] == (4 if name == "Acrobot-v1" else 1) and pol["envs_per_thread"] == (1 if name == "Acrobot-v1" else 4)
         env.Reset(); env.SetState(s)
         out = env.Step(a)
-        assert np.array_equal(env.GetState(), ws)
-        assert np.array_equal(out.Observation, wo.T)
+        # sin / cos beyond |x| = 65536 fall back to OCML on the GPU and libm on the CPU (they may differ by an ulp, envs.hpp): state
+        # and observation are compared where the angle is inside that range, the reward (no trigonometry in it) everywhere
+        ok = np.abs(s[0]) <= 65536.0 if name == "Pendulum-v1" else np.ones(n, bool)
+        assert ok.sum() > 0.98 * n
+        assert np.array_equal(env.GetState()[:, ok], ws[:, ok])
+        assert np.array_equal(out.Observation[ok], wo.T[ok])
         assert np.array_equal(out.Reward, wr.astype(np.float32)) and np.array_equal(out.Done, wd.astype(bool))
 
 

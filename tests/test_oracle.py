@@ -395,3 +395,16 @@ def test_reference_constant_initialisers_are_parsed_not_evaluated():
         with pytest.raises((ValueError, SyntaxError)):
             chk._arith(hostile)
     assert "eval(" not in open(os.path.join(ROOT, "oracle", "check_against_reference.py")).read().replace("to eval()", "")
+
+
+def test_pendulum_fast_fmod_is_exact(oracle):
+    """envs.hpp Pendulum::fmod_2pi (one multiply, trunc, two fma and a repair step instead of OCML's iterative fmodf) must be
+    EXACT, because the float32 restatement keeps calling libm's fmodf: every 97th binary32 pattern below 2^22 * 2 pi in both
+    signs (2.6e7 arguments) and the 7 neighbours of each of the first 400 000 multiples of 2 pi, bit for bit; infinities, NaN
+    and huge arguments take the fallback."""
+    assert oracle.check_fmod_2pi(97, 400_000) == 0
+    L = oracle.lib()
+    for x in (0.0, -0.0, 6.2831855, -6.2831855, 1e30, -1e30, float("inf")):
+        want = np.fmod(np.float32(x), np.float32(2 * np.float32(np.pi))) if np.isfinite(x) else np.float32("nan")
+        got = np.float32(L.ref_fmod_2pi_kernel(x))
+        assert (np.isnan(want) and np.isnan(got)) or (want == got and np.signbit(want) == np.signbit(got)), x
