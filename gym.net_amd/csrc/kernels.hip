@@ -2,8 +2,9 @@
 //
 // The hot path is HBM-bound streaming (CartPole: 41 algorithmic bytes per env-step against ~105 VALU), so the
 // design rules are the memory ones: structure-of-arrays, one env per lane, 16-byte (dwordx4) accesses per lane
-// on every stream, a static block->lane map, no LDS (there is no reuse to stage: each state word is read once
-// and written once per launch), no MFMA (no dense contraction exists on this path).
+// on every stream, a static block->lane map, no LDS staging of the streams (there is no reuse to stage: each state word is read
+// once and written once per launch; LDS carries only the lane-to-lane hand-offs: reset_pending_wave, compact_done_kernel,
+// step_kernel_lds), no MFMA (no dense contraction exists on this path).
 // What the counters say (profiles/rocprof_pmc_r01.txt): every launch fetches all of its input bytes through the
 // fabric again — the per-XCD L2s keep nothing across a kernel boundary — so the only cross-launch reuse level
 // is the 256 MiB Infinity Cache, and an XCD-aware block remap would buy nothing here; what matters instead is
