@@ -311,12 +311,15 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, float (&s)[
     }
     if (total == 0) return;                                   // wave-uniform
     const int64_t wave_i0 = i0 - (int64_t)lane * VEC;          // first lane index of this wave
-    for (uint32_t base = 0; base < total; base += 64) {        // wave-uniform; more than 64 finished slots in a wave: ~never
+    // The drawing lanes are the wave's ACTIVE lanes.  In the batch's last (partial) wave the threads past the end have left the
+    // kernel; the active ones are a prefix 0 .. A-1 (the lane index grows with the thread index), and a round serves A slots.
+    const uint32_t A = (uint32_t)__popcll(__ballot(1));
+    for (uint32_t base = 0; base < total; base += A) {         // wave-uniform; more finished slots than lanes in a wave: ~never
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            if (((pending >> j) & 1u) && rank[j] - base < 64u) sc->slot[rank[j] - base] = lane * VEC + (uint32_t)j;
+            if (((pending >> j) & 1u) && rank[j] - base < A) sc->slot[rank[j] - base] = lane * VEC + (uint32_t)j;
         wave_lds_fence();
-        if (lane < total - base) {
+        if (lane < total - base) {                             // (an active lane by construction: lane < A whenever it has a slot)
             const uint32_t sl = sc->slot[lane];
             const int64_t gl = wave_i0 + (int64_t)sl;
             uint64_t key = a.seed;
@@ -337,11 +340,11 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, float (&s)[
         for (int j = 0; j < VEC; ++j) {
             const uint32_t r = rank[j] - base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) got[j][k] = sc->draw[r < 64u ? r : 63u][k];
+            for (int k = 0; k < S; ++k) got[j][k] = sc->draw[r < A ? r : 0u][k];
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const bool mine = ((pending >> j) & 1u) && rank[j] - base < 64u;
+            const bool mine = ((pending >> j) & 1u) && rank[j] - base < A;
 #pragma unroll
             for (int k = 0; k < S; ++k) s[k][j] = mine ? got[j][k] : s[k][j];
         }

@@ -638,3 +638,28 @@ def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg)
             b.RolloutFusedDevice(d, 8, n, 4)
         b.Seed(np.full(n, 7))                               # and back
         assert b.KernelName() == lean
+
+
+@pytest.mark.parametrize("n", [1024 + 5, 64 * 4 * 3 + 1, 7, 64 * 4 + 3])
+def test_wave_compacted_reset_when_every_lane_finishes_and_the_last_wave_is_partial(gpu_pkg, oracle, monkeypatch, n):
+    """reset_pending_wave hands a wave's finished sub-lanes to the wave's ACTIVE lanes.  Worst cases for that hand-off: every
+    sub-lane of every lane finishes in the same step (256 slots per full wave: four rounds of 64), and the batch's last wave
+    has only one or two active threads (rounds of one or two slots).  Every lane must come out holding exactly its own Philox
+    reset draw, and the compacted form must equal the per-thread drain loop."""
+    s = np.zeros((4, n), np.float32)
+    s[0] = 2.39; s[1] = 3.0                                        # x' = 2.39 + 0.02 * 3 > x_threshold for every lane
+    got = {}
+    for rf in (1, 0):
+        monkeypatch.setenv("GYMNET_VEC", "4")
+        monkeypatch.setenv("GYMNET_RESET_FORM", str(rf))
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=12345) as env:
+            assert env.KernelName() == f"step_kernel<CartPole,4,true,false,15,{rf}>"
+            env.Reset(); env.SetState(s)
+            tick = env.Tick
+            out = env.Step(np.ones(n, np.int32))
+            assert out.Done.all()
+            got[rf] = env.GetState()
+            assert np.array_equal(got[rf], oracle.cartpole_reset(SEED, 12345, tick, n))
+            out = env.Step(np.ones(n, np.int32))                      # and the NEXT step sees ordinary states again
+            assert not out.Done.any()
+    assert np.array_equal(got[0], got[1])
