@@ -12,6 +12,13 @@
  * second restatement (oracle/numpy_ref.py), against hand-derived closed forms and symmetry
  * properties (tests/test_oracle.py).  Philox4x32-10 IS pinned: it is checked against the
  * published Random123 known-answer vectors.
+ * Round 3 — the closest substitute this image allows: the reference's Step() body and constant initialisers are EVALUATED
+ * FROM THEIR OWN SOURCE TEXT by a small interpreter for the C# subset they use (oracle/evaluate_reference_text.py; C#'s
+ * numeric promotion implemented explicitly; build container only), the resulting input -> output vectors are committed
+ * (tests/golden/cartpole_reference_text.npz + its generating script), and ref_cartpole_step_f64 below reproduces all 3200 of
+ * them bit for bit.  That is still not an execution of the C# (the interpreter's typing rules are the residual assumption),
+ * so the header keeps saying "unpinned"; what it removes is every doubt about whether this restatement and the reference's
+ * text denote the same arithmetic.
  *
  * What is restated, and from where (paths relative to /root/reference):
  *   - CartPoleEnv constants      src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:24-36

@@ -663,3 +663,30 @@ def test_wave_compacted_reset_when_every_lane_finishes_and_the_last_wave_is_part
             out = env.Step(np.ones(n, np.int32))                      # and the NEXT step sees ordinary states again
             assert not out.Done.any()
     assert np.array_equal(got[0], got[1])
+
+
+def test_hip_step_against_vectors_evaluated_from_the_reference_text(gpu_pkg, golden):
+    """The HIP path against tests/golden/cartpole_reference_text.npz — CartPoleEnv.Step outputs obtained by evaluating the
+    reference's own source text (oracle/evaluate_reference_text.py; see tests/test_oracle.py): float32 state within 1e-5 of the
+    reference's float64 result, reward and steps_beyond_done exact, done exact except where the float64 value lies within float32
+    rounding of a threshold (the fixture puts 200 instances within +-2 float32 ulps of one on purpose)."""
+    g = golden("cartpole_reference_text")
+    n = g["state"].shape[1]
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=False) as env:
+        env.Reset()
+        env.SetState(g["state"].astype(np.float32))                 # the fixture's states are binary32 values
+        env.SetStepsBeyondDone(g["sbd"])
+        out = env.Step(g["action"])
+        got = env.GetState().astype(np.float64)
+        want = g["next_state"]
+        err = np.abs(got - want)
+        inr = slice(0, 2400)
+        assert err[:, inr].max() <= TOL                                             # in-range block: absolute bar of north_star
+        assert (err / np.maximum(1.0, np.abs(want))).max() <= TOL                   # wide block: values up to ~1e2
+        near = _near_threshold(want, 1e-6)
+        d = g["done"].astype(bool)
+        assert np.array_equal(out.Done[~near], d[~near]) and 100 <= near.sum() <= 260
+        same = out.Done == d
+        assert np.array_equal(out.Reward[same], g["reward"][same])
+        assert np.array_equal(env.GetStepsBeyondDone()[same], g["sbd_out"][same])
+        assert same[3000:].mean() > 0.5                                             # most of the +-2-ulp cases still agree

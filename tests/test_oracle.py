@@ -408,3 +408,56 @@ def test_pendulum_fast_fmod_is_exact(oracle):
         want = np.fmod(np.float32(x), np.float32(2 * np.float32(np.pi))) if np.isfinite(x) else np.float32("nan")
         got = np.float32(L.ref_fmod_2pi_kernel(x))
         assert (np.isnan(want) and np.isnan(got)) or (want == got and np.signbit(want) == np.signbit(got)), x
+
+
+def test_oracle_equals_vectors_evaluated_from_the_reference_text(oracle, golden):
+    """tests/golden/cartpole_reference_text.npz holds 3200 CartPoleEnv.Step input -> output vectors obtained by evaluating the
+    REFERENCE'S OWN SOURCE TEXT statement by statement (oracle/evaluate_reference_text.py: an interpreter for the subset of C#
+    that method uses, with C#'s numeric promotion — not a .NET runtime; generated in the build container by
+    tests/golden/make_reference_text_golden.py).  The float64 restatement must reproduce them BIT FOR BIT: states, the float
+    reward, the done flag, steps_beyond_done — in-range states, wide states, +-2 float32 ulps around both thresholds, actions
+    other than 0 / 1, and all three phases of the reward machine (sbd = -1, 0, > 0)."""
+    g = golden("cartpole_reference_text")
+    s, r, d, b = oracle.cartpole_step(g["state"], g["action"], g["sbd"], dtype=np.float64)
+    assert np.array_equal(s, g["next_state"])
+    assert np.array_equal(r, g["reward"]) and np.array_equal(d, g["done"]) and np.array_equal(b, g["sbd_out"])
+    assert np.array_equal(np.array(list(oracle.cartpole_constants().values())), g["constants"])
+    assert 500 < int(g["done"].sum()) < 2000 and set(g["reward"].tolist()) == {0.0, 1.0} and (g["sbd_out"] > 1).any()
+    # the independent NumPy writing agrees with the same vectors too
+    from oracle import numpy_ref
+    s2, r2, d2, b2 = numpy_ref.cartpole_step(g["state"], g["action"], g["sbd"])
+    assert np.array_equal(s2, g["next_state"]) and np.array_equal(r2, g["reward"]) and np.array_equal(d2, g["done"].astype(bool))
+    assert np.array_equal(b2, g["sbd_out"])
+
+
+def test_reference_text_vectors_are_reproducible_and_the_interpreter_is_strict():
+    """Build container only (needs /root/reference): regenerating the vectors from the reference text reproduces the committed
+    fixture exactly, and the interpreter refuses anything outside its grammar instead of guessing (the text is untrusted: it is
+    tokenised and parsed, never eval()'d)."""
+    import importlib.util
+    if not os.path.exists("/root/reference/src/Gym.Environments/Envs/Classic/CartPoleEnv.cs"):
+        pytest.skip("reference tree not present (GPU box)")
+    spec = importlib.util.spec_from_file_location("make_reference_text_golden", os.path.join(ROOT, "tests", "golden", "make_reference_text_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from oracle.evaluate_reference_text import Parser, ReferenceText, Value, _tokens
+    ref = ReferenceText()
+    state, action, sbd = mk.inputs()
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "cartpole_reference_text.npz")))
+    assert np.array_equal(state, g["state"]) and np.array_equal(action, g["action"]) and np.array_equal(sbd, g["sbd"])
+    for i in list(range(0, state.shape[1], 37)) + list(range(3000, 3200)):
+        s, r, d, b = ref.step(state[:, i], int(action[i]), int(sbd[i]))
+        assert np.array_equal(s, g["next_state"][:, i]) and r == g["reward"][i] and d == bool(g["done"][i]) and b == g["sbd_out"][i]
+    assert ref.reads == ["x", "x_dot", "theta", "theta_dot"] == ref.writes and ref.integrator_literal == "euler"
+    # C#'s numeric promotion as the interpreter implements it
+    env = {"f": Value(np.float32(0.1), "float"), "d": Value(0.1, "double")}
+    assert Parser(_tokens("f * f"), env).expr().t == "float" and Parser(_tokens("f * d"), env).expr().t == "double"
+    assert Parser(_tokens("(float) (12 * 2 * Math.PI / 360)"), env).expr().v == np.float32(12 * 2 * np.pi / 360)
+    assert Parser(_tokens("7 / 2"), env).expr().v == 3
+    for hostile in ("__import__", "f . g", "System.IO.File", "f [ 0 ]", "new Foo ( )"):
+        with pytest.raises(ValueError):
+            p = Parser(_tokens(hostile), env)
+            p.expr()
+            if p.peek() is not None:
+                raise ValueError("trailing tokens")
+    assert "eval(" not in open(os.path.join(ROOT, "oracle", "evaluate_reference_text.py")).read().replace("handed to eval()", "")
