@@ -187,6 +187,8 @@ class Parser:
             a = self.expr()
             self.take(")")
             x = float(a.v)                                      # Math.Cos / Math.Sin take and return double
+            if not math.isfinite(x):                            # .NET returns NaN for +-Infinity and NaN (Python raises)
+                return Value(float("nan"), F64)
             return Value(math.cos(x) if tok == "Math.Cos" else math.sin(x), F64)
         if tok == "Math.PI":
             return Value(math.pi, F64)

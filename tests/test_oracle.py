@@ -461,3 +461,44 @@ def test_reference_text_vectors_are_reproducible_and_the_interpreter_is_strict()
             if p.peek() is not None:
                 raise ValueError("trailing tokens")
     assert "eval(" not in open(os.path.join(ROOT, "oracle", "evaluate_reference_text.py")).read().replace("handed to eval()", "")
+
+
+def test_restatement_fixtures_agree_with_the_reference_text(golden):
+    """Build container only: the fixtures that were generated BY THE RESTATEMENT (teacher-forced tuples, threshold edges, the
+    steps_beyond_done stream and the reference-test-shaped 1000-iteration trace of CartpoleEnvironment.cs:19-27) re-derived with the
+    interpreter over the reference's own text (oracle/evaluate_reference_text.py) — bit for bit, including the free-running
+    trace's 1000 states and its episode lengths."""
+    if not os.path.exists("/root/reference/src/Gym.Environments/Envs/Classic/CartPoleEnv.cs"):
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle.evaluate_reference_text import ReferenceText
+    ref = ReferenceText()
+    g = golden("cartpole_teacher_forced")
+    for i in range(0, g["state"].shape[1], 7):
+        s, r, d, _ = ref.step(g["state"][:, i].astype(np.float64), int(g["action"][i]), -1)
+        assert np.array_equal(s, g["next_state"][:, i]) and r == g["reward"][i] and d == bool(g["done"][i])
+    g = golden("cartpole_edges")
+    for i in range(g["state"].shape[1]):
+        s, r, d, _ = ref.step(g["state"][:, i].astype(np.float64), int(g["action"][i]), -1)
+        assert np.array_equal(s, g["next_state"][:, i], equal_nan=True) and d == bool(g["done"][i]), i
+    g = golden("cartpole_steps_beyond_done")
+    s, sbd = g["start"].astype(np.float64), -1
+    for t in range(g["reward"].shape[0]):
+        s, r, d, sbd = ref.step(s, 1, sbd)
+        assert np.array_equal(s, g["states"][t]) and r == g["reward"][t] and d == bool(g["done"][t]) and sbd == g["sbd"][t]
+    g = golden("cartpole_reference_test_trace")                    # done = true; for i: if (done) Reset() else Step(i % 2)
+    done, k, lens, cur = True, 0, [], 0
+    s, sbd = None, -1
+    for i in range(1000):
+        if done:
+            s, sbd = g["resets"][k].astype(np.float64), -1
+            k += 1
+            done = False
+            if cur:
+                lens.append(cur)
+            cur = 0
+        else:
+            s, r, done, sbd = ref.step(s, i % 2, sbd)
+            cur += 1
+            assert r == 1.0
+        assert np.array_equal(s, g["it_state"][i]) and int(done) == g["it_done"][i], i
+    assert k == int(g["resets_used"]) and lens == list(g["episode_lengths"])
