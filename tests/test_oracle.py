@@ -502,3 +502,30 @@ def test_restatement_fixtures_agree_with_the_reference_text(golden):
             assert r == 1.0
         assert np.array_equal(s, g["it_state"][i]) and int(done) == g["it_done"][i], i
     assert k == int(g["resets_used"]) and lens == list(g["episode_lengths"])
+
+
+def test_observation_space_bounds_evaluated_from_the_reference_text(gymnet):
+    """CartPoleEnv's ctor builds `high = np.array(x_threshold * 2, float.MaxValue, theta_threshold_radians * 2, float.MaxValue)`
+    (CartPoleEnv.cs:46) and `ObservationSpace = new Box(-1 * high, high, np.float32)`.  The engine's gymnet_env_describe must
+    report exactly those bounds: the two products are evaluated from the reference's text (float * int folds in binary32)."""
+    if not os.path.exists("/root/reference/src/Gym.Environments/Envs/Classic/CartPoleEnv.cs"):
+        pytest.skip("reference tree not present (GPU box)")
+    import re as _re
+    from oracle.evaluate_reference_text import Parser, _tokens, load_reference, reference_constants
+    text = load_reference()
+    env = reference_constants(text)
+    args = _re.search(r"var high = np\.array\(([^;]*)\);", text).group(1).split(",")
+    assert len(args) == 4
+    fmax = float(np.finfo(np.float32).max)
+    want = []
+    for a in args:
+        a = a.strip()
+        if a == "float.MaxValue":
+            want.append(fmax)
+        else:
+            v = Parser(_tokens(a), env).expr()
+            assert v.t == "float"
+            want.append(float(v.v))
+    info = gymnet.env_describe(0)
+    assert list(info.obs_high[:4]) == want and list(info.obs_low[:4]) == [-w for w in want]
+    assert _re.search(r"ActionSpace = new Discrete\((\d+)\);", text).group(1) == str(info.action_n) == "2"
