@@ -32,3 +32,18 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+
+
+def test_group_leg_child_reports_instead_of_raising_without_a_gpu():
+    """bench.py's single-process gymnet_group_* leg runs in a fresh child; whatever happens to it (here: no GPU at all) comes back
+    as a record in the JSON line, never as an exception that would lose the headline."""
+    if os.path.exists("/dev/kfd"):
+        import pytest
+        pytest.skip("a GPU is present")
+    b = _bench()
+
+    class A:
+        env, num_envs, steps = "CartPole-v1", 1 << 10, 4
+    r = b.run_group_child(A, 2, timeout=240)
+    assert isinstance(r, dict) and ("error" in r or any("error" in v for v in r.values() if isinstance(v, dict)))
+    json.dumps(r)
