@@ -601,6 +601,10 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     // the computing waves' waits on memory instructions drop from 34 % to 21 % of their cycles, the s_barrier per tile adds more.
     if (const char *e = std::getenv("GYMNET_LDS_PIPE")) { if (std::atoi(e) == 1 && lds_ok) h->lcfg.lds_pipe = 1; }
     if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
+    // 64-thread workgroups for the dwordx4 kernels of the smallest payloads (< 40 MiB per vector step at dwordx4: MountainCar and
+    // Pendulum at 2^20 lanes): such a launch is ramp / drain bound, and one-wave workgroups ramp and retire faster — MountainCar 4.92-5.05
+    // -> 4.55-4.73 us, Pendulum 5.97 -> 5.88 us; CartPole (41 MiB) does not gain (tools/gpu_nt_ab_r03.sh, profiles/block_nt_probe_r03.txt)
+    if (h->lcfg.vec == 4 && step_bytes < ((size_t)40 << 20)) h->lcfg.block = 64;
     if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
 #undef CREATE_TRY
 #undef CREATE_HIP
