@@ -1,6 +1,8 @@
-"""Times the code-shape variants of the CartPole kernels at 2^20 lanes (bench workload) and checks that they agree bitwise:
-   one-step kernel: GYMNET_RESET_FORM 0 (per-thread drain loop) / 1 (wave-compacted reset through LDS);
-   fused rollout:   GYMNET_ROLLOUT_FORM 0..3 (bit 0: inline sub-lane loop, bit 1: wave-compacted reset).
+"""Times the reset forms of the CartPole one-step kernel at 2^20 lanes (bench workload) — GYMNET_RESET_FORM 0 (per-thread drain
+loop) / 1 (wave-compacted reset through LDS) — and the fused rollout kernel, and checks that everything agrees bitwise (forms
+with each other, fused with stepwise).  The fused kernel's code-shape variants of round 3 (GYMNET_ROLLOUT_FORM 0..3: bit 0 = the
+sub-lane loop written out, bit 1 = wave-compacted reset) were measured with this script at commit "Full-size (2^20) auto-reset
+parity tests ..." and then reduced to the winning shape; the numbers are in profiles/forms_probe_r03.txt.
 Usage: python tools/forms_probe.py [env] [n]"""
 import json
 import os
