@@ -41,7 +41,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 MIN_TIMED_SECONDS = 0.05   # repeat the K-step region until this much has been timed
 MAX_REPEATS = 2000
-WATCHDOG_EXIT = 3          # exit status of every rank when a collective section hung and the watchdog fired
+# Exit status of every rank when a SECONDARY section (the optional observation all-gather, the teardown) hung and the watchdog
+# fired.  By then the headline — the contract's product — has been measured and rank 0 prints it with `"watchdog_fired": <section>`
+# and the section's error record, so the hang is visible IN the line; the status stays 0 by default because a driver that
+# discards a line over a non-zero status would lose a valid N-GPU measurement to an optional figure.  GYMNET_BENCH_WATCHDOG_RC=3
+# (CI, tests) makes a fired watchdog fail the process as well.
+WATCHDOG_EXIT = int(os.environ.get("GYMNET_BENCH_WATCHDOG_RC", "0"))
 
 
 def parse():
@@ -581,8 +586,9 @@ def main():
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)    # where each rank was stuck
                 if rank == 0:
                     out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
+                    out["watchdog_fired"] = section
                     print(json.dumps(out), flush=True)
-                os._exit(WATCHDOG_EXIT)          # non-zero: a deadlocked section must be visible to the caller (never exec)
+                os._exit(WATCHDOG_EXIT)          # never exec; see WATCHDOG_EXIT for the status
         t = threading.Timer(seconds, fire)
         t.daemon = True
         t.start()
