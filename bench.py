@@ -557,25 +557,6 @@ def main():
     out = headline() if rank == 0 else {}
     emitted = threading.Lock()
 
-    # N > 1: what each rank ran on and measured by itself, and proof that the collective backend really spans `world` ranks
-    if use_dist:
-        props = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": props.name,
-                "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
-                "pid": os.getpid(), "kernel": local.KernelName(),
-                "events_us_per_step": median([r[1] for r in headline_rows if r[1] >= 0]) * 1e3 / K,
-                "wall_us_per_step": median([r[0] for r in headline_rows if r[1] < 0] or [r[0] for r in headline_rows]) * 1e6 / K}
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        probe = torch.tensor([rank + 1], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(probe, op=dist.ReduceOp.SUM)            # every rank contributes rank + 1: sum = N (N + 1) / 2
-        if rank == 0:
-            out["ranks"] = everyone
-            out["collective"] = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl",
-                                 "world_size": dist.get_world_size(),
-                                 "allreduce_sum_of_rank_plus_1": int(probe[0]), "expected": world * (world + 1) // 2,
-                                 "distinct_devices": len({(e["uuid"], e["pci_bus_id"], e["device"]) for e in everyone})}
-
     def emit_and_exit_on_timeout(section, seconds):
         """Watchdog for a secondary section that could hang rather than fail (a collective waiting for a peer): after `seconds`
         rank 0 prints the headline it already has, with the section marked as timed out, and every rank leaves."""
@@ -593,6 +574,33 @@ def main():
         t.daemon = True
         t.start()
         return t
+
+    # N > 1: what each rank ran on and measured by itself, and proof that the collective backend really spans `world` ranks.
+    # Nothing here may cost the headline: a rank that cannot describe itself still takes part in both collectives (so nobody
+    # waits for it), and the section runs under the watchdog.
+    if use_dist:
+        watchdog = emit_and_exit_on_timeout("ranks", 90)
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "pid": os.getpid()}
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            mine.update(name=props.name, uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None),
+                        kernel=local.KernelName(),
+                        events_us_per_step=median([r[1] for r in headline_rows if r[1] >= 0]) * 1e3 / K,
+                        wall_us_per_step=median([r[0] for r in headline_rows if r[1] < 0] or [r[0] for r in headline_rows]) * 1e6 / K)
+        except Exception as e:                                   # noqa: BLE001
+            mine["error"] = repr(e)[:200]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        probe = torch.tensor([rank + 1], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)            # every rank contributes rank + 1: sum = N (N + 1) / 2
+        if rank == 0:
+            out["ranks"] = everyone
+            out["collective"] = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl",
+                                 "world_size": dist.get_world_size(),
+                                 "allreduce_sum_of_rank_plus_1": int(probe[0]), "expected": world * (world + 1) // 2,
+                                 "distinct_devices": len({(e.get("uuid"), e.get("pci_bus_id"), e["device"]) for e in everyone})}
+        watchdog.cancel()
+
 
     extras = rank == 0 and world == 1 and not args.no_extras and not gather_in_region
     # Cross-check of the per-launch figure: 200 single launches, each bracketed by its own HIP-event pair on the
@@ -612,25 +620,31 @@ def main():
     # registers, gymnet_vecenv_rollout_fused_device) — open-loop rollouts only, so it is reported beside, not as, `value`.
     fused = None
     if extras:
-        fsteps = max(ring, (min(max(K, 1024), 2048) // ring) * ring)
-        local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
-        torch.cuda.synchronize(dev)
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record(stream)
-        for _ in range(fsteps // ring):
+        try:
+            fsteps = max(ring, (min(max(K, 1024), 2048) // ring) * ring)
             local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
-        f1.record(stream)
-        torch.cuda.synchronize(dev)
-        fused_us = f0.elapsed_time(f1) * 1e3 / fsteps
-        fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
-                 "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
+            torch.cuda.synchronize(dev)
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            for _ in range(fsteps // ring):
+                local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring)
+            f1.record(stream)
+            torch.cuda.synchronize(dev)
+            fused_us = f0.elapsed_time(f1) * 1e3 / fsteps
+            fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
+                     "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
+        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
+            fused = {"error": repr(e)[:300]}
 
     # Secondary figure, NEVER `value`: the NDArray-shaped host boundary a C# VectorEnv.Step(NDArray) reaches — gymnet_vecenv_step
     # with caller-owned host buffers, PCIe both ways inside the call (VecEnvWrapper.cs:22-24, Step.cs:8-10): (a) ordinary
     # pageable caller memory, (b) the library's pinned, device-mapped buffers (gymnet_vecenv_host_buffers: zero staging).
     host_boundary = None
     if extras and not args.no_host_boundary:
-        host_boundary = measure_host_boundary(pkg, args.env, n, dev_index, seed, local.AlgorithmicBytesPerStep)
+        try:
+            host_boundary = measure_host_boundary(pkg, args.env, n, dev_index, seed, local.AlgorithmicBytesPerStep)
+        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
+            host_boundary = {"error": repr(e)[:300]}
 
     # Secondary figures for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
     # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
@@ -687,7 +701,7 @@ def main():
     copy_bw = None
     if extras:
         copy_bw = {}
-        for label, mib in (("32MiB", 32), ("2GiB", 2048)):
+        for label, mib in (("32MiB", 32), ("2GiB", 2048)) if torch.cuda.mem_get_info(dev)[0] > (6 << 30) else (("32MiB", 32),):
             src = torch.empty(mib * (1 << 18), dtype=torch.float32, device=dev).normal_()
             dst = torch.empty_like(src)
             for _ in range(3):
@@ -760,9 +774,12 @@ def main():
             if not args.no_group_leg and not gather_in_region:
                 out["group_single_process"] = run_group_child(args, world)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
-            if world > 1:
-                out["cpu_baseline"]["when"] = "on rank 0's host after the other ranks had exited (no GPU timing live)"
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+                if world > 1:
+                    out["cpu_baseline"]["when"] = "on rank 0's host after the other ranks had exited (no GPU timing live)"
+            except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
+                out["cpu_baseline"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
 
 
