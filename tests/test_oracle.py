@@ -529,3 +529,22 @@ def test_observation_space_bounds_evaluated_from_the_reference_text(gymnet):
     info = gymnet.env_describe(0)
     assert list(info.obs_high[:4]) == want and list(info.obs_low[:4]) == [-w for w in want]
     assert _re.search(r"ActionSpace = new Discrete\((\d+)\);", text).group(1) == str(info.action_n) == "2"
+
+
+def test_discrete_contains_evaluated_from_the_reference_text(oracle):
+    """Discrete.Contains(int) (src/Gym/Spaces/Discrete.cs:38-40) — the rule GYMNET_FLAG_VALIDATE_ACTIONS applies on the device —
+    evaluated from the reference's text for every x in [-3, N + 3) and several N, against the oracle's restatement (which the
+    GPU test test_validate_actions compares the kernel with)."""
+    path = "/root/reference/src/Gym/Spaces/Discrete.cs"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present (GPU box)")
+    import re as _re
+    from oracle.evaluate_reference_text import Parser, Value, _strip_comments, _tokens
+    text = _strip_comments(open(path, encoding="utf-8-sig").read())
+    body = _re.search(r"public bool Contains\(int x\)\s*\{\s*return ([^;]+);\s*\}", text).group(1)
+    toks = _tokens(body)
+    L = oracle.lib()
+    for n in (1, 2, 3, 7):
+        for x in range(-3, n + 3):
+            want = Parser(toks, {"x": Value(x, "int"), "N": Value(n, "int"), "Start": Value(0, "int")}).expr()
+            assert want.t == "bool" and bool(L.ref_discrete_contains(x, n)) == bool(want.v), (x, n)
