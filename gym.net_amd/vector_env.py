@@ -44,16 +44,20 @@ def _host(a):
 class BatchStep:
     """What `Step[]` (IVecEnv.cs:15) becomes at 2^20 lanes: three arrays.  Indexing / iterating yields the
     reference's per-env Step records (Step.cs:7-20), materialised lazily."""
-    __slots__ = ("Observation", "Reward", "Done", "Information")
+    __slots__ = ("Observation", "Reward", "Done", "Information", "Truncated")
 
-    def __init__(self, observation, reward, done, information=None):
+    def __init__(self, observation, reward, done, information=None, truncated=None):
         self.Observation, self.Reward, self.Done, self.Information = observation, reward, done, information
+        self.Truncated = truncated          # bool [N]: the episode ended by the max_episode_steps extension (done byte, bit 1)
 
     def __len__(self):
         return self.Reward.shape[0]
 
     def __getitem__(self, i):
-        return Step(self.Observation[i], float(self.Reward[i]), bool(self.Done[i]), self.Information)
+        info = self.Information
+        if self.Truncated is not None and self.Truncated[i]:
+            info = {"TimeLimit.truncated": True}                  # upstream gym's TimeLimit convention (the reference has none, SURVEY F6)
+        return Step(self.Observation[i], float(self.Reward[i]), bool(self.Done[i]), info)
 
     def __iter__(self):
         for i in range(len(self)):
@@ -200,7 +204,7 @@ class VectorEnv:
         else:
             a = self._actions(action)
             capi.check(self._lib.gymnet_vecenv_step(self._h, _host(a), _host(obs), _host(rew), _host(done)))
-        return BatchStep(obs, rew, done.astype(bool), None)
+        return BatchStep(obs, rew, done.astype(bool), None, truncated=(done & 2) != 0)
 
     def HostBuffers(self):
         """(actions, obs, reward, done): numpy views over the library's page-locked, device-mapped host buffers
@@ -243,12 +247,12 @@ class VectorEnv:
     def StepWait(self):
         obs, rew, done = self._outs()
         capi.check(self._lib.gymnet_vecenv_step_wait(self._h, _host(obs), _host(rew), _host(done)))
-        return BatchStep(obs, rew, done.astype(bool), None)
+        return BatchStep(obs, rew, done.astype(bool), None, truncated=(done & 2) != 0)
 
     def Read(self):
         obs, rew, done = self._outs()
         capi.check(self._lib.gymnet_vecenv_read(self._h, _host(obs), _host(rew), _host(done)))
-        return BatchStep(obs, rew, done.astype(bool), None)
+        return BatchStep(obs, rew, done.astype(bool), None, truncated=(done & 2) != 0)
 
     def SampleActions(self, seed=0, tick=0):
         """ActionSpace.Sample() for every lane, on the device (TrainingPlaySession.cs:46-49 batched)."""
@@ -538,7 +542,7 @@ class GroupVectorEnv:
             raise ValueError("Number of actions passed should be equals to number of environments")
         obs, rew, done = np.empty((n, self.ObsDim), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
         capi.check(self._lib.gymnet_group_step(self._g, _host(a), _host(obs), _host(rew), _host(done)))
-        return BatchStep(obs, rew, done.astype(bool), None)
+        return BatchStep(obs, rew, done.astype(bool), None, truncated=(done & 2) != 0)
 
     # device-resident path
     def ResetDevice(self):
@@ -591,8 +595,12 @@ class GpuEnv:
     tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35) runs unmodified on the engine."""
     ENV = "CartPole-v1"
 
-    def __init__(self, device=0, seed=0, validate_actions=False):
-        self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions)
+    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0):
+        """max_episode_steps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; an extension: the
+        reference has no time limit): the step that reaches the limit returns Done with
+        Information["TimeLimit.truncated"] = True — the same shape as the C# GpuEnv (csharp/GpuEnv.cs)."""
+        self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions,
+                            episode_stats=max_episode_steps > 0, max_episode_steps=max_episode_steps)
         self.ActionSpace, self.ObservationSpace = self._v.ActionSpace, self._v.ObservationSpace
         self.Metadata, self.RewardRange = self._v.Metadata, self._v.RewardRange
         self._pending = None

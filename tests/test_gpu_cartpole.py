@@ -690,3 +690,31 @@ def test_hip_step_against_vectors_evaluated_from_the_reference_text(gpu_pkg, gol
         assert np.array_equal(out.Reward[same], g["reward"][same])
         assert np.array_equal(env.GetStepsBeyondDone()[same], g["sbd_out"][same])
         assert same[3000:].mean() > 0.5                                             # most of the +-2-ulp cases still agree
+
+
+def test_single_instance_facade_with_the_time_limit_extension(gpu_pkg):
+    """GpuEnv(max_episode_steps=k): upstream gym's TimeLimit on the single-instance façade (an extension; the reference has none).
+    A MountainCar episode under a constant action never reaches the goal, so it ends exactly at the limit, by truncation, with
+    Information["TimeLimit.truncated"]; CartPole's natural termination carries no such flag."""
+    mc = gpu_pkg.MountainCarEnv(seed=3, max_episode_steps=25)
+    try:
+        mc.Reset()
+        for t in range(1, 26):
+            obs, reward, done, info = mc.Step(1)
+            assert reward == -1.0 and done == (t == 25)
+        assert info == {"TimeLimit.truncated": True}
+        mc.Reset()
+        obs, reward, done, info = mc.Step(1)
+        assert not done and info is None                              # a reset starts the count again
+    finally:
+        mc.CloseEnvironment()
+    cp = gpu_pkg.CartPoleEnv(seed=3, max_episode_steps=500)
+    try:
+        cp.Reset()
+        for t in range(200):
+            obs, reward, done, info = cp.Step(1)                          # always push right: falls within a dozen steps
+            if done:
+                break
+        assert done and t < 30 and info is None
+    finally:
+        cp.CloseEnvironment()
