@@ -119,6 +119,22 @@ __device__ __forceinline__ void sincos_small(T x, T &s_out, T &c_out) {
     }
 }
 
+// sin / cos for |x| <= 0.785 (< pi/4), where the range reduction of sincos_bounded is the identity: n = rint(x * 2/pi) = 0
+// (|x * 2/pi| < 0.4998), each fma(-C, 0, r) returns r bit for bit (also for +-0), and the quadrant fix-up with q = 0 changes
+// nothing.  So evaluating the two polynomials on x itself gives EXACTLY the bits of sincos_f32(x) — 14 instructions shorter
+// (multiply, rint, three fma, float->int, eight quadrant instructions).  CartPole's pole angle is below 0.21 rad until the
+// episode ends, so its step takes this path whenever every lane of the wave qualifies (kernels.hip: advance_all).
+constexpr float kSmallAngle = 0.785f;
+__device__ __forceinline__ void sincos_tiny(float x, float &s_out, float &c_out) {
+    const float z = x * x;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    s_out = fmaf(x * z, ps, x);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    c_out = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+}
+
 // BOUNDED = true drops the OCML fallback: for callers whose argument is bounded by construction (Acrobot's wrapped
 // angles and RK4 stage angles, |x| < 16).  Same bits as the full version for every |x| <= 65536; beyond that the result
 // is unspecified (finite garbage or NaN, never a hang).  It exists because the ten inlined Payne-Hanek fallbacks made the
@@ -176,12 +192,19 @@ struct CartPole {
 
     __device__ __forceinline__ static float div_tm(float x) { return DivByTotalMass<>::apply(x); }
 
+    // The state component whose magnitude decides whether the step may use sincos_tiny (SMALL_ANGLE), and the bound
+    static constexpr bool HAS_SMALL_ANGLE_PATH = true;
+    static constexpr int ANGLE_ROW = 2;
+
     // :146-167.  Any action != 1 pushes left (validity is only Debug.Assert'ed, :139).
+    // SMALL_ANGLE: the caller guarantees |theta| <= kSmallAngle; the results are bit-identical either way (sincos_tiny).
+    template <bool SMALL_ANGLE = false>
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const float force = (a == 1) ? force_mag : -force_mag;                                   // :146
         float sintheta, costheta;
-        sincos_f32(theta, sintheta, costheta);                                                   // :147-148
+        if constexpr (SMALL_ANGLE) sincos_tiny(theta, sintheta, costheta);
+        else sincos_f32(theta, sintheta, costheta);                                              // :147-148
         // `/ total_mass` below is IEEE division by a constant, evaluated as DivByTotalMass (bit-identical)
         const float temp = div_tm(force + polemass_length * theta_dot * theta_dot * sintheta);   // :149
         const float thetaacc = (gravity * sintheta - costheta * temp)
@@ -228,6 +251,7 @@ struct Pendulum {
     static constexpr bool BOX_ACTION = true;
     static constexpr bool PACKED2 = false;
     static constexpr bool PIPELINED = false;
+    static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = float;                    // Box(-2, 2, (1,))
     static constexpr float PI = 3.14159265358979323846f;
 
@@ -297,6 +321,7 @@ struct MountainCar {
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = false;
     static constexpr bool PIPELINED = false;
+    static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = int32_t;                  // Discrete(3)
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
@@ -337,6 +362,7 @@ struct Acrobot {
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = true;    // step_observe_x2: two envs per thread on v_pk_*_f32
     static constexpr bool PIPELINED = true;  // step_kernel_pipe: ITEMS lanes per thread, loads / arithmetic / stores overlapped
+    static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = int32_t;                  // Discrete(3): torque = a - 1
     static constexpr float PI = 3.14159265358979323846f;
 
