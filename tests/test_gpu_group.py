@@ -535,3 +535,34 @@ def test_group_flags_validation_and_bookkeeping(gpu_pkg, oracle):
     capi.check(lib.gymnet_sample_discrete_masked_device(0, None, C.c_void_p(out.data_ptr()), cnt, 5, 10, None, 0, 99, 1234, 6))   # no mask: Discrete.cs:27
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), oracle.discrete_sample(99, 1234, 6, 5, 10, cnt))
+
+
+@pytest.mark.gpu
+def test_driver_shaped_bench_line_carries_the_contract(gpu_pkg):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` — the driver's N = 1 command — prints ONE JSON line with the contract's
+    keys, the `roofline` and `cpu_baseline` objects, and the secondary figures (none of which may ever be `value`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"] == "env-steps/sec" and j["unit"] == "env-steps/s" and j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["value"] > 5e10 and abs(j["value"] - (1 << 20) / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
+    assert "CartPole-v1 batched, batch=1048576" in j["config"]["workload"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["kernel"] == "step_kernel<CartPole,4,true,false,15,1>" and rf["algorithmic_bytes_per_launch"] == 41 << 20
+    assert abs(rf["achieved"] - 41 * (1 << 20) / (rf["launch_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"] and 0.4 < rf["frac"] < 1.0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e6 and cb["unit"] == "env-steps/s" and cb["sample"]
+    assert j["fused_rollout"]["us_per_step"] < j["ms_per_step"] * 1e3
+    hb = j["host_boundary"]
+    assert hb["pinned_library_buffers"]["ms_per_step"] <= hb["pageable_caller_buffers"]["ms_per_step"] * 1.1
+    assert hb["pinned_library_buffers"]["env_steps_per_sec"] < 0.1 * j["value"]           # PCIe-inclusive: never the headline
+    oc = j["other_configs_2p20"]
+    assert oc["Pendulum-v1"]["kernel"].startswith("step_kernel<Pendulum,4,true") and oc["Acrobot-v1"]["kernel"] == "step_kernel_pipe<Acrobot,4,true,15>"
+    assert all(0.3 < oc[k]["frac_of_peak"] < 1.0 for k in oc)
+    assert j["hbm_resident_2p27"]["num_envs"] == 1 << 27 and 0.5 < j["hbm_resident_2p27"]["frac_of_peak"] < 1.0
