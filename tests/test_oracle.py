@@ -548,3 +548,25 @@ def test_discrete_contains_evaluated_from_the_reference_text(oracle):
         for x in range(-3, n + 3):
             want = Parser(toks, {"x": Value(x, "int"), "N": Value(n, "int"), "Start": Value(0, "int")}).expr()
             assert want.t == "bool" and bool(L.ref_discrete_contains(x, n)) == bool(want.v), (x, n)
+
+
+def test_reset_distribution_parameters_evaluated_from_the_reference_text(oracle):
+    """CartPoleEnv.Reset() (CartPoleEnv.cs:63-67): `steps_beyond_done = -1; state = random.uniform(low, high, count)`.  The three
+    arguments are evaluated from the reference's text; the engine's Philox reset (a different generator by design: north_star)
+    must draw `count` components per lane inside [low, high) with the uniform's mean and variance, and leave sbd at the text's value."""
+    if not os.path.exists("/root/reference/src/Gym.Environments/Envs/Classic/CartPoleEnv.cs"):
+        pytest.skip("reference tree not present (GPU box)")
+    import re as _re
+    from oracle.evaluate_reference_text import Parser, _tokens, load_reference
+    text = load_reference()
+    body = text[text.index("public override NDArray Reset()"):]
+    body = body[:body.index("return")]
+    sbd0 = Parser(_tokens(_re.search(r"steps_beyond_done = ([^;]+);", body).group(1)), {}).expr()
+    args = _re.search(r"state = random\.uniform\(([^;]*)\);", body).group(1).split(",")
+    low, high, count = (Parser(_tokens(a), {}).expr() for a in args)
+    assert (sbd0.v, low.v, high.v, count.v) == (-1, -0.05, 0.05, 4) and count.t == "int"
+    s = oracle.cartpole_reset(0x5EED, 0, 0, 200_000)
+    assert s.shape[0] == count.v and s.min() >= low.v and s.max() < high.v
+    assert abs(float(s.mean()) - (low.v + high.v) / 2) < 2e-4 and abs(float(s.std()) - (high.v - low.v) / np.sqrt(12)) < 2e-4
+    st, r, d, b = oracle.cartpole_step(s.astype(np.float64), np.ones(s.shape[1], np.int32))
+    assert (b[d == 0] == sbd0.v).all()                                  # a fresh episode starts from the text's steps_beyond_done
