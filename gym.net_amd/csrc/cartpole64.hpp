@@ -1,0 +1,118 @@
+// cartpole64.hpp — CartPole in the REFERENCE'S OWN arithmetic: binary64 state, the literal operation sequence of
+// src/Gym.Environments/Envs/Classic/CartPoleEnv.cs:141-167 (paths relative to the Gym.NET tree), binary32-valued constants
+// widened at use exactly as C# widens its `const float`s.  Selected per handle with GYMNET_FLAG_F64 (include/gymnet_amd.h).
+//
+// Why it exists: the reference keeps `state` as a float64 NDArray and returns THAT as the
+// observation (:166,185).  The float32 engine is within 1e-5 per teacher-forced step, but free-running float32 leaves 1e-5 after
+// ~50 steps and can end an episode one step early or late; this mode reproduces the reference's states to the last few ulps and
+// therefore its episode lengths, free-running, for as long as the caller likes.  It moves 73 B per env-step instead of 41.
+//
+// Compiled with -ffp-contract=off like the rest of the library: every operation below is one IEEE-754 binary64 operation in
+// the order written, `/` is correctly rounded division, so the CPU restatement (oracle/classic_control_ref.c:
+// ref_cartpole_step_f64_kernel) reproduces every result BIT FOR BIT.  The single place where this file and the reference can
+// differ is sin / cos: the reference calls Math.Sin / Math.Cos (the platform's libm, <= 1 ulp), this file evaluates its own
+// (below, <= 1.5 ulp measured) — a last-bit difference in sin(theta) that moves a state by <= 1e-17 per step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace gymnet {
+
+// ---------------------------------------------------------------------------------------------
+// sin / cos in binary64 from IEEE mul / add / fma / rint only.
+//   reduction: n = rint(x * 2/pi); r = ((x - n P1) - n P2) - n P3 with pi/2 = P1 + P2 + P3 + ..., P1 and P2 cut to 33 bits so
+//     that n * P1 and n * P2 are exact for |n| < 2^20 (the fma then rounds once per step); |x| <= 2^19 * pi/2.
+//   kernels on |r| <= pi/4: the minimax polynomials published with Sun's fdlibm (k_sin.c / k_cos.c: degree 13 / 14, the same
+//     coefficients every libm descended from it uses), evaluated in Horner form; the cosine as w + ((1 - w) - z/2 + z^2 C(z))
+//     with w = 1 - z/2, which keeps the rounding of 1 - z/2 out of the result.
+// Accuracy against a 200-bit reference over |x| <= 8e5: <= 1.5 ulp (tests/test_oracle.py); for |x| <= pi/4 (every CartPole
+// pole angle before the episode ends) n = 0, the reduction is the identity and the error is the polynomials' (< 1 ulp).
+// Larger arguments (a pole left spinning for ~1e5 steps after `done`), infinities and NaN take the OCML routines.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out) {
+    if (__builtin_expect(!(__builtin_fabs(x) <= 823549.0), 0)) {
+        s_out = ::sin(x);
+        c_out = ::cos(x);
+        return;
+    }
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);      // P1: first 33 bits of pi/2  (0x3FF921FB54400000)
+    r = __builtin_fma(-n, 6.07710050630396597660e-11, r);             // P2: next 33 bits            (0x3DD0B4611A600000)
+    r = __builtin_fma(-n, 2.02226624879595063154e-21, r);             // P3: pi/2 - P1 - P2 rounded  (0x3BA3198A2E037073)
+    const double z = r * r;
+    // sin r = r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
+    double ps = __builtin_fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double s = __builtin_fma(r * z, ps, r);
+    // cos r = w + (((1 - w) - z/2) + z (z (C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6))))))),  w = 1 - z/2
+    double pc = __builtin_fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant: sin x = {s, c, -s, -c}[n mod 4], cos x = {c, -s, -c, s}[n mod 4]
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    s_out = (q & 2) ? -ss : ss;
+    c_out = ((q + 1) & 2) ? -cc : cc;
+}
+
+// 53-bit uniform in [0, 1) from two Philox words, the construction NumPy's random_sample() uses for its doubles
+// ((a >> 5) * 2^26 + (b >> 6)) / 2^53 — the reference draws its reset state with NumSharp's port of that generator,
+// CartPoleEnv.cs:65): exactly representable, so low + (high - low) * u below rounds once per operation.
+__host__ __device__ __forceinline__ double u01_53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+// second Philox call of a float64 reset draw: same counter (lane, tick), key ^ this constant (a stream of its own)
+constexpr uint64_t kStreamReset64 = 0xC2B2AE3D27D4EB4Full;
+
+struct CartPole64 {
+    static constexpr int S = 4;
+    // :24-36 — the float32 VALUES of the C# consts (total_mass, polemass_length const-folded in float), widened at use
+    static constexpr float gravity = 9.8f;
+    static constexpr float masspole = 0.1f;
+    static constexpr float total_mass = 0.1f + 1.0f;
+    static constexpr float length = 0.5f;
+    static constexpr float polemass_length = 0.1f * 0.5f;
+    static constexpr float force_mag = 10.0f;
+    static constexpr float tau = 0.02f;
+    static constexpr float theta_threshold = 0.20943951606750488f;   // (float)(12 * 2 * Math.PI / 360)
+    static constexpr float x_threshold = 2.4f;
+
+    // :141-167, statement for statement; C#'s usual arithmetic conversions written out (float op double -> double)
+    __device__ __forceinline__ static void step(double (&st)[S], int32_t a, bool &done) {
+        double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];                                  // :141-144
+        const float force = a == 1 ? force_mag : -force_mag;                                                // :146
+        double sintheta, costheta;
+        sincos_f64(theta, sintheta, costheta);                                                              // :147-148
+        const double temp = ((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta) / (double)total_mass;   // :149
+        const double thetaacc = ((double)gravity * sintheta - costheta * temp)
+                                / ((double)length * (4.0 / 3.0 - (double)masspole * costheta * costheta / (double)total_mass)); // :150
+        const double xacc = temp - (double)polemass_length * thetaacc * costheta / (double)total_mass;       // :151
+        x = x + (double)tau * x_dot;                                                                        // :154
+        x_dot = x_dot + (double)tau * xacc;                                                                 // :155
+        theta = theta + (double)tau * theta_dot;                                                            // :156
+        theta_dot = theta_dot + (double)tau * thetaacc;                                                     // :157
+        st[0] = x; st[1] = x_dot; st[2] = theta; st[3] = theta_dot;                                         // :166
+        done = x < -(double)x_threshold || x > (double)x_threshold
+               || theta < -(double)theta_threshold || theta > (double)theta_threshold;                      // :167
+    }
+
+    // :63-67 — state = uniform(-0.05, 0.05, 4) in float64: low + (high - low) * u, u with 53 random bits
+    __device__ __forceinline__ static void reset(double (&st)[S], uint64_t key, uint64_t lane, uint64_t tick) {
+        const PhiloxWords a = lane_words(key, lane, tick);                      // the words the float32 engine draws from, too
+        const PhiloxWords b = lane_words(key ^ kStreamReset64, lane, tick);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k] = -0.05 + (0.05 - -0.05) * u01_53(a.w[k], b.w[k]);
+    }
+};
+
+}  // namespace gymnet

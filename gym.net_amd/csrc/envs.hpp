@@ -216,7 +216,16 @@ struct CartPole {
         const float ntheta = theta + tau * theta_dot;
         const float ntheta_dot = theta_dot + tau * thetaacc;
         s[0] = nx; s[1] = nx_dot; s[2] = ntheta; s[3] = ntheta_dot;                              // :166
-        done = nx < -x_threshold || nx > x_threshold || ntheta < -theta_threshold || ntheta > theta_threshold;  // :167
+        // :167 — the INTEGER output.  The reference forms x + tau * x_dot and theta + tau * theta_dot in binary64 (:154,156:
+        // double state, tau widened from its float const) and compares THOSE with the widened float thresholds.  The flag is
+        // therefore derived from the same two binary64 sums, not from the binary32 nx / ntheta stored above: for every
+        // float32-representable input it is the reference's flag exactly (tau * x_dot is a 48-bit product, exact in binary64,
+        // so fma(tau, x_dot, x) IS the reference's x + tau * x_dot; |v| > thr is the four strict comparisons, false for NaN).
+        // Comparing the rounded binary32 values instead flips the flag for inputs within ~2 float32 ulps of a threshold
+        // (22 of the 200 such vectors in tests/golden/cartpole_reference_text.npz).  4 conversions + 2 v_fma_f64 + 2 v_cmp.
+        const double vx = __builtin_fma((double)tau, (double)x_dot, (double)x);
+        const double vtheta = __builtin_fma((double)tau, (double)theta_dot, (double)theta);
+        done = __builtin_fabs(vx) > (double)x_threshold || __builtin_fabs(vtheta) > (double)theta_threshold;
         reward = 1.0f;   // the steps_beyond_done rule (:168-183) is applied by the kernel, which owns sbd
     }
 

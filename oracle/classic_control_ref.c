@@ -165,7 +165,7 @@ int64_t ref_check_div_total_mass(const int32_t *biased_exponents, int32_t count)
 
 /* The same Step() in the HIP kernel's arithmetic: every operation in binary32 with the same
  * binary32 constants (4.0f/3.0f for the double literal), same association order, the kernel's own
- * sin/cos, thresholds compared in binary32.  This is NOT the reference's arithmetic; it exists so
+ * sin/cos; the done flag from the binary64 sums the reference compares.  This is NOT the reference's arithmetic; it exists so
  * tests can require the kernel to match it BIT FOR BIT (all operations are IEEE on both sides; the
  * kernel's constant divisions are proven equal to the plain `/` written here), in addition to the
  * north_star bar of 1e-5 against ref_cartpole_step_f64. */
@@ -182,9 +182,13 @@ int ref_cartpole_step_f32(float *state, int action, int *sbd, float *reward) {
     x_dot = x_dot + CP_TAU * xacc;
     theta = theta + CP_TAU * theta_dot;
     theta_dot = theta_dot + CP_TAU * thetaacc;
+    /* the integer output is the reference's own: :154,156 evaluated in binary64 from the (float32-representable) inputs and
+     * compared as at :167 — what the kernel does (envs.hpp CartPole::step); the stored state stays binary32 */
+    double vx = (double)state[0] + (double)CP_TAU * (double)state[1];
+    double vtheta = (double)state[2] + (double)CP_TAU * (double)state[3];
     state[0] = x; state[1] = x_dot; state[2] = theta; state[3] = theta_dot;
-    int done = x < -CP_X_THRESHOLD || x > CP_X_THRESHOLD
-            || theta < -CP_THETA_THRESHOLD || theta > CP_THETA_THRESHOLD;
+    int done = vx < -(double)CP_X_THRESHOLD || vx > (double)CP_X_THRESHOLD
+            || vtheta < -(double)CP_THETA_THRESHOLD || vtheta > (double)CP_THETA_THRESHOLD;
     if (!done) { *reward = 1.0f; }
     else if (*sbd == -1) { *sbd = 0; *reward = 1.0f; }
     else { *sbd += 1; *reward = 0.0f; }

@@ -55,9 +55,13 @@ def cartpole_step(state, action, sbd, dtype=f64):
     nx_dot = x_dot + tau * xacc                                                     # :155
     ntheta = theta + tau * theta_dot                                                # :156
     ntheta_dot = theta_dot + tau * thetaacc                                         # :157
-    xt, tt = t(X_THRESHOLD), t(THETA_THRESHOLD)
+    # :167 on the float64 sums of :154,156 for either dtype: the kernel (dtype=f32) keeps float32 state but derives the integer
+    # done flag from the reference's own float64 comparison (envs.hpp CartPole::step)
+    vx = x.astype(f64) + f64(TAU) * x_dot.astype(f64)
+    vt = theta.astype(f64) + f64(TAU) * theta_dot.astype(f64)
+    xt, tt = f64(X_THRESHOLD), f64(THETA_THRESHOLD)
     with np.errstate(invalid="ignore"):
-        done = (nx < -xt) | (nx > xt) | (ntheta < -tt) | (ntheta > tt)              # :167
+        done = (vx < -xt) | (vx > xt) | (vt < -tt) | (vt > tt)                      # :167
     first = done & (sbd == -1)
     later = done & (sbd != -1)
     reward = np.where(later, f32(0.0), f32(1.0)).astype(f32)                        # :168-183

@@ -430,6 +430,29 @@ def test_oracle_equals_vectors_evaluated_from_the_reference_text(oracle, golden)
     assert np.array_equal(b2, g["sbd_out"])
 
 
+def test_kernel_semantics_give_the_reference_integer_outputs_on_every_vector(oracle, golden):
+    """Row a3: float32 state, but done / reward / steps_beyond_done exactly the reference's for EVERY float32
+    input — the kernel semantics derive the flag from the float64 sums x + tau*x_dot, theta + tau*theta_dot the reference
+    compares (CartPoleEnv.cs:154,156,167), not from their float32 roundings.  All 3200 reference-text vectors (200 of them within
+    +-2 float32 ulps of a threshold) and the 78 constructed edge cases, for both twins (C and NumPy); a float32 comparison
+    would flip 22 of them."""
+    from oracle import numpy_ref
+    g = golden("cartpole_reference_text")
+    assert np.array_equal(g["state"], g["state"].astype(np.float32).astype(np.float64))     # the inputs ARE float32 values
+    s, r, d, b = oracle.cartpole_step(g["state"].astype(np.float32), g["action"], g["sbd"], dtype=np.float32)
+    assert np.array_equal(d, g["done"]) and np.array_equal(r, g["reward"]) and np.array_equal(b, g["sbd_out"])
+    s2, r2, d2, b2 = numpy_ref.cartpole_step(g["state"].astype(np.float32), g["action"], g["sbd"], dtype=np.float32)
+    assert np.array_equal(d2, g["done"].astype(bool)) and np.array_equal(r2, g["reward"]) and np.array_equal(b2, g["sbd_out"])
+    # what a float32 comparison of the float32 next state would have answered: differs on the +-2-ulp block (the bug this guards)
+    xt, tt = np.float32(2.4), np.float32(0.20943951606750488)
+    with np.errstate(invalid="ignore"):
+        naive = (s[0] < -xt) | (s[0] > xt) | (s[2] < -tt) | (s[2] > tt)
+    assert 1 <= int((naive != g["done"].astype(bool)).sum()) <= 64
+    e = golden("cartpole_edges")
+    _, _, de, _ = oracle.cartpole_step(e["state"], e["action"], dtype=np.float32)
+    assert np.array_equal(de, e["done"])
+
+
 def test_reference_text_vectors_are_reproducible_and_the_interpreter_is_strict():
     """Build container only (needs /root/reference): regenerating the vectors from the reference text reproduces the committed
     fixture exactly, and the interpreter refuses anything outside its grammar instead of guessing (the text is untrusted: it is
