@@ -42,11 +42,12 @@ HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_M
 MIN_TIMED_SECONDS = 0.05   # repeat the K-step region until this much has been timed
 MAX_REPEATS = 2000
 # Exit status of every rank when a SECONDARY section (the optional observation all-gather, the teardown) hung and the watchdog
-# fired.  By then the headline — the contract's product — has been measured and rank 0 prints it with `"watchdog_fired": <section>`
-# and the section's error record, so the hang is visible IN the line; the status stays 0 by default because a driver that
-# discards a line over a non-zero status would lose a valid N-GPU measurement to an optional figure.  GYMNET_BENCH_WATCHDOG_RC=3
-# (CI, tests) makes a fired watchdog fail the process as well.
-WATCHDOG_EXIT = int(os.environ.get("GYMNET_BENCH_WATCHDOG_RC", "0"))
+# fired: NON-ZERO.  A GPU process whose collective hung must not leave with status 0.  The headline has been measured
+# by then and rank 0 prints it FIRST — with `"watchdog_fired": <section>` and the section's error record — so the measurement is
+# in the log either way; spawn_ranks() propagates the status.  (GYMNET_BENCH_WATCHDOG_RC overrides the value.)
+WATCHDOG_EXIT = int(os.environ.get("GYMNET_BENCH_WATCHDOG_RC", "3"))
+# xGMI: 7 links per GPU, ~153 GB/s each (/opt/skills/guides/MI355X_MICROARCH.md) — the SURVEY §8(e) all-gather model
+XGMI_LINK_GBPS = 153.0
 
 
 def parse():
@@ -70,6 +71,10 @@ def parse():
     p.add_argument("--no-group-leg", action="store_true", help="N > 1: skip the single-process gymnet_group_* leg")
     p.add_argument("--no-host-boundary", action="store_true", help="skip the NDArray-shaped host path figure (gymnet_vecenv_step)")
     p.add_argument("--group-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run the gymnet_group_* leg over this many members
+    p.add_argument("--policy", default="", help="launch policy overrides for the headline handle, e.g. vec=4,nt=12,block=128 "
+                   "(gymnet_vecenv_set_launch_policy; every configuration computes the same bits)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: CartPole in the reference's own float64 arithmetic "
+                   "(GYMNET_FLAG_F64, 73 B per env-step); the default line is always f32")
     return p.parse_args()
 
 
@@ -217,6 +222,42 @@ class NodeBarrier:
                 os.unlink(self.path)
         except Exception:
             pass
+
+
+def make_watchdog(rank, out, emitted, section, seconds, exit_fn=os._exit):
+    """Watchdog for a secondary section that could hang rather than fail (a collective waiting for a peer): after `seconds` rank 0
+    prints the line it already has — headline first, the section marked as timed out — and every rank leaves with
+    WATCHDOG_EXIT (non-zero).  Never re-execs."""
+    def fire():
+        if emitted.acquire(blocking=False):
+            import faulthandler
+            sys.stderr.write(f"[bench rank {rank}] section {section!r} timed out after {seconds} s; stacks:\n")
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)    # where each rank was stuck
+            if rank == 0:
+                out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
+                out["watchdog_fired"] = section
+                print(json.dumps(out), flush=True)
+            exit_fn(WATCHDOG_EXIT)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def allgather_model(world, bytes_per_rank):
+    """what a per-step observation all-gather costs on point-to-point xGMI — direct (every rank stores its slice to
+    each peer over that peer's own link, all links concurrently) vs a ring (per-link bound, G - 1 hops)."""
+    direct_us = bytes_per_rank / (XGMI_LINK_GBPS * 1e9) * 1e6
+    return {"link_GBps": XGMI_LINK_GBPS, "bytes_per_rank": bytes_per_rank, "direct_us": direct_us, "ring_us": direct_us * max(0, world - 1),
+            "note": "analytic: 16 MiB per rank at 2^20 CartPole lanes -> ~110 us direct, ~770 us ring at 8 GPUs"}
+
+
+def parse_policy(text):
+    pol = {}
+    for item in filter(None, (x.strip() for x in text.split(","))):
+        k, v = item.split("=")
+        pol[k.strip()] = int(v)
+    return pol
 
 
 def median(xs):
@@ -400,10 +441,27 @@ def main():
     can_gather = use_dist and backend == "nccl"
     # the headline always steps IN PLACE (double-buffered observation arrays cost the step kernel ~0.8 us at this size,
     # profiles/double_buffer_probe_r02.txt); the overlapped-gather figure below builds its own double-buffered shard
-    env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
-                               auto_reset=True, gather_obs=use_dist, tensor_device=dev,
-                               force_gather=args.force_dist, overlap=False)
-    local = env.local
+    f64 = args.dtype == "f64"
+    if f64 and (world > 1 or args.env != "CartPole-v1"):
+        raise SystemExit("--dtype f64 is the single-GPU CartPole reference-arithmetic figure")
+    if f64:        # a plain handle (float64 handles keep their own state arrays: no shard / gather buffer)
+        local = pkg.VectorEnv(args.env, n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream, dtype="float64")
+
+        class _Plain:
+            def __init__(self, v):
+                self.local, self.obs_dim = v, v.ObsDim
+            ResetDevice = lambda self: self.local.ResetDevice()
+            StepDevice = lambda self, p: self.local.StepDevice(p)
+            Sync = lambda self: self.local.Sync()
+            Close = lambda self: self.local.Close()
+        env = _Plain(local)
+    else:
+        env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
+                                   auto_reset=True, gather_obs=use_dist, tensor_device=dev,
+                                   force_gather=args.force_dist, overlap=False)
+        local = env.local
+    if args.policy:
+        local.SetLaunchPolicy(**parse_policy(args.policy))
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
     actions = torch.empty((ring, n), dtype=adtype, device=dev)
     for t in range(ring):      # ActionSpace.Sample() per lane per step, on the device (Philox stream "action", key = seed + 1)
@@ -502,13 +560,18 @@ def main():
     c = local.Counters()
     assert c["lane_steps"] - steps_before == repeats * K * n, (c, steps_before, repeats)
 
-    bytes_per_step = local.AlgorithmicBytesPerStep                      # CartPole: 41 B
+    # CartPole: 41 B; float64 mode: 73 B (32 + 4 read, 32 + 4 + 1 written).  Envs that store a state row once,
+    # in the observation (Pendulum 33 of 37 B, Acrobot 57 of 65 B), are priced on the bytes they MOVE: the
+    # algorithmic figure is printed beside it, never used for the fraction.
+    algo_bytes_per_step = 73 if f64 else local.AlgorithmicBytesPerStep
+    bytes_per_step = 73 if f64 else local.TrafficBytesPerStep
     launch_policy = local.LaunchPolicy()
 
     def headline():
         """The contract's JSON line from the main timing alone; the secondary figures are added to it as they arrive."""
         launch_us = ev_ms * 1e3 / K                                          # HIP events over the (median) timed region / launches
-        achieved = bytes_per_step * n / (launch_us * 1e-6) / 1e9             # GB/s per GPU, algorithmic bytes
+        by_events = bytes_per_step * n / (launch_us * 1e-6) / 1e9            # GB/s per GPU from the kernel-side clock
+        achieved = bytes_per_step * n / (wall / K) / 1e9                     # GB/s per GPU from the SAME wall clock `value` uses
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")               # rocprofv3 --pmc result, per launch
         if os.path.exists(tpath):
@@ -530,9 +593,9 @@ def main():
         return {
             "metric": "env-steps/sec", "value": n * world * K / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if f64 else "f32", "data": "synthetic",
             "repeats": repeats, "region_ms_median": wall * 1e3, "region_ms_min": min(walls) * 1e3, "region_ms_max": max(walls) * 1e3,
-            "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), float32 SoA state, "
+            "config": {"workload": f"{args.env} batched, batch={n} lanes per GPU (global {n * world}), {'float64' if f64 else 'float32'} SoA state, "
                                    f"fused auto-reset, iid random actions pre-generated in HBM; {what}",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
                        "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or gather_in_region) else
@@ -545,12 +608,16 @@ def main():
                                    ("process-group barrier" if use_dist else "none (one rank)")),
                        "allgather_obs_in_timed_region": gather_in_region, "double_buffered_obs": False,
                        "parallelism": f"lane-sharded x{world}"},
+            # `achieved` / `frac` are the WALL-CLOCK figures (driver-comparable: bytes per launch / ms_per_step), the conservative
+            # ones; the HIP-event figures — the kernel's own duration over the timed region, what rocprofv3 --stats reproduces —
+            # sit beside them (the event-based fraction flatters a 20-step region that pays a ~14 us bracket)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel,
-                         "algorithmic_bytes_per_launch": bytes_per_step * n, "moved_bytes_per_launch": local.TrafficBytesPerStep * n,
-                         "launch_us": launch_us,
-                         "frac_by_wall": bytes_per_step * n / (wall / K) / 1e9 / HBM_PEAK_GBPS,
+                         "bytes_per_env_step": bytes_per_step, "algorithmic_bytes_per_env_step": algo_bytes_per_step,
+                         "bytes_per_launch": bytes_per_step * n, "algorithmic_bytes_per_launch": algo_bytes_per_step * n,
+                         "launch_us": launch_us, "achieved_by_events": by_events, "frac_by_events": by_events / HBM_PEAK_GBPS,
+                         "frac_by_wall": achieved / HBM_PEAK_GBPS,
                          "note": "at 2^20 lanes the working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
         }
 
@@ -558,22 +625,7 @@ def main():
     emitted = threading.Lock()
 
     def emit_and_exit_on_timeout(section, seconds):
-        """Watchdog for a secondary section that could hang rather than fail (a collective waiting for a peer): after `seconds`
-        rank 0 prints the headline it already has, with the section marked as timed out, and every rank leaves."""
-        def fire():
-            if emitted.acquire(blocking=False):
-                import faulthandler
-                sys.stderr.write(f"[bench rank {rank}] section {section!r} timed out after {seconds} s; stacks:\n")
-                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)    # where each rank was stuck
-                if rank == 0:
-                    out[section] = {"error": f"timed out after {seconds} s; headline unaffected"}
-                    out["watchdog_fired"] = section
-                    print(json.dumps(out), flush=True)
-                os._exit(WATCHDOG_EXIT)          # never exec; see WATCHDOG_EXIT for the status
-        t = threading.Timer(seconds, fire)
-        t.daemon = True
-        t.start()
-        return t
+        return make_watchdog(rank, out, emitted, section, seconds)
 
     # N > 1: what each rank ran on and measured by itself, and proof that the collective backend really spans `world` ranks.
     # Nothing here may cost the headline: a rank that cannot describe itself still takes part in both collectives (so nobody
@@ -602,7 +654,7 @@ def main():
         watchdog.cancel()
 
 
-    extras = rank == 0 and world == 1 and not args.no_extras and not gather_in_region
+    extras = rank == 0 and world == 1 and not args.no_extras and not gather_in_region and not f64
     # Cross-check of the per-launch figure: 200 single launches, each bracketed by its own HIP-event pair on the
     # engine's stream (isolated launches: no back-to-back overlap with a neighbour's ramp / drain).
     single_us = None
@@ -642,7 +694,7 @@ def main():
     host_boundary = None
     if extras and not args.no_host_boundary:
         try:
-            host_boundary = measure_host_boundary(pkg, args.env, n, dev_index, seed, local.AlgorithmicBytesPerStep)
+            host_boundary = measure_host_boundary(pkg, args.env, n, dev_index, seed, algo_bytes_per_step)
         except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
             host_boundary = {"error": repr(e)[:300]}
 
@@ -694,6 +746,7 @@ def main():
                     genv.Sync()
                     genv.Close()
         gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4
+        gathered["xgmi_model"] = allgather_model(world, env.obs_dim * n * 4)
         watchdog.cancel()
 
     # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
@@ -769,15 +822,50 @@ def main():
                     o1.record(stream)
                     torch.cuda.synchronize(dev)
                     us = o0.elapsed_time(o1) * 1e3 / 1024
-                    gb = e3.AlgorithmicBytesPerStep * n / (us * 1e-6) / 1e9
+                    gb = e3.TrafficBytesPerStep * n / (us * 1e-6) / 1e9              # the bytes the kernel MOVES
+                    gba = e3.AlgorithmicBytesPerStep * n / (us * 1e-6) / 1e9
                     other[name] = {"kernel": e3.KernelName(), "launch_us": us, "env_steps_per_sec": n / (us * 1e-6),
                                    "algorithmic_bytes_per_step": e3.AlgorithmicBytesPerStep, "moved_bytes_per_step": e3.TrafficBytesPerStep,
-                                   "achieved_GBps": gb, "frac_of_peak": gb / HBM_PEAK_GBPS}
+                                   "achieved_GBps": gb, "frac_of_peak": gb / HBM_PEAK_GBPS,
+                                   "algorithmic_GBps": gba, "frac_of_peak_algorithmic_bytes": gba / HBM_PEAK_GBPS,
+                                   "clock": "HIP events over 1024 back-to-back launches"}
                     del a3
             except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
                 other[name] = {"error": repr(e)[:200]}
 
+    # Secondary figure, NEVER `value`: CartPole at the same batch in the reference's own float64 arithmetic (GYMNET_FLAG_F64,
+    # cartpole64.hpp) — 73 B per env-step: 32 + 4 read, 32 + 4 + 1 written — with its own 73 B roofline fraction.
+    f64_fig = None
+    if extras and args.env == "CartPole-v1":
+        try:
+            with pkg.VectorEnv("CartPole-v1", n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream, dtype="float64") as e4:
+                r4 = 32
+                a4 = torch.empty((r4, n), dtype=torch.int32, device=dev)
+                for t in range(r4):
+                    e4.SampleActionsDevice(a4[t].data_ptr(), seed=seed + 1, tick=t)
+                e4.ResetDevice()
+                e4.RolloutDevice(a4.data_ptr(), 128, n, r4)
+                torch.cuda.synchronize(dev)
+                q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                q0.record(stream)
+                e4.RolloutDevice(a4.data_ptr(), 1024, n, r4)
+                q1.record(stream)
+                torch.cuda.synchronize(dev)
+                w4 = time.perf_counter() - t0
+                us = q0.elapsed_time(q1) * 1e3 / 1024
+                f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
+                           "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
+                           "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
+                           "frac_of_peak_by_events": 73 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                           "note": "reference-exact float64 mode; reported beside, never as, `value`"}
+                del a4
+        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
+            f64_fig = {"error": repr(e)[:300]}
+
     if rank == 0:
+        if f64_fig:
+            out["cartpole_f64_2p20"] = f64_fig
         if other:
             out["other_configs_2p20"] = other
         out["roofline"]["isolated_launch_us_median"] = single_us
@@ -801,10 +889,39 @@ def main():
         dist.destroy_process_group()
         watchdog.cancel()
     if rank == 0 and emitted.acquire(blocking=False):
+        # the measured headline goes to STDERR now (stdout carries exactly ONE line, at the end): a driver timeout during the
+        # legs below — a fresh child process and a CPU run — can no longer lose a measurement that already exists
+        sys.stderr.write("[bench] headline so far: " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step") if k in out}) + "\n")
+        sys.stderr.flush()
         if world > 1:
             time.sleep(1.0)                                      # the other ranks are exiting
+            # N = 1 on THIS box, same kernel, same K / repeats protocol without the ranks: value / (N x this) is the weak-scaling
+            # efficiency measured inside one run (the driver computes its own from its separate N = 1 run)
+            try:
+                with pkg.VectorEnv(args.env, n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream) as e1:
+                    a1 = torch.empty((ring, n), dtype=adtype, device=dev)
+                    for t in range(ring):
+                        e1.SampleActionsDevice(a1[t].data_ptr(), seed=seed + 1, tick=t)
+                    e1.ResetDevice()
+                    e1.RolloutDevice(a1.data_ptr(), W, n, ring)
+                    torch.cuda.synchronize(dev)
+                    ws = []
+                    t_end = time.perf_counter() + max(args.min_seconds, 0.05)
+                    while len(ws) < 3 or (time.perf_counter() < t_end and len(ws) < MAX_REPEATS):
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        e1.RolloutDevice(a1.data_ptr(), K, n, ring)
+                        torch.cuda.synchronize(dev)
+                        ws.append(time.perf_counter() - t0)
+                    v1 = n * K / median(ws)
+                    out["same_box_n1"] = {"value": v1, "unit": "env-steps/s", "ms_per_step": median(ws) * 1e3 / K, "repeats": len(ws),
+                                          "scaling_efficiency": out["value"] / (world * v1),
+                                          "note": "rank 0's GPU alone after the other ranks exited; efficiency = value / (N x this)"}
+                    del a1
+            except Exception as e:                               # noqa: BLE001
+                out["same_box_n1"] = {"error": repr(e)[:300]}
             if not args.no_group_leg and not gather_in_region:
-                out["group_single_process"] = run_group_child(args, world)
+                out["group_single_process"] = run_group_child(args, world, timeout=180)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)

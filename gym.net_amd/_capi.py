@@ -36,9 +36,15 @@ FLAG_DONE_LIST = 0x04
 FLAG_EPISODE_STATS = 0x08
 FLAG_FINAL_OBS = 0x10
 FLAG_DOUBLE_BUFFER = 0x20
+FLAG_F64 = 0x40
+FLAG_COMPACT_RECORDS_ONLY = 0x80
+
+DTYPE_F32, DTYPE_F64 = 0, 1
+(ARRAY_REWARD, ARRAY_DONE, ARRAY_STEPS_BEYOND_DONE, ARRAY_EPISODE_RETURN, ARRAY_EPISODE_LENGTH, ARRAY_FINISHED_RETURN,
+ ARRAY_FINISHED_LENGTH, ARRAY_FINAL_OBS, ARRAY_LANE_SEEDS) = range(9)
 
 GATHER_NONE, GATHER_DIRECT, GATHER_RCCL = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Config(C.Structure):
@@ -68,8 +74,14 @@ class DeviceView(C.Structure):
                 ("d_final_obs", C.c_void_p), ("d_done_list", C.c_void_p),
                 ("d_episode_return", C.c_void_p), ("d_episode_length", C.c_void_p),
                 ("d_finished_return", C.c_void_p), ("d_finished_length", C.c_void_p),
-                ("stream", C.c_void_p), ("obs_buffer", C.c_int32), ("reserved", C.c_int32),
+                ("stream", C.c_void_p), ("obs_buffer", C.c_int32), ("state_dtype", C.c_int32),
                 ("d_obs_alt", C.c_void_p)]
+
+
+class LaunchPolicy(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("vec", C.c_int32), ("block", C.c_int32), ("nt", C.c_int32),
+                ("sequential_lanes", C.c_int32), ("reset_form", C.c_int32), ("lds_pipe", C.c_int32),
+                ("occupancy_lds_bytes", C.c_int32), ("graph", C.c_int32)]
 
 
 class GroupConfig(C.Structure):
@@ -123,6 +135,8 @@ PROTOTYPES = {
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),
     "gymnet_vecenv_launch_policy": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
+    "gymnet_vecenv_set_launch_policy": (C.c_int, [_H, C.POINTER(LaunchPolicy)]),
+    "gymnet_vecenv_get_launch_policy": (C.c_int, [_H, C.POINTER(LaunchPolicy)]),
     "gymnet_vecenv_kernel_name": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "gymnet_vecenv_host_buffers": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gymnet_vecenv_get_state": (C.c_int, [_H, _P]),
@@ -132,6 +146,9 @@ PROTOTYPES = {
     "gymnet_vecenv_get_tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "gymnet_vecenv_set_tick": (C.c_int, [_H, C.c_uint64]),
     "gymnet_vecenv_counters": (C.c_int, [_H, C.POINTER(Counters)]),
+    "gymnet_vecenv_get_array": (C.c_int, [_H, C.c_int32, _P, C.c_int64]),
+    "gymnet_vecenv_set_array": (C.c_int, [_H, C.c_int32, _P, C.c_int64]),
+    "gymnet_vecenv_get_seed": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     "gymnet_vecenv_done_lanes": (C.c_int, [_H, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "gymnet_vecenv_done_lanes_device": (C.c_int, [_H, _P, _P]),
     "gymnet_vecenv_episode_stats": (C.c_int, [_H, _P, _P]),

@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libgymnet_amd.so")
-SOURCES = ["kernels.hip", "capi.hip", "group.hip"]
-DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
+SOURCES = ["kernels.hip", "kernels64.hip", "capi.hip", "group.hip"]
+DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "cartpole64.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
 # -fno-slp-vectorize: on gfx950 a packed FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) occupies the SIMD about
 # as long as the two scalar instructions it replaces (~5 cycles against ~2.4 each in these kernels' instruction mix:
 # tools/acrobot_alu_probe.hip, tools/valu_probe.hip, profiles/*_r02.txt), so the compiler's opportunistic pairing saves
@@ -21,6 +21,11 @@ DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "philox.hpp", "handle.hpp", os.path
 # bench kernels time the same either way).  Off = deterministic, purely scalar code generation.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
+# Probe builds only: GYMNET_BUILD_PROBE_ENV=1 compiles the GYMNET_VEC / GYMNET_NT / ... environment overrides of the launch policy
+# back in (the round 1-3 tools/ scripts use them).  The shipped library never reads the process environment for its policy:
+# gymnet_vecenv_set_launch_policy is the interface.
+if os.environ.get("GYMNET_BUILD_PROBE_ENV") == "1":
+    FLAGS = FLAGS + ["-DGYMNET_PROBE_ENV"]
 
 
 def hipcc():

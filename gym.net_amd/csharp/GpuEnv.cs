@@ -6,9 +6,11 @@
 // UNVERIFIED: never compiled (no .NET toolchain in the build image).  tests/test_host_api.py lexes it, checks every native
 // call against the header's arity, and that the four classes derive from Env and override every abstract member.
 //
-// What is NOT here: rendering (Render returns null — NullEnvViewer semantics; the viewers are out of scope) and the
-// float64 observation the reference actually returns (SURVEY F5): observations are float32, the DECLARED dtype of
-// ObservationSpace (CartPoleEnv.cs:48).
+// What is NOT here: rendering (Render returns null — NullEnvViewer semantics; the viewers are out of scope).
+// Dtype: GpuCartPoleEnv defaults to float64 = true — GymnetFlags.F64, the reference's own arithmetic (float64 state, the literal
+// CartPoleEnv.cs:141-167 sequence) and the float64 observation NDArray the reference actually returns (:166,185; SURVEY F5) — so
+// the loops above see the reference's states to the last few ulps and its exact episode lengths, free-running.  float64 = false
+// (and the three envs the reference does not have) return float32, the DECLARED dtype of ObservationSpace (CartPoleEnv.cs:48).
 using System;
 using System.Threading.Tasks;
 using Gym.Collections;
@@ -24,16 +26,20 @@ namespace Gym.Envs.Amd {
         private IntPtr _h;
         private readonly int _obsDim;
         private readonly bool _boxAction;
-        private readonly float[] _obs;                       // reused: one observation row
+        private readonly bool _f64;                          // GymnetFlags.F64: observations are double (CartPole only)
+        private readonly float[] _obs;                       // reused: one observation row (float32 handles)
+        private readonly double[] _obs64;                    // reused: one observation row (float64 handles)
         private readonly float[] _rew = new float[1];
         private readonly byte[] _done = new byte[1];
 
         /// maxEpisodeSteps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; the reference has none,
         /// SURVEY F6): the step that reaches the limit returns Done = true with Information["TimeLimit.truncated"] = true.
-        protected GpuEnv(GymnetEnvId env, int device, ulong seed, int maxEpisodeSteps, bool validateActions) {
+        protected GpuEnv(GymnetEnvId env, int device, ulong seed, int maxEpisodeSteps, bool validateActions, bool float64 = false) {
             Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo info));
             _obsDim = info.obs_dim; _boxAction = info.action_is_box != 0;
+            _f64 = float64;
             _obs = new float[_obsDim];
+            _obs64 = new double[_obsDim];
             var lo = new float[_obsDim]; var hi = new float[_obsDim];
             for (int k = 0; k < _obsDim; k++) { lo[k] = info.obs_low[k]; hi[k] = info.obs_high[k]; }
             ObservationSpace = new Box(np.array(lo), np.array(hi), np.float32);                                   // CartPoleEnv.cs:46-48
@@ -43,6 +49,7 @@ namespace Gym.Envs.Amd {
             GymnetFlags flags = GymnetFlags.None;
             if (validateActions) flags |= GymnetFlags.ValidateActions;
             if (maxEpisodeSteps > 0) flags |= GymnetFlags.EpisodeStats;
+            if (float64) flags |= GymnetFlags.F64;
             var cfg = new GymnetConfig {
                 struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = 1, lane_offset = 0,
                 device = device, flags = (uint) flags, seed = seed, max_episode_steps = maxEpisodeSteps
@@ -50,15 +57,19 @@ namespace Gym.Envs.Amd {
             Native.Check(Native.gymnet_vecenv_create(ref cfg, out _h));
         }
 
+        /// the observation row just written by the library, as a fresh NDArray of the handle's dtype (a COPY, like CartPoleEnv.cs:66)
+        private NDArray Observation() => _f64 ? np.array((double[]) _obs64.Clone()) : np.array((float[]) _obs.Clone());
+
         public override NDArray Reset() {                                                                         // CartPoleEnv.cs:63-67
-            fixed (float* p = _obs) Native.Check(Native.gymnet_vecenv_reset(_h, p));
-            return np.array((float[]) _obs.Clone());                                                              // a COPY, like :66
+            fixed (float* p = _obs) fixed (double* p64 = _obs64)
+                Native.Check(Native.gymnet_vecenv_reset(_h, _f64 ? (void*) p64 : (void*) p));
+            return Observation();
         }
 
         private Step Result() {
             bool truncated = (_done[0] & 2) != 0;
             Dict info = truncated ? new Dict("TimeLimit.truncated", true) : null;
-            return new Step(np.array((float[]) _obs.Clone()), _rew[0], _done[0] != 0, info);                      // Step.cs:15-20
+            return new Step(Observation(), _rew[0], _done[0] != 0, info);                                         // Step.cs:15-20
         }
 
         /// One boxed action, cast like the reference: a Discrete env does `(int) action` (InvalidCastException for anything that
@@ -75,7 +86,8 @@ namespace Gym.Envs.Amd {
         public override Step Step(object action) {                                                                // CartPoleEnv.cs:137-186
             int ia = 0; float fa = 0f;
             Stage(action, &ia, &fa);
-            fixed (float* po = _obs) fixed (float* pr = _rew) fixed (byte* pd = _done) {
+            fixed (float* p32 = _obs) fixed (double* p64 = _obs64) fixed (float* pr = _rew) fixed (byte* pd = _done) {
+                void* po = _f64 ? (void*) p64 : (void*) p32;
                 if (_boxAction) Native.Check(Native.gymnet_vecenv_step(_h, &fa, po, pr, pd));
                 else Native.Check(Native.gymnet_vecenv_step(_h, &ia, po, pr, pd));
             }
@@ -91,8 +103,8 @@ namespace Gym.Envs.Amd {
             if (_boxAction) Native.Check(Native.gymnet_vecenv_step_async(_h, &fa));
             else Native.Check(Native.gymnet_vecenv_step_async(_h, &ia));
             return Task.Run(() => {
-                fixed (float* po = _obs) fixed (float* pr = _rew) fixed (byte* pd = _done)
-                    Native.Check(Native.gymnet_vecenv_step_wait(_h, po, pr, pd));
+                fixed (float* p32 = _obs) fixed (double* p64 = _obs64) fixed (float* pr = _rew) fixed (byte* pd = _done)
+                    Native.Check(Native.gymnet_vecenv_step_wait(_h, _f64 ? (void*) p64 : (void*) p32, pr, pd));
                 return Result();
             });
         }
@@ -109,8 +121,8 @@ namespace Gym.Envs.Amd {
     /// CartPoleEnv (src/Gym.Environments/Envs/Classic/CartPoleEnv.cs) on the GPU engine.  The viewer-delegate ctor argument of
     /// the reference (CartPoleEnv.cs:54-61) has no counterpart: nothing is rendered.
     public sealed class GpuCartPoleEnv : GpuEnv {
-        public GpuCartPoleEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
-            : base(GymnetEnvId.CartPole, device, seed, maxEpisodeSteps, validateActions) { }
+        public GpuCartPoleEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false, bool float64 = true)
+            : base(GymnetEnvId.CartPole, device, seed, maxEpisodeSteps, validateActions, float64) { }
     }
 
     /// Pendulum-v1 / MountainCar-v0 / Acrobot-v1: unchecked roadmap items of the reference (README.md:69-76), upstream gym semantics.

@@ -1,4 +1,4 @@
-// Native.cs — P/Invoke declarations for include/gymnet_amd.h (libgymnet_amd.so), ABI version 3.
+// Native.cs — P/Invoke declarations for include/gymnet_amd.h (libgymnet_amd.so), ABI version 4.
 // UNVERIFIED: no .NET toolchain exists in the build image, so this file has never been compiled.
 // It is the binding a Gym.NET maintainer would add next to src/Gym/Envs/VecEnv.cs.  What CAN be checked here is checked by
 // tests/test_host_api.py: one [DllImport] per header entry point (no exceptions), and every [StructLayout(Sequential)]
@@ -20,7 +20,14 @@ namespace Gym.Envs.Amd {
     [Flags]
     public enum GymnetFlags : uint {
         None = 0, AutoReset = 0x01, ValidateActions = 0x02, DoneList = 0x04, EpisodeStats = 0x08, FinalObs = 0x10,
-        DoubleBuffer = 0x20
+        DoubleBuffer = 0x20, F64 = 0x40, CompactRecordsOnly = 0x80
+    }
+
+    public enum GymnetDtype { F32 = 0, F64 = 1 }
+
+    public enum GymnetArrayId {
+        Reward = 0, Done = 1, StepsBeyondDone = 2, EpisodeReturn = 3, EpisodeLength = 4, FinishedReturn = 5, FinishedLength = 6,
+        FinalObs = 7, LaneSeeds = 8
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -48,13 +55,20 @@ namespace Gym.Envs.Amd {
         public IntPtr d_state; public IntPtr d_obs; public IntPtr d_reward; public IntPtr d_done;
         public IntPtr d_steps_beyond_done; public IntPtr d_final_obs; public IntPtr d_done_list;
         public IntPtr d_episode_return; public IntPtr d_episode_length; public IntPtr d_finished_return; public IntPtr d_finished_length;
-        public IntPtr stream; public int obs_buffer; public int reserved; public IntPtr d_obs_alt;
+        public IntPtr stream; public int obs_buffer; public int state_dtype; public IntPtr d_obs_alt;
     }
 
     [StructLayout(LayoutKind.Sequential)]
     public struct GymnetCounters {
         public uint struct_size; public uint reserved; public ulong tick; public ulong lane_steps; public ulong stepped_after_done;
         public long last_done_count;
+    }
+
+    /// Launch configuration of the step kernel; every field -1 = leave as it is (gymnet_vecenv_set_launch_policy).
+    [StructLayout(LayoutKind.Sequential)]
+    public struct GymnetLaunchPolicy {
+        public uint struct_size; public int vec; public int block; public int nt; public int sequential_lanes; public int reset_form;
+        public int lds_pipe; public int occupancy_lds_bytes; public int graph;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -85,14 +99,14 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_seed(IntPtr h, ulong seed);
         [DllImport(Lib)] public static extern int gymnet_vecenv_seed_lanes(IntPtr h, ulong[] seeds, long count);
 
-        // ---- host-boundary path
-        [DllImport(Lib)] public static extern int gymnet_vecenv_reset(IntPtr h, float* obs_out);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_reset_where(IntPtr h, byte* mask, float* obs_out);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_step(IntPtr h, void* actions, float* obs_out, float* reward_out, byte* done_out);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_step_broadcast(IntPtr h, int action, float* obs_out, float* reward_out, byte* done_out);
+        // ---- host-boundary path (obs_out: float32 [N, D]; float64 for a handle created with GymnetFlags.F64 — hence void*)
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset(IntPtr h, void* obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_reset_where(IntPtr h, byte* mask, void* obs_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step(IntPtr h, void* actions, void* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_broadcast(IntPtr h, int action, void* obs_out, float* reward_out, byte* done_out);
         [DllImport(Lib)] public static extern int gymnet_vecenv_step_async(IntPtr h, void* actions);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_step_wait(IntPtr h, float* obs_out, float* reward_out, byte* done_out);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_read(IntPtr h, float* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_step_wait(IntPtr h, void* obs_out, float* reward_out, byte* done_out);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_read(IntPtr h, void* obs_out, float* reward_out, byte* done_out);
 
         // ---- device-resident path
         [DllImport(Lib)] public static extern int gymnet_vecenv_reset_device(IntPtr h);
@@ -105,17 +119,22 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_sync(IntPtr h);
         [DllImport(Lib)] public static extern int gymnet_vecenv_device_view(IntPtr h, out GymnetDeviceView view);
         [DllImport(Lib)] public static extern int gymnet_vecenv_launch_policy(IntPtr h, out int vec, out int block, out int nt, out int sequential_lanes);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_launch_policy(IntPtr h, ref GymnetLaunchPolicy policy);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_launch_policy(IntPtr h, out GymnetLaunchPolicy policy);
         [DllImport(Lib)] public static extern int gymnet_vecenv_kernel_name(IntPtr h, byte[] buf, int capacity);
         [DllImport(Lib)] public static extern int gymnet_vecenv_host_buffers(IntPtr h, out IntPtr actions, out IntPtr obs, out IntPtr reward, out IntPtr done);
 
         // ---- state access / bookkeeping
-        [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, float* state_soa);
-        [DllImport(Lib)] public static extern int gymnet_vecenv_set_state(IntPtr h, float* state_soa);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_state(IntPtr h, void* state_soa);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_state(IntPtr h, void* state_soa);
         [DllImport(Lib)] public static extern int gymnet_vecenv_get_steps_beyond_done(IntPtr h, int* out_sbd);
         [DllImport(Lib)] public static extern int gymnet_vecenv_set_steps_beyond_done(IntPtr h, int* in_sbd);
         [DllImport(Lib)] public static extern int gymnet_vecenv_get_tick(IntPtr h, out ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_set_tick(IntPtr h, ulong tick);
         [DllImport(Lib)] public static extern int gymnet_vecenv_counters(IntPtr h, out GymnetCounters counters);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_array(IntPtr h, int which, void* out_array, long bytes);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_set_array(IntPtr h, int which, void* in_array, long bytes);
+        [DllImport(Lib)] public static extern int gymnet_vecenv_get_seed(IntPtr h, out ulong seed, out int per_lane);
         [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes(IntPtr h, int* lanes_out, long capacity, out long count);
         [DllImport(Lib)] public static extern int gymnet_vecenv_done_lanes_device(IntPtr h, IntPtr d_lanes_out, IntPtr d_count_out);
         [DllImport(Lib)] public static extern int gymnet_vecenv_episode_stats(IntPtr h, float* finished_return, int* finished_length);

@@ -130,6 +130,31 @@ namespace Gym.Envs.Amd {
             Native.Check(Native.gymnet_vecenv_step(_h, (void*) b.Actions, (float*) b.Obs, (float*) b.Reward, (byte*) b.Done));
         }
 
+        /// ABI 4: override fields of the step kernel's launch configuration (every field of `policy` that is -1 stays as it is;
+        /// start from KeepPolicy()).  All configurations compute bit-identical results; a value this handle cannot run throws
+        /// ArgumentException.  This is the ONLY way to steer the policy: the library does not read the process environment.
+        public static GymnetLaunchPolicy KeepPolicy() => new GymnetLaunchPolicy {
+            struct_size = (uint) sizeof(GymnetLaunchPolicy), vec = -1, block = -1, nt = -1, sequential_lanes = -1, reset_form = -1,
+            lds_pipe = -1, occupancy_lds_bytes = -1, graph = -1
+        };
+
+        public void SetLaunchPolicy(GymnetLaunchPolicy policy) {
+            policy.struct_size = (uint) sizeof(GymnetLaunchPolicy);
+            Native.Check(Native.gymnet_vecenv_set_launch_policy(_h, ref policy));
+        }
+
+        /// ABI 4: any per-lane array the handle keeps, by id — with GetState / the tick / the seed a complete checkpoint of every
+        /// configuration (episode return / length, done flags, per-lane Philox keys, ...).  T must be the array's element type.
+        public T[] GetArray<T>(GymnetArrayId which, int count) where T : unmanaged {
+            var a = new T[count];
+            fixed (T* p = a) Native.Check(Native.gymnet_vecenv_get_array(_h, (int) which, p, (long) count * sizeof(T)));
+            return a;
+        }
+
+        public void SetArray<T>(GymnetArrayId which, T[] a) where T : unmanaged {
+            fixed (T* p = a) Native.Check(Native.gymnet_vecenv_set_array(_h, (int) which, p, (long) a.Length * sizeof(T)));
+        }
+
         /// Compact records of the lanes that finished in the most recent step (GymnetFlags.DoneList [+ EpisodeStats] [+ FinalObs]):
         /// what BasePlaySession.cs:58-69 accumulates per episode, without shipping N flags to the host.
         public (int[] lanes, float[] episodeReturn, int[] episodeLength, float[] finalObs) DoneRecords(bool episode, bool finalObs) {

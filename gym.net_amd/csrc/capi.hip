@@ -71,7 +71,8 @@ int dalloc(gymnet_vecenv *h, T **p, size_t count) {
 // device-resident consumer (bench.py, a GPU policy) never pays for it — at 2^27 CartPole lanes it is 2.6 GiB.
 int ensure_staging(gymnet_vecenv *h, bool actions, bool pack, bool mask) {
     if (actions && !h->d_actions) ST_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)h->padded));
-    if (pack && !h->d_pack) ST_TRY(dalloc(h, &h->d_pack, (size_t)h->padded * h->desc->obs_dim));
+    if (pack && h->f64 && !h->d_pack64) ST_TRY(dalloc(h, &h->d_pack64, (size_t)h->padded * h->desc->obs_dim));
+    if (pack && !h->f64 && !h->d_pack) ST_TRY(dalloc(h, &h->d_pack, (size_t)h->padded * h->desc->obs_dim));
     if (mask && !h->d_mask) ST_TRY(dalloc(h, &h->d_mask, (size_t)h->padded));
     return GYMNET_OK;
 }
@@ -87,6 +88,7 @@ void drop_graphs(gymnet_vecenv *h) {
     h->graphs.clear();
 }
 
+int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict);
 StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     StepArgs a{};
     const bool alias = h->desc->alias;
@@ -99,11 +101,14 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.done = h->d_done;
     a.sbd = h->d_sbd;
     a.tick2 = h->d_tick2;
-    a.final_obs = h->d_final_obs;
+    // the dense "last finished episode per lane" arrays are maintained by the step kernel itself unless the caller opted for
+    // compact records only (GYMNET_FLAG_COMPACT_RECORDS_ONLY with DONE_LIST): then the getters apply the records on demand
+    const bool dense = !(h->compact_only && h->d_done_list);
+    a.final_obs = dense ? h->d_final_obs : nullptr;
     a.done_list = h->d_done_list;
     a.done_count2 = h->d_done_count2;
     a.done_cap = h->done_cap;
-    a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
+    a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = dense ? h->d_fin_ret : nullptr; a.fin_len = dense ? h->d_fin_len : nullptr;
     a.rec_ret = h->d_rec_ret; a.rec_len = h->d_rec_len; a.rec_obs = h->d_rec_obs;
     a.lane_seed = h->d_lane_seed;
     a.after_done = h->d_after_done;
@@ -112,6 +117,21 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.seed = h->seed;
     a.parity = (int32_t)h->tslot;
     a.cparity = (int32_t)(h->step_launches & 1u);
+    a.max_episode_steps = h->cfg.max_episode_steps;
+    return a;
+}
+
+StepArgs64 make_step_args64(gymnet_vecenv *h, const void *d_actions) {
+    StepArgs64 a{};
+    a.state = h->d_state64;
+    a.action = static_cast<const int32_t *>(d_actions);
+    a.reward = h->d_reward; a.done = h->d_done; a.sbd = h->d_sbd; a.tick2 = h->d_tick2;
+    a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
+    a.lane_seed = h->d_lane_seed;
+    a.after_done = h->d_after_done;
+    a.n = h->n; a.stride = h->sstride;
+    a.lane_offset = (uint64_t)h->cfg.lane_offset; a.seed = h->seed;
+    a.parity = (int32_t)h->tslot;
     a.max_episode_steps = h->cfg.max_episode_steps;
     return a;
 }
@@ -145,6 +165,112 @@ float *state_row(gymnet_vecenv *h, int k) {
     return m < 0 ? h->d_state + (size_t)k * h->sstride : h->d_obs + (size_t)m * h->ostride;
 }
 
+// Applies the fields of `p` that are not -1.  strict: a value the handle cannot run is an error; else it is ignored (probe builds).
+int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
+    LaunchCfg c = h->lcfg;
+    const bool acrobot = h->cfg.env_id == GYMNET_ENV_ACROBOT;
+    auto bad = [&](const char *what, int v) -> int {
+        return strict ? fail(h, GYMNET_ERR_INVALID_ARG, "launch policy: %s = %d is not available for this handle", what, v) : GYMNET_OK;
+    };
+    if (p.vec != -1) {
+        const bool ok = h->f64 ? (p.vec == 1 || p.vec == 2)
+                               : (p.vec == 1 || (p.vec == 4 && h->can_vec4 && !acrobot) || (p.vec == 2 && h->can_vec2 && acrobot));
+        if (ok) c.vec = p.vec; else ST_TRY(bad("vec", p.vec));
+    }
+    if (p.block != -1) { if (p.block == 64 || p.block == 128 || p.block == 256) c.block = p.block; else ST_TRY(bad("block", p.block)); }
+    if (p.nt != -1) { if (p.nt == 0 || p.nt == 12 || p.nt == 15) c.nt = p.nt; else ST_TRY(bad("nt", p.nt)); }
+    if (p.sequential_lanes != -1) {
+        if (p.sequential_lanes >= 1 && p.sequential_lanes <= 5 && (acrobot || p.sequential_lanes == 1)) c.items = p.sequential_lanes;
+        else ST_TRY(bad("sequential_lanes", p.sequential_lanes));
+    }
+    if (p.reset_form != -1) { if (p.reset_form == 0 || p.reset_form == 1) c.reset_form = p.reset_form; else ST_TRY(bad("reset_form", p.reset_form)); }
+    if (p.lds_pipe != -1) {
+        if (p.lds_pipe == 0 || (p.lds_pipe == 1 && h->lds_ok)) c.lds_pipe = p.lds_pipe; else ST_TRY(bad("lds_pipe", p.lds_pipe));
+    }
+    if (p.occupancy_lds_bytes != -1) {
+        if (p.occupancy_lds_bytes >= 0 && p.occupancy_lds_bytes <= 160 * 1024) c.lds_bytes = p.occupancy_lds_bytes;
+        else ST_TRY(bad("occupancy_lds_bytes", p.occupancy_lds_bytes));
+    }
+    if (p.graph != -1) { if (p.graph == 0 || p.graph == 1) h->graph_mode = p.graph; else if (p.graph == -2) h->graph_mode = -1; else ST_TRY(bad("graph", p.graph)); }
+    if (std::memcmp(&c, &h->lcfg, sizeof c) != 0) {
+        h->lcfg = c;
+        drop_graphs(h);          // captured launches froze the old configuration
+    }
+    return GYMNET_OK;
+}
+
+// The launch configuration a handle starts with (gymnet_vecenv_set_launch_policy changes it afterwards).
+void default_policy(gymnet_vecenv *h) {
+    const EnvDesc &d = *h->desc;
+    const gymnet_config *cfg = &h->cfg;
+    if (h->f64) {
+        // float64 CartPole: two lanes per thread (one dwordx4 per state row and direction); stream policy by the bytes a vector
+        // step moves, with the thresholds of the float32 path below
+        const size_t step_bytes = (size_t)h->n * 73;
+        h->can_vec4 = false; h->can_vec2 = true; h->lds_ok = false;
+        // measured at 2^20 lanes (73 MiB per step; us per step, gpurun_out r4): every stream non-temporal 14.3, state cacheable 14.8,
+        // nothing non-temporal 16.2, one lane per thread 15.6
+        h->lcfg = LaunchCfg{2, 256, 15, 0, 1, 0, 0};
+        if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
+        return;
+    }
+    // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
+    const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0) &&
+                          (!h->d_obs_alt || aligned16(h->d_obs_alt));
+    // Launch policy, measured on MI355X with tools/probe_step.hip and bench.py (profiles/probe_r01.txt, DESIGN.md §4),
+    // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
+    //  - <= 24 MiB (2^19 CartPole lanes): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
+    //  - <= 48 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
+    //  - <= 768 MiB (state fits the 256 MiB Infinity Cache): dwordx4, state cacheable, action / reward / done streamed
+    //    past it, so the next launch re-reads the state from the cache;
+    //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal;
+    //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
+    const size_t step_bytes = (size_t)h->n * (size_t)d.algorithmic_bytes;
+    const bool alu_bound = cfg->env_id == GYMNET_ENV_ACROBOT;
+    if (alu_bound || step_bytes <= ((size_t)24 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
+    else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
+    else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    if (!can_vec4) h->lcfg.vec = 1;
+    // Acrobot's wide form is TWO lanes per thread whose arithmetic rides the packed FP32 instructions (envs.hpp).  Opt-in
+    // (gymnet_launch_policy.vec = 2): bit-identical, 287 instead of 454 VALU per env-step, and slower — 15.0 vs 14.2 us at 2^20
+    // lanes, 13.6 vs 12.3 us per 2^20 lanes at 2^23 (profiles/acrobot_probes_r02.txt).
+    const bool can_vec2 = aligned_to(h->d_state, 8) && aligned_to(h->d_obs, 8) && (h->sstride % 2 == 0) && (h->ostride % 2 == 0) &&
+                          (!h->d_obs_alt || aligned_to(h->d_obs_alt, 8));
+    // Acrobot's multi-lane kernel (step_kernel_pipe: all loads first, then compute / store lane after lane) wins where the
+    // one-shot kernel would run as ~2 lock-step wave generations: it turns the launch into ONE generation of 4096 waves whose
+    // stores drain under the next lane's arithmetic.  Measured (profiles/acrobot_probes_r02.txt, us per 2^20 lanes, one-shot
+    // vs k = ceil(n / 2^18) lanes per thread): n = 2^19 15.1 vs 14.5, 3*2^18 13.9 vs 13.9, 2^20 14.9 vs 13.1, 5*2^18 13.7 vs
+    // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
+    if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
+    // Wave-compacted fused reset (kernels.hip: reset_pending_wave) wherever the dwordx4 lean kernel of an env whose observation IS
+    // its state runs: the wave's finished sub-lanes are drawn in ONE Philox pass by its first lanes instead of 1.6 mostly idle
+    // passes.  CartPole at 2^20 lanes: 6.91 -> 6.52 us per launch, bit-identical (profiles/forms_probe_r03.txt).
+    h->lcfg.reset_form = (d.alias && h->lcfg.vec == 4) ? 1 : 0;
+    // producer / consumer form of the multi-lane kernel (opt-in, gymnet_launch_policy.lds_pipe = 1): whole 512-lane tiles and
+    // 16-byte aligned rows only.  Bit-identical and SLOWER at 2^20 lanes — 13.5-14.9 vs 11.7-12.7 us (profiles/acrobot_lds_r03.txt):
+    // the computing waves' waits on memory instructions drop from 34 % to 21 % of their cycles, the s_barrier per tile adds more.
+    const bool lds_ok = alu_bound && can_vec4 && (h->n % 512) == 0;
+    // 64-thread workgroups for the dwordx4 kernels of the smallest payloads (< 40 MiB per vector step at dwordx4: MountainCar and
+    // Pendulum at 2^20 lanes): such a launch is ramp / drain bound, and one-wave workgroups ramp and retire faster — MountainCar 4.92-5.05
+    // -> 4.55-4.73 us, Pendulum 5.97 -> 5.88 us; CartPole (41 MiB) does not gain (tools/gpu_nt_ab_r03.sh, profiles/block_nt_probe_r03.txt)
+    if (h->lcfg.vec == 4 && step_bytes < ((size_t)40 << 20)) h->lcfg.block = 64;
+    h->can_vec4 = can_vec4; h->can_vec2 = can_vec2; h->lds_ok = lds_ok;
+#ifdef GYMNET_PROBE_ENV
+    // PROBE BUILDS ONLY (build.py: GYMNET_BUILD_PROBE_ENV=1): the round 1-3 tools/ scripts steer the policy through the process
+    // environment.  The shipped library never reads it — a host process's environment must not silently change which kernel a
+    // library runs; tests, bench.py and current tools use gymnet_vecenv_set_launch_policy.
+    gymnet_launch_policy p;
+    std::memset(&p, 0xFF, sizeof p);          // every field -1 = keep
+    p.struct_size = sizeof p;
+    auto envi = [](const char *name, int32_t *dst) { if (const char *e = std::getenv(name)) *dst = std::atoi(e); };
+    envi("GYMNET_VEC", &p.vec); envi("GYMNET_NT", &p.nt); envi("GYMNET_ITEMS", &p.sequential_lanes);
+    envi("GYMNET_RESET_FORM", &p.reset_form); envi("GYMNET_LDS_PIPE", &p.lds_pipe); envi("GYMNET_LDS", &p.occupancy_lds_bytes);
+    envi("GYMNET_BLOCK", &p.block);
+    (void)apply_policy(h, p, /*strict=*/false);
+#endif
+}
+
 void recompute_extras(gymnet_vecenv *h) {
     h->extras = (h->cfg.flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS)) != 0 ||
                 h->d_lane_seed != nullptr;
@@ -166,6 +292,12 @@ int seed_handle(gymnet_vecenv *h, uint64_t seed) {
 
 // one vector step = one kernel launch; bumps the host mirrors of the device-side counters
 int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
+    if (h->f64) {
+        StepArgs64 a = make_step_args64(h, d_actions);
+        HIP_TRY(h, launch_step_f64(h->autoreset, h->extras, a, h->lcfg.vec, h->lcfg.nt, h->stream));
+        h->tick += 1; h->tslot ^= 1; h->step_launches += 1; h->lane_steps += (uint64_t)h->n;
+        return GYMNET_OK;
+    }
     StepArgs a = make_step_args(h, d_actions);
     HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
     swap_buffers(h);
@@ -178,6 +310,16 @@ int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
 }
 
 int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
+    if (h->f64) {
+        ResetArgs64 r{};
+        r.state = h->d_state64; r.sbd = h->d_sbd; r.done = h->d_done; r.mask = d_mask;
+        r.tick2 = h->d_tick2; r.lane_seed = h->d_lane_seed; r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
+        r.n = h->n; r.stride = h->sstride; r.lane_offset = (uint64_t)h->cfg.lane_offset; r.seed = h->seed;
+        r.parity = (int32_t)h->tslot;
+        HIP_TRY(h, launch_reset_f64(r, h->stream));
+        h->tick += 1; h->tslot ^= 1;
+        return GYMNET_OK;
+    }
     ResetArgs r{};
     r.state = h->d_state; r.obs = h->d_obs; r.sbd = h->d_sbd; r.done = h->d_done;
     r.mask = d_mask;
@@ -201,9 +343,13 @@ int write_tick(gymnet_vecenv *h) {
 
 // queues the copies of the current results to host buffers (any may be NULL) without the closing synchronize;
 // only for handles without the host-mapped small-batch path
-int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+int queue_copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
-    if (obs_out) {
+    if (obs_out && h->f64) {
+        ST_TRY(ensure_staging(h, false, true, false));
+        HIP_TRY(h, launch_pack_obs_f64(d.obs_dim, h->d_state64, h->sstride, h->d_pack64, h->n, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack64, (size_t)h->n * d.obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else if (obs_out) {
         ST_TRY(ensure_staging(h, false, true, false));
         HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
         HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -214,21 +360,26 @@ int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t 
 }
 
 // copy the current results to host buffers (any may be NULL); blocks
-int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+int copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
-    if (h->pin_block && (obs_out || reward_out || done_out) && (!obs_out || obs_out == h->pin_obs) &&
+    const size_t esz = h->f64 ? sizeof(double) : sizeof(float);      // element size of an observation at the boundary
+    if (h->pin_block && (obs_out || reward_out || done_out) && (!obs_out || obs_out == (void *)h->pin_obs) &&
         (!reward_out || reward_out == h->pin_reward) && (!done_out || done_out == h->pin_done)) {
         // the caller reads the library's pinned buffers: ONE kernel writes the results across PCIe, no staging, no memcpy calls
-        HIP_TRY(h, launch_export_host(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, obs_out, reward_out, done_out, h->n, h->stream));
+        if (h->f64) HIP_TRY(h, launch_export_host_f64(d.obs_dim, h->d_state64, h->sstride, h->d_reward, h->d_done, static_cast<double *>(obs_out), reward_out, done_out, h->n, h->stream));
+        else HIP_TRY(h, launch_export_host(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, static_cast<float *>(obs_out), reward_out, done_out, h->n, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GYMNET_OK;
     }
     if (h->hm_block) {   // latency path for small batches: one export kernel into host-mapped memory, one sync, host memcpy
-        if (obs_out || reward_out || done_out)
+        if ((obs_out || reward_out || done_out) && h->f64)
+            HIP_TRY(h, launch_export_small_f64(d.obs_dim, h->d_state64, h->sstride, h->d_reward, h->d_done, reinterpret_cast<double *>(h->hm_obs),
+                                               reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr, h->n, h->stream));
+        else if (obs_out || reward_out || done_out)
             HIP_TRY(h, launch_export_small(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, h->hm_obs,
                                            reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr, h->n, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (obs_out) std::memcpy(obs_out, h->hm_obs, (size_t)h->n * d.obs_dim * sizeof(float));
+        if (obs_out) std::memcpy(obs_out, h->hm_obs, (size_t)h->n * d.obs_dim * esz);
         if (reward_out) std::memcpy(reward_out, h->hm_reward, (size_t)h->n * sizeof(float));
         if (done_out) std::memcpy(done_out, h->hm_done, (size_t)h->n);
         return GYMNET_OK;
@@ -298,8 +449,11 @@ int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_
     // MI355X, replay beats eager launches up to ~2^18 CartPole lanes (2.6 vs 5.7 us/step at 2^16), ties at 2^19
     // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
     const bool launch_bound = (size_t)h->n * (size_t)h->desc->algorithmic_bytes < ((size_t)24 << 20);
-    const char *force = std::getenv("GYMNET_GRAPH");
-    const bool use_graph = graph_mode >= 0 ? graph_mode != 0 : (force ? std::atoi(force) != 0 : launch_bound);
+    if (graph_mode < 0) graph_mode = h->graph_mode;          // gymnet_vecenv_set_launch_policy(.graph)
+#ifdef GYMNET_PROBE_ENV
+    if (graph_mode < 0) { if (const char *force = std::getenv("GYMNET_GRAPH")) graph_mode = std::atoi(force) != 0; }
+#endif
+    const bool use_graph = graph_mode >= 0 ? graph_mode != 0 : launch_bound;
     if (use_graph && glen <= 4096 && steps >= glen) {
         const int parity = h->tslot, cparity = (int)(h->step_launches & 1u), cur = h->cur;
         GraphEntry *ge = nullptr;
@@ -443,6 +597,15 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt needs d_ext_obs and GYMNET_FLAG_DOUBLE_BUFFER");
     if (cfg->d_ext_obs_alt && cfg->d_ext_obs_alt == cfg->d_ext_obs)
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt must be a different buffer than d_ext_obs");
+    if (cfg->flags & GYMNET_FLAG_F64) {
+        if (cfg->env_id != GYMNET_ENV_CARTPOLE)
+            return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 exists for CartPole only (the one env whose float64 arithmetic the reference defines)");
+        if (cfg->flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER))
+            return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 cannot be combined with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER");
+        if (cfg->d_ext_obs) return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 keeps its own (float64) state arrays: no d_ext_obs");
+    }
+    if ((cfg->flags & GYMNET_FLAG_COMPACT_RECORDS_ONLY) && !(cfg->flags & GYMNET_FLAG_DONE_LIST))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "GYMNET_FLAG_COMPACT_RECORDS_ONLY needs GYMNET_FLAG_DONE_LIST");
 
     int ndev = 0;
     int s = gymnet_device_count(&ndev);
@@ -458,6 +621,8 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     h->seed = cfg->seed;
     h->autoreset = (cfg->flags & GYMNET_FLAG_AUTORESET) != 0;
     h->double_buffer = (cfg->flags & GYMNET_FLAG_DOUBLE_BUFFER) != 0;
+    h->f64 = (cfg->flags & GYMNET_FLAG_F64) != 0;
+    h->compact_only = (cfg->flags & GYMNET_FLAG_COMPACT_RECORDS_ONLY) != 0;
     const EnvDesc &d = *h->desc;
     DeviceScope dev_scope;
 
@@ -482,7 +647,9 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 
     const int64_t padded = (h->n + 63) / 64 * 64;   // every component array starts 256-byte aligned
     h->padded = padded;
-    if (cfg->d_ext_obs) {
+    if (h->f64) {
+        CREATE_TRY(dalloc(h, &h->d_state64, (size_t)padded * d.state_dim)); h->sstride = padded; h->ostride = padded;
+    } else if (cfg->d_ext_obs) {
         if (d.alias) { h->d_state = cfg->d_ext_obs; h->sstride = cfg->ext_obs_stride; h->d_obs = h->d_state; h->ostride = h->sstride; }
         else {
             h->d_obs = cfg->d_ext_obs; h->ostride = cfg->ext_obs_stride;
@@ -505,7 +672,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     CREATE_TRY(dalloc(h, &h->d_after_done, (size_t)kShards * kAfterStride));
     CREATE_TRY(dalloc(h, &h->d_bad, 1));
     if (h->n <= kSmallHostPath) {
-        const size_t a_bytes = (size_t)padded * 4, o_bytes = (size_t)padded * d.obs_dim * 4, r_bytes = (size_t)padded * 4, d_bytes = (size_t)padded;
+        const size_t a_bytes = (size_t)padded * 4, o_bytes = (size_t)padded * d.obs_dim * (h->f64 ? 8 : 4), r_bytes = (size_t)padded * 4, d_bytes = (size_t)padded;
         if (hipHostMalloc(&h->hm_block, a_bytes + o_bytes + r_bytes + d_bytes, hipHostMallocMapped) == hipSuccess) {
             char *b = static_cast<char *>(h->hm_block);
             h->hm_actions = b; h->hm_obs = reinterpret_cast<float *>(b + a_bytes);
@@ -545,7 +712,8 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     }
     recompute_extras(h);
     // defined start: zero state, reward, done; sbd = -1
-    CREATE_HIP(hipMemsetAsync(h->d_state, 0, (size_t)h->sstride * (d.state_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
+    if (h->f64) CREATE_HIP(hipMemsetAsync(h->d_state64, 0, (size_t)padded * d.state_dim * 8, h->stream));
+    else CREATE_HIP(hipMemsetAsync(h->d_state, 0, (size_t)h->sstride * (d.state_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     if (h->d_obs_alt) CREATE_HIP(hipMemsetAsync(h->d_obs_alt, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_reward, 0, (size_t)padded * 4, h->stream));
@@ -555,57 +723,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     if (h->d_sbd) CREATE_HIP(launch_fill_i32(h->d_sbd, -1, h->n, h->stream));
     CREATE_TRY(write_tick(h));
 
-    // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
-    const bool can_vec4 = aligned16(h->d_state) && aligned16(h->d_obs) && (h->sstride % 4 == 0) && (h->ostride % 4 == 0) &&
-                          (!h->d_obs_alt || aligned16(h->d_obs_alt));
-    // Launch policy, measured on MI355X with tools/probe_step.hip and bench.py (profiles/probe_r01.txt, DESIGN.md §4),
-    // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
-    //  - <= 24 MiB (2^19 CartPole lanes): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
-    //  - <= 48 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
-    //  - <= 768 MiB (state fits the 256 MiB Infinity Cache): dwordx4, state cacheable, action / reward / done streamed
-    //    past it, so the next launch re-reads the state from the cache;
-    //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal;
-    //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
-    const size_t step_bytes = (size_t)h->n * (size_t)d.algorithmic_bytes;
-    const bool alu_bound = cfg->env_id == GYMNET_ENV_ACROBOT;
-    if (alu_bound || step_bytes <= ((size_t)24 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
-    else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
-    else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
-    else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
-    if (!can_vec4) h->lcfg.vec = 1;
-    // Acrobot's wide form is TWO lanes per thread whose arithmetic rides the packed FP32 instructions (envs.hpp).  Opt-in
-    // (GYMNET_VEC=2): bit-identical, 287 instead of 454 VALU per env-step, and slower — 15.0 vs 14.2 us at 2^20 lanes, 13.6 vs
-    // 12.3 us per 2^20 lanes at 2^23 (profiles/acrobot_probes_r02.txt).
-    const bool can_vec2 = aligned_to(h->d_state, 8) && aligned_to(h->d_obs, 8) && (h->sstride % 2 == 0) && (h->ostride % 2 == 0) &&
-                          (!h->d_obs_alt || aligned_to(h->d_obs_alt, 8));
-    if (const char *e = std::getenv("GYMNET_VEC")) {
-        int v = std::atoi(e);
-        if (v == 1 || (v == 4 && can_vec4 && !alu_bound) || (v == 2 && can_vec2 && alu_bound)) h->lcfg.vec = v;
-    }
-    if (const char *e = std::getenv("GYMNET_NT")) { int v = std::atoi(e); if (v == 0 || v == 12 || v == 15) h->lcfg.nt = v; }
-    // Acrobot's multi-lane kernel (step_kernel_pipe: all loads first, then compute / store lane after lane) wins where the
-    // one-shot kernel would run as ~2 lock-step wave generations: it turns the launch into ONE generation of 4096 waves whose
-    // stores drain under the next lane's arithmetic.  Measured (profiles/acrobot_probes_r02.txt, us per 2^20 lanes, one-shot
-    // vs k = ceil(n / 2^18) lanes per thread): n = 2^19 15.1 vs 14.5, 3*2^18 13.9 vs 13.9, 2^20 14.9 vs 13.1, 5*2^18 13.7 vs
-    // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
-    if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
-    if (const char *e = std::getenv("GYMNET_ITEMS")) { int v = std::atoi(e); if (v >= 1 && v <= 5) h->lcfg.items = v; }
-    // Wave-compacted fused reset (kernels.hip: reset_pending_wave) wherever the dwordx4 lean kernel of an env whose observation IS
-    // its state runs: the wave's finished sub-lanes are drawn in ONE Philox pass by its first lanes instead of 1.6 mostly idle
-    // passes.  CartPole at 2^20 lanes: 6.91 -> 6.52 us per launch, bit-identical (profiles/forms_probe_r03.txt).
-    h->lcfg.reset_form = (d.alias && h->lcfg.vec == 4) ? 1 : 0;
-    if (const char *e = std::getenv("GYMNET_RESET_FORM")) { int v = std::atoi(e); if (v == 0 || v == 1) h->lcfg.reset_form = v; }
-    // producer / consumer form of the multi-lane kernel: whole 512-lane tiles and 16-byte aligned rows only
-    const bool lds_ok = alu_bound && can_vec4 && (h->n % 512) == 0;
-    // Opt-in (GYMNET_LDS_PIPE=1): bit-identical and SLOWER at 2^20 lanes — 13.5-14.9 vs 11.7-12.7 us (profiles/acrobot_lds_r03.txt):
-    // the computing waves' waits on memory instructions drop from 34 % to 21 % of their cycles, the s_barrier per tile adds more.
-    if (const char *e = std::getenv("GYMNET_LDS_PIPE")) { if (std::atoi(e) == 1 && lds_ok) h->lcfg.lds_pipe = 1; }
-    if (const char *e = std::getenv("GYMNET_LDS")) { int v = std::atoi(e); if (v >= 0 && v <= 160 * 1024) h->lcfg.lds_bytes = v; }
-    // 64-thread workgroups for the dwordx4 kernels of the smallest payloads (< 40 MiB per vector step at dwordx4: MountainCar and
-    // Pendulum at 2^20 lanes): such a launch is ramp / drain bound, and one-wave workgroups ramp and retire faster — MountainCar 4.92-5.05
-    // -> 4.55-4.73 us, Pendulum 5.97 -> 5.88 us; CartPole (41 MiB) does not gain (tools/gpu_nt_ab_r03.sh, profiles/block_nt_probe_r03.txt)
-    if (h->lcfg.vec == 4 && step_bytes < ((size_t)40 << 20)) h->lcfg.block = 64;
-    if (const char *e = std::getenv("GYMNET_BLOCK")) { int b = std::atoi(e); if (b == 64 || b == 128 || b == 256) h->lcfg.block = b; }
+    default_policy(h);
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = h;
@@ -665,7 +783,7 @@ int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
     });
 }
 
-int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out) {
+int gymnet_vecenv_reset(gymnet_vecenv *h, void *obs_out) {
     return guarded([&]() -> int {
     ENTER(h);
     ST_TRY(launch_reset_lanes(h, nullptr));
@@ -673,7 +791,7 @@ int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out) {
     });
 }
 
-int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out) {
+int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, void *obs_out) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!mask && h->autoreset) return copy_out(h, obs_out, nullptr, nullptr);   // no-op, see gymnet_vecenv_reset_where_device
@@ -686,13 +804,13 @@ int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_
     });
 }
 
-int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, float **obs, float **reward, uint8_t **done) {
+int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, void **obs, float **reward, uint8_t **done) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!h->pin_block) {
         const EnvDesc &d = *h->desc;
         auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };          // every buffer on its own page
-        const size_t a_b = up((size_t)h->n * 4), o_b = up((size_t)h->n * d.obs_dim * 4), r_b = up((size_t)h->n * 4), d_b = up((size_t)h->n);
+        const size_t a_b = up((size_t)h->n * 4), o_b = up((size_t)h->n * d.obs_dim * (h->f64 ? 8 : 4)), r_b = up((size_t)h->n * 4), d_b = up((size_t)h->n);
         void *blk = nullptr;
         hipError_t e = hipHostMalloc(&blk, a_b + o_b + r_b + d_b, hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, GYMNET_ERR_OOM, "hipHostMalloc(%zu bytes, mapped) failed: %s", a_b + o_b + r_b + d_b, hipGetErrorString(e)); }
@@ -709,7 +827,7 @@ int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, float **obs, fl
     });
 }
 
-int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) {
+int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
@@ -720,7 +838,7 @@ int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, fl
     });
 }
 
-int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_out, float *reward_out, uint8_t *done_out) {
+int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
     ENTER(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
@@ -753,7 +871,7 @@ int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions) {
     });
 }
 
-int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+int gymnet_vecenv_step_wait(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!h->async_pending) return fail(h, GYMNET_ERR_NOT_STEPPING, "not running an async step");
@@ -762,7 +880,7 @@ int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out,
     });
 }
 
-int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out) {
+int gymnet_vecenv_read(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
     ENTER(h);
     return copy_out(h, obs_out, reward_out, done_out);
@@ -793,6 +911,7 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
+    if (h->f64) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no GYMNET_FLAG_F64 variant; use gymnet_vecenv_rollout_device");
     if (h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no DONE_LIST / EPISODE_STATS / FINAL_OBS / per-lane-seed variant");
     if (h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device");
     if (steps == 0) return GYMNET_OK;
@@ -814,12 +933,16 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     });
 }
 
-int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor) {
+int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, void *d_obs_rowmajor) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!d_obs_rowmajor) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor is null");
     if (!aligned16(d_obs_rowmajor)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor must be 16-byte aligned");
-    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_obs, h->ostride, d_obs_rowmajor, h->n, h->stream));
+    if (h->f64) {
+        HIP_TRY(h, launch_pack_obs_f64(h->desc->obs_dim, h->d_state64, h->sstride, static_cast<double *>(d_obs_rowmajor), h->n, h->stream));
+        return GYMNET_OK;
+    }
+    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_obs, h->ostride, static_cast<float *>(d_obs_rowmajor), h->n, h->stream));
     return GYMNET_OK;
     });
 }
@@ -839,7 +962,9 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     out->struct_size = sizeof *out;
     out->state_dim = h->desc->state_dim; out->obs_dim = h->desc->obs_dim; out->obs_aliases_state = h->desc->alias;
     out->num_envs = h->n; out->state_stride = h->sstride; out->obs_stride = h->ostride;
-    out->d_state = h->d_state; out->d_obs = h->d_obs; out->d_reward = h->d_reward; out->d_done = h->d_done;
+    out->d_state = h->f64 ? (void *)h->d_state64 : (void *)h->d_state; out->d_obs = h->f64 ? (void *)h->d_state64 : (void *)h->d_obs;
+    out->state_dtype = h->f64 ? GYMNET_DTYPE_F64 : GYMNET_DTYPE_F32;
+    out->d_reward = h->d_reward; out->d_done = h->d_done;
     out->d_steps_beyond_done = h->d_sbd; out->d_final_obs = h->d_final_obs; out->d_done_list = h->d_done_compact;
     out->d_episode_return = h->d_ep_ret; out->d_episode_length = h->d_ep_len;
     out->d_finished_return = h->d_fin_ret; out->d_finished_length = h->d_fin_len;
@@ -864,16 +989,24 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
 int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity) {
     return guarded([&]() -> int {
     if (!h || !buf || capacity < 1) return fail(h, GYMNET_ERR_INVALID_ARG, "null handle / buffer");
+    if (h->f64) { describe_step_kernel_f64(h->autoreset, h->extras, h->lcfg.vec, h->lcfg.nt, buf, (size_t)capacity); return GYMNET_OK; }
     if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, buf, (size_t)capacity) < 0)
         return fail(h, GYMNET_ERR_INVALID_ARG, "unknown env");
     return GYMNET_OK;
     });
 }
 
-int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa) {
+int gymnet_vecenv_get_state(gymnet_vecenv *h, void *state_soa_v) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    if (!state_soa_v) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    if (h->f64) {
+        HIP_TRY(h, hipMemcpy2DAsync(state_soa_v, (size_t)h->n * 8, h->d_state64, (size_t)h->sstride * 8, (size_t)h->n * 8, (size_t)h->desc->state_dim,
+                                    hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return GYMNET_OK;
+    }
+    float *state_soa = static_cast<float *>(state_soa_v);
     for (int k = 0; k < h->desc->state_dim; ++k)      // row by row: a row the observation repeats lives in the observation array
         HIP_TRY(h, hipMemcpyAsync(state_soa + (size_t)k * h->n, state_row(h, k), (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -881,10 +1014,17 @@ int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa) {
     });
 }
 
-int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa) {
+int gymnet_vecenv_set_state(gymnet_vecenv *h, const void *state_soa_v) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (!state_soa) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    if (!state_soa_v) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
+    if (h->f64) {
+        HIP_TRY(h, hipMemcpy2DAsync(h->d_state64, (size_t)h->sstride * 8, state_soa_v, (size_t)h->n * 8, (size_t)h->n * 8, (size_t)h->desc->state_dim,
+                                    hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return GYMNET_OK;
+    }
+    const float *state_soa = static_cast<const float *>(state_soa_v);
     for (int k = 0; k < h->desc->state_dim; ++k)
         HIP_TRY(h, hipMemcpyAsync(state_row(h, k), state_soa + (size_t)k * h->n, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
     if (!h->desc->alias)
@@ -1036,8 +1176,8 @@ int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_
     return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_fin_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_EPISODE_STATS");
-    // with a done list the step writes compact records only: bring the dense view up to date for the most recent step
-    if (h->d_rec_ret && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
+    // GYMNET_FLAG_COMPACT_RECORDS_ONLY: the step wrote compact records only — bring the dense view up to date for the most recent step
+    if (h->compact_only && h->d_rec_ret && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
     if (finished_return) HIP_TRY(h, hipMemcpyAsync(finished_return, h->d_fin_ret, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     if (finished_length) HIP_TRY(h, hipMemcpyAsync(finished_length, h->d_fin_len, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1050,7 +1190,7 @@ int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
     ENTER(h);
     if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
     if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
-    if (h->d_rec_obs && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
+    if (h->compact_only && h->d_rec_obs && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
     ST_TRY(ensure_staging(h, false, true, false));
     HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_final_obs, h->n, h->d_pack, h->n, h->stream));
     HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1162,6 +1302,102 @@ int gymnet_vecenv_sample_actions(gymnet_vecenv *h, void *actions_out, uint64_t s
     ENTER(h);
     HIP_TRY(h, hipMemcpyAsync(actions_out, h->d_actions, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_set_launch_policy(gymnet_vecenv *h, const gymnet_launch_policy *p) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!p) return fail(h, GYMNET_ERR_INVALID_ARG, "policy is null");
+    if (p->struct_size != sizeof(gymnet_launch_policy))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "policy.struct_size %u != %zu (ABI mismatch)", p->struct_size, sizeof(gymnet_launch_policy));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));     // no launch of the old configuration is still being captured / replayed
+    return apply_policy(h, *p, /*strict=*/true);
+    });
+}
+
+int gymnet_vecenv_get_launch_policy(gymnet_vecenv *h, gymnet_launch_policy *out) {
+    return guarded([&]() -> int {
+    if (!h || !out) return fail(h, GYMNET_ERR_INVALID_ARG, "null argument");
+    out->struct_size = sizeof *out;
+    out->vec = h->lcfg.vec; out->block = h->lcfg.block; out->nt = h->lcfg.nt; out->sequential_lanes = h->lcfg.items;
+    out->reset_form = h->lcfg.reset_form; out->lds_pipe = h->lcfg.lds_pipe; out->occupancy_lds_bytes = h->lcfg.lds_bytes;
+    out->graph = h->graph_mode;
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_get_seed(gymnet_vecenv *h, uint64_t *seed, int32_t *per_lane) {
+    return guarded([&]() -> int {
+    if (!h) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");
+    if (seed) *seed = h->seed;
+    if (per_lane) *per_lane = h->d_lane_seed ? 1 : 0;
+    return GYMNET_OK;
+    });
+}
+
+}  // extern "C"
+
+namespace {
+// the per-lane array behind a gymnet_array_id: device pointer, bytes, row stride / rows for the one 2-D member
+struct ArrayRef { void *p; size_t row_bytes; int rows; size_t pitch; const char *needs; };
+ArrayRef array_ref(gymnet_vecenv *h, int which) {
+    const size_t n = (size_t)h->n;
+    switch (which) {
+        case GYMNET_ARRAY_REWARD: return {h->d_reward, n * 4, 1, 0, nullptr};
+        case GYMNET_ARRAY_DONE: return {h->d_done, n, 1, 0, nullptr};
+        case GYMNET_ARRAY_STEPS_BEYOND_DONE: return {h->d_sbd, n * 4, 1, 0, "CartPole without GYMNET_FLAG_AUTORESET"};
+        case GYMNET_ARRAY_EPISODE_RETURN: return {h->d_ep_ret, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
+        case GYMNET_ARRAY_EPISODE_LENGTH: return {h->d_ep_len, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
+        case GYMNET_ARRAY_FINISHED_RETURN: return {h->d_fin_ret, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
+        case GYMNET_ARRAY_FINISHED_LENGTH: return {h->d_fin_len, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
+        case GYMNET_ARRAY_FINAL_OBS: return {h->d_final_obs, n * 4, h->desc->obs_dim, n * 4, "GYMNET_FLAG_FINAL_OBS"};
+        case GYMNET_ARRAY_LANE_SEEDS: return {h->d_lane_seed, n * 8, 1, 0, "per-lane seeds (gymnet_vecenv_seed_lanes)"};
+        default: return {nullptr, 0, 0, 0, "a gymnet_array_id"};
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int gymnet_vecenv_get_array(gymnet_vecenv *h, int32_t which, void *out, int64_t bytes) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!out) return fail(h, GYMNET_ERR_INVALID_ARG, "out is null");
+    // with compact records only, the dense "last finished episode" arrays are brought up to date first (as their getters do)
+    if (h->compact_only && h->last_cparity >= 0 &&
+        (((which == GYMNET_ARRAY_FINISHED_RETURN || which == GYMNET_ARRAY_FINISHED_LENGTH) && h->d_rec_ret) || (which == GYMNET_ARRAY_FINAL_OBS && h->d_rec_obs)))
+        ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
+    const ArrayRef a = array_ref(h, which);
+    if (!a.p) return fail(h, which < 0 || which > GYMNET_ARRAY_LANE_SEEDS ? GYMNET_ERR_INVALID_ARG : GYMNET_ERR_UNSUPPORTED, "array %d needs %s", which, a.needs);
+    if (bytes != (int64_t)(a.row_bytes * a.rows)) return fail(h, GYMNET_ERR_INVALID_ARG, "array %d holds %zu bytes, caller passed %lld", which, a.row_bytes * a.rows, (long long)bytes);
+    HIP_TRY(h, hipMemcpyAsync(out, a.p, a.row_bytes * a.rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GYMNET_OK;
+    });
+}
+
+int gymnet_vecenv_set_array(gymnet_vecenv *h, int32_t which, const void *in, int64_t bytes) {
+    return guarded([&]() -> int {
+    ENTER(h);
+    if (!in) return fail(h, GYMNET_ERR_INVALID_ARG, "in is null");
+    if (which == GYMNET_ARRAY_LANE_SEEDS && !h->d_lane_seed) {
+        // installs per-lane keys WITHOUT touching the engine tick (gymnet_vecenv_seed_lanes rewinds it): checkpoint restore
+        if (bytes != h->n * 8) return fail(h, GYMNET_ERR_INVALID_ARG, "array %d holds %lld bytes, caller passed %lld", which, (long long)h->n * 8, (long long)bytes);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!h->d_lane_seed_buf) ST_TRY(dalloc(h, &h->d_lane_seed_buf, (size_t)h->n));
+        h->d_lane_seed = h->d_lane_seed_buf;
+        recompute_extras(h);
+        drop_graphs(h);
+    }
+    const ArrayRef a = array_ref(h, which);
+    if (!a.p) return fail(h, which < 0 || which > GYMNET_ARRAY_LANE_SEEDS ? GYMNET_ERR_INVALID_ARG : GYMNET_ERR_UNSUPPORTED, "array %d needs %s", which, a.needs);
+    if (bytes != (int64_t)(a.row_bytes * a.rows)) return fail(h, GYMNET_ERR_INVALID_ARG, "array %d holds %zu bytes, caller passed %lld", which, a.row_bytes * a.rows, (long long)bytes);
+    HIP_TRY(h, hipMemcpyAsync(a.p, in, a.row_bytes * a.rows, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the compacted done list / records describe the step that produced the PREVIOUS flags: not part of a restored state
+    if (which == GYMNET_ARRAY_DONE) h->last_cparity = -1;
     return GYMNET_OK;
     });
 }

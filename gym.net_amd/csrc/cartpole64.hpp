@@ -8,10 +8,10 @@
 // therefore its episode lengths, free-running, for as long as the caller likes.  It moves 73 B per env-step instead of 41.
 //
 // Compiled with -ffp-contract=off like the rest of the library: every operation below is one IEEE-754 binary64 operation in
-// the order written, `/` is correctly rounded division, so the CPU restatement (oracle/classic_control_ref.c:
-// ref_cartpole_step_f64_kernel) reproduces every result BIT FOR BIT.  The single place where this file and the reference can
+// the order written, `/` is correctly rounded division, so the CPU restatement the tests check against (the test
+// infrastructure's float64 "kernel semantics" twin) reproduces every result BIT FOR BIT.  The single place where this file and the reference can
 // differ is sin / cos: the reference calls Math.Sin / Math.Cos (the platform's libm, <= 1 ulp), this file evaluates its own
-// (below, <= 1.5 ulp measured) — a last-bit difference in sin(theta) that moves a state by <= 1e-17 per step.
+// (below, < 0.75 ulp for the angles of a live episode) — a last-bit difference in sin(theta) that moves a state by <= 1e-17 per step.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,8 +27,9 @@ namespace gymnet {
 //   kernels on |r| <= pi/4: the minimax polynomials published with Sun's fdlibm (k_sin.c / k_cos.c: degree 13 / 14, the same
 //     coefficients every libm descended from it uses), evaluated in Horner form; the cosine as w + ((1 - w) - z/2 + z^2 C(z))
 //     with w = 1 - z/2, which keeps the rounding of 1 - z/2 out of the result.
-// Accuracy against a 200-bit reference over |x| <= 8e5: <= 1.5 ulp (tests/test_oracle.py); for |x| <= pi/4 (every CartPole
-// pole angle before the episode ends) n = 0, the reduction is the identity and the error is the polynomials' (< 1 ulp).
+// Accuracy against a 200-bit reference (tests/test_oracle.py): < 0.75 ulp for |x| <= pi/4 — every CartPole pole angle before
+// the episode ends: n = 0, the reduction is the identity and the error is the polynomials' — and <= 2.1 ulp over |x| <= 8e5
+// (the reduced argument is kept in one double, without a tail).
 // Larger arguments (a pole left spinning for ~1e5 steps after `done`), infinities and NaN take the OCML routines.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out) {

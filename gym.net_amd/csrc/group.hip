@@ -340,6 +340,8 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "global_num_envs %lld must be a positive multiple of num_members %d",
                     (long long)cfg->global_num_envs, G);
     if (cfg->gather < GYMNET_GATHER_NONE || cfg->gather > GYMNET_GATHER_RCCL) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad gather mode");
+    if (cfg->flags & GYMNET_FLAG_F64)
+        return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 handles keep their own float64 state arrays: they cannot be group members");
     int ndev = 0;
     ST_TRY(gymnet_device_count(&ndev));
 

@@ -52,6 +52,11 @@ struct gymnet_vecenv {
     // d_state_alt / d_obs_alt are what the next step writes, and the pairs swap after every step launch.
     float *d_state = nullptr, *d_obs = nullptr;
     float *d_state_alt = nullptr, *d_obs_alt = nullptr;
+    // GYMNET_FLAG_F64 (CartPole only): the state — which IS the observation — lives in d_state64 [4][sstride] as binary64 and
+    // d_state / d_obs stay NULL; every host-boundary buffer that carries observations or state then holds doubles.
+    bool f64 = false;
+    double *d_state64 = nullptr;
+    double *d_pack64 = nullptr;    // row-major staging of the float64 observations (allocated on first use)
     bool double_buffer = false;
     int cur = 0;                   // index of the buffer d_obs points at (0 = the one reset first wrote)
     float *d_reward = nullptr;
@@ -89,6 +94,9 @@ struct gymnet_vecenv {
     bool async_pending = false;
     std::atomic<bool> busy{false};
     gymnet::LaunchCfg lcfg{4, 256, 0, 0, 1};
+    int graph_mode = -1;           // gymnet_launch_policy.graph: -1 = by batch size, 0 = eager launches, 1 = hipGraph replay
+    bool can_vec4 = false, can_vec2 = false, lds_ok = false;   // what the buffers' alignment / the batch size allow (set at create)
+    bool compact_only = false;     // GYMNET_FLAG_COMPACT_RECORDS_ONLY
     std::vector<gymnet::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     std::vector<void *> owned;     // device allocations to free
@@ -167,8 +175,9 @@ int launch_one_step(gymnet_vecenv *h, const void *d_actions);       // one vecto
 int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask);    // NULL = all lanes
 int stage_host_actions(gymnet_vecenv *h, const void *actions, const void **d_use, bool validate_now);
 int validate_staged_actions(gymnet_vecenv *h, const void *d_actions);
-int queue_copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);   // no final sync (large-batch path)
-int copy_out(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);         // blocks
+// obs_out: float32 [n, obs_dim], or float64 for a GYMNET_FLAG_F64 handle
+int queue_copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out);   // no final sync (large-batch path)
+int copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out);         // blocks
 // graph_mode: -1 = by batch size (replay only while launch-bound), 0 = eager launches, 1 = always replay a captured graph
 int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode = -1);
 int write_tick(gymnet_vecenv *h);

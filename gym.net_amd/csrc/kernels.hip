@@ -462,16 +462,19 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
         reward[j] = rw;
 
         if constexpr (EXTRAS) {
-            // Without a done list the finished lanes' records go to the dense per-lane arrays (scattered 4-byte stores, one
-            // cache line each).  With one (below) they are written COMPACTED at the lane's position in the list instead.
-            if (!a.done_list && fin && a.final_obs && (!GUARD || i0 + j < n)) {
+            // The finished lanes' records go to the dense per-lane arrays (scattered 4-byte stores, one cache line each) whenever
+            // those are handed in — always, unless the caller opted for compact records only (GYMNET_FLAG_COMPACT_RECORDS_ONLY:
+            // capi.hip then passes NULL here) — so the dense "last finished episode per lane" view is current after any sequence
+            // of launches, read or not.  With a done list (below) they are ALSO written compacted at the lane's
+            // position in the list.
+            if (fin && a.final_obs && (!GUARD || i0 + j < n)) {
 #pragma unroll
                 for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
             }
             if (stats && fin && (!GUARD || i0 + j < n)) {
                 fin_ret[j] = ep_ret[j];
                 fin_len[j] = ep_len[j];
-                if (!a.done_list) { a.fin_ret[i0 + j] = ep_ret[j]; a.fin_len[i0 + j] = ep_len[j]; }
+                if (a.fin_ret) { a.fin_ret[i0 + j] = ep_ret[j]; a.fin_len[i0 + j] = ep_len[j]; }
                 if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
             }
         }

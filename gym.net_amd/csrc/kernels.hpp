@@ -19,14 +19,15 @@ struct StepArgs {
     int32_t *sbd;            // [n] CartPole steps_beyond_done (CartPoleEnv.cs:41); NULL with auto-reset
     uint64_t *tick2;         // device tick, double-buffered: launch with tick t reads tick2[t&1], writes tick2[(t+1)&1]=t+1
     // extras (all NULL / 0 in the lean hot-path variant)
-    float *final_obs;        // [O][n]
+    float *final_obs;        // [O][n] dense terminal observations; NULL = none kept / compact records only
     // Done-lane compaction is SHARDED: 4096 waves hammering one counter word serialise at ~88 atomics/us (46 us per
     // step at 2^20 lanes, measured); wave w appends to shard w % kShards, each shard has its own counter (64-byte
     // stride) and its own segment of the list.  compact_done gathers the segments into one list on demand.
     int32_t *done_list;      // [kShards][done_cap] segmented
     uint32_t *done_count2;   // [2][kShards * kCountStride]: this launch fills half [cparity] and zeroes half [cparity^1]
     int64_t done_cap;        // entries per shard segment
-    float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;
+    float *ep_ret; int32_t *ep_len;
+    float *fin_ret; int32_t *fin_len;   // dense last-finished-episode arrays; NULL = compact records only (with done_list)
     // compact records, segmented like done_list (position p of shard s = the lane at done_list[s * done_cap + p]):
     float *rec_ret; int32_t *rec_len;   // [kShards][done_cap]     finished episode's return / length   (EPISODE_STATS + DONE_LIST)
     float *rec_obs;                     // [kShards][O][done_cap]  terminal observation                  (FINAL_OBS + DONE_LIST)
@@ -58,6 +59,42 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
 // The template instantiation launch_step would run for this configuration, as text ("step_kernel<CartPole,4,true,false,15,1>");
 // returns the length, or < 0 for an unknown env.
 int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, char *buf, size_t cap);
+
+// ---- GYMNET_FLAG_F64: CartPole in the reference's own binary64 arithmetic (cartpole64.hpp, kernels64.hip) ------------------
+// 73 B per env-step: 32 B state read + 4 B action + 32 B state written (the observation IS the state) + 4 B reward + 1 B done.
+struct StepArgs64 {
+    double *state;           // [4][stride]  x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144), read and written in place
+    const int32_t *action;   // [n]
+    float *reward;           // [n]   (Step.Reward is a C# float, Step.cs:9)
+    uint8_t *done;           // [n]
+    int32_t *sbd;            // [n] steps_beyond_done (CartPoleEnv.cs:41); NULL with auto-reset
+    uint64_t *tick2;         // as StepArgs
+    float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;   // EPISODE_STATS (NULL without)
+    const uint64_t *lane_seed;
+    unsigned long long *after_done;
+    int64_t n, stride;
+    uint64_t lane_offset, seed;
+    int32_t parity, max_episode_steps;
+};
+// vec: 2 (16-byte accesses on the state rows) or 1; nt as LaunchCfg::nt
+hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, hipStream_t st);
+int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, char *buf, size_t cap);
+struct ResetArgs64 {
+    double *state; int32_t *sbd; uint8_t *done;
+    const uint8_t *mask;      // NULL = all lanes
+    uint64_t *tick2; const uint64_t *lane_seed;
+    float *ep_ret; int32_t *ep_len;
+    int64_t n, stride;
+    uint64_t lane_offset, seed;
+    int32_t parity;
+};
+hipError_t launch_reset_f64(const ResetArgs64 &a, hipStream_t st);
+// float64 twins of launch_pack_obs / launch_export_small / launch_export_host (obs_dim 4 only: CartPole)
+hipError_t launch_pack_obs_f64(int obs_dim, const double *obs, int64_t stride, double *out_rowmajor, int64_t n, hipStream_t st);
+hipError_t launch_export_small_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                                   double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
+hipError_t launch_export_host_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                                  double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
 
 // Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
 struct RolloutArgs {

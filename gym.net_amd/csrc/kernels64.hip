@@ -1,0 +1,254 @@
+// kernels64.hip — GYMNET_FLAG_F64: the CartPole step / reset / export kernels over binary64 structure-of-arrays state.
+//
+// Same design rules as kernels.hip (one env per lane, SoA rows, 16-byte accesses where the row allows, static block -> lane map,
+// one ballot + one atomic per wave for the step-after-done counter), for the path whose ARITHMETIC is the reference's own
+// (cartpole64.hpp): 73 B per env-step against ~45 binary64 operations, three of them IEEE divisions.  A thread owns VEC = 2
+// consecutive lanes: one dwordx4 per state row and direction, one dwordx2 for the actions and the rewards, one 16-bit store
+// for the done flags.  Compiled with -ffp-contract=off.
+#include "kernels.hpp"
+
+#include <cstdio>
+
+#include "cartpole64.hpp"
+
+namespace gymnet {
+
+namespace {
+
+template <class T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
+
+// VEC consecutive elements of one SoA row; `full` = all VEC lanes are inside the batch (else element by element)
+template <class T, int VEC, bool NT>
+__device__ __forceinline__ void load_row(const T *__restrict__ p, int64_t i0, int64_t n, bool full, T (&v)[VEC]) {
+    if constexpr (VEC > 1) {
+        if (full) {
+            typedef typename VecOf<T, VEC>::type V;
+            V t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p + i0));
+            else t = *reinterpret_cast<const V *>(p + i0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = t[j];
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (i0 + j < n) { if constexpr (NT) v[j] = __builtin_nontemporal_load(p + i0 + j); else v[j] = p[i0 + j]; }
+        else v[j] = T(0);
+    }
+}
+
+template <class T, int VEC, bool NT>
+__device__ __forceinline__ void store_row(T *__restrict__ p, int64_t i0, int64_t n, bool full, const T (&v)[VEC]) {
+    if constexpr (VEC > 1) {
+        if (full) {
+            typedef typename VecOf<T, VEC>::type V;
+            V t;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) t[j] = v[j];
+            if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<V *>(p + i0));
+            else *reinterpret_cast<V *>(p + i0) = t;
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+        if (i0 + j < n) { if constexpr (NT) __builtin_nontemporal_store(v[j], p + i0 + j); else p[i0 + j] = v[j]; }
+}
+
+__device__ __forceinline__ uint32_t lane_id64() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+}  // namespace
+
+// ONE launch advances every lane by one env-step.  NT as in kernels.hip: 1 state loads, 2 state stores, 4 action load,
+// 8 reward / done stores.  EXTRAS: episode return / length bookkeeping, the max_episode_steps truncation, per-lane seeds.
+template <int VEC, bool AUTORESET, bool EXTRAS, int NT>
+__global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
+    constexpr int S = CartPole64::S;
+    constexpr bool NT_SL = (NT & 1) != 0, NT_SS = (NT & 2) != 0, NT_A = (NT & 4) != 0, NT_O = (NT & 8) != 0;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t n = a.n;
+    if (i0 >= n) return;
+    const bool full = i0 + VEC <= n;
+
+    double s[S][VEC];
+#pragma unroll
+    for (int k = 0; k < S; ++k) load_row<double, VEC, NT_SL>(a.state + k * a.stride, i0, n, full, s[k]);
+    int32_t act[VEC];
+    load_row<int32_t, VEC, NT_A>(a.action, i0, n, full, act);
+    int32_t sbd[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sbd[j] = -1;
+    if constexpr (!AUTORESET) load_row<int32_t, VEC, NT_SL>(a.sbd, i0, n, full, sbd);
+    float ep_ret[VEC];
+    int32_t ep_len[VEC];
+    bool stats = false;
+    if constexpr (EXTRAS) {
+        stats = a.ep_ret != nullptr;
+        if (stats) { load_row<float, VEC, NT_SL>(a.ep_ret, i0, n, full, ep_ret); load_row<int32_t, VEC, NT_SL>(a.ep_len, i0, n, full, ep_len); }
+    }
+
+    float reward[VEC];
+    uint8_t done[VEC];
+    uint32_t after = 0;            // lanes of this thread stepped although they had already returned done (CartPoleEnv.cs:176-179)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        double sj[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+        bool dn;
+        CartPole64::step(sj, act[j], dn);
+        float rw = 1.0f;                                                             // :168-183
+        if constexpr (!AUTORESET) {
+            if (dn) {
+                if (sbd[j] == -1) sbd[j] = 0;
+                else { after += (i0 + j < n) ? 1u : 0u; sbd[j] += 1; rw = 0.0f; }
+            }
+        }
+        uint8_t db = dn ? 1 : 0;
+        if constexpr (EXTRAS) {
+            if (stats) {
+                ep_ret[j] += rw;
+                ep_len[j] += 1;
+                if (a.max_episode_steps > 0 && ep_len[j] >= a.max_episode_steps) db |= 2;      // truncated (extension)
+                if (db && i0 + j < n) {
+                    a.fin_ret[i0 + j] = ep_ret[j];
+                    a.fin_len[i0 + j] = ep_len[j];
+                    if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
+                }
+            }
+        }
+        if constexpr (AUTORESET) {
+            if (db) {                                                                // the caller's `if (done) Reset()`, fused
+                uint64_t key = a.seed;
+                if constexpr (EXTRAS) { if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j]; }
+                CartPole64::reset(sj, key, a.lane_offset + (uint64_t)(i0 + j), tick);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+        reward[j] = rw;
+        done[j] = db;
+    }
+
+    if constexpr (!AUTORESET) {       // one 64-bit atomic per wave, and only if the wave has something to report
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t c = 1; c <= (uint32_t)VEC; ++c) total += c * (uint32_t)__popcll(__ballot(after == c));
+        if (total && lane_id64() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) {
+            const uint32_t shard = (uint32_t)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kShards - 1));
+            atomicAdd(&a.after_done[shard * kAfterStride], (unsigned long long)total);
+        }
+    }
+
+    store_row<float, VEC, NT_O>(a.reward, i0, n, full, reward);
+    store_row<uint8_t, VEC, NT_O>(a.done, i0, n, full, done);
+#pragma unroll
+    for (int k = 0; k < S; ++k) store_row<double, VEC, NT_SS>(a.state + k * a.stride, i0, n, full, s[k]);
+    if constexpr (!AUTORESET) store_row<int32_t, VEC, NT_SS>(a.sbd, i0, n, full, sbd);
+    if constexpr (EXTRAS) {
+        if (stats) { store_row<float, VEC, NT_SS>(a.ep_ret, i0, n, full, ep_ret); store_row<int32_t, VEC, NT_SS>(a.ep_len, i0, n, full, ep_len); }
+    }
+}
+
+// Reset: all lanes, or the lanes selected by a byte mask (which may alias a.done: a lane's flag is read before it is cleared)
+__global__ __launch_bounds__(256) void reset_kernel_f64(const ResetArgs64 a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    if (i >= a.n) return;
+    if (a.mask && !a.mask[i]) return;
+    double s[4];
+    CartPole64::reset(s, a.lane_seed ? a.lane_seed[i] : a.seed, a.lane_offset + (uint64_t)i, tick);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.state[k * a.stride + i] = s[k];
+    if (a.sbd) a.sbd[i] = -1;            // CartPoleEnv.cs:64
+    if (a.done) a.done[i] = 0;
+    if (a.ep_ret) { a.ep_ret[i] = 0.0f; a.ep_len[i] = 0; }
+}
+
+// SoA [4][stride] -> row-major [n][4] float64 (what an NDArray<double> of shape (N, 4) holds); optionally reward / done beside
+// it (the host boundary: `out_*` may be host-mapped memory, in which case the stores are the PCIe transfer)
+__global__ __launch_bounds__(256) void export_f64_kernel(const double *__restrict__ obs, int64_t stride, const float *__restrict__ reward,
+                                                         const uint8_t *__restrict__ done, double *__restrict__ out_obs,
+                                                         float *__restrict__ out_reward, uint8_t *__restrict__ out_done, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (out_obs) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 lo, hi;
+        lo.x = obs[i]; lo.y = obs[stride + i]; hi.x = obs[2 * stride + i]; hi.y = obs[3 * stride + i];
+        d2 *dst = reinterpret_cast<d2 *>(out_obs + i * 4);            // 32 contiguous bytes per lane, 2 KiB per wave
+        dst[0] = lo; dst[1] = hi;
+    }
+    if (out_reward) out_reward[i] = reward[i];
+    if (out_done) out_done[i] = done[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid64(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
+
+hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, hipStream_t st) {
+    if (vec != 2) vec = 1;
+    if (nt != 12 && nt != 15) nt = 0;
+    const int64_t threads = (a.n + vec - 1) / vec;
+    const dim3 grid(grid64(threads > 0 ? threads : 1, 256)), blk(256);
+#define GYMNET_L64(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel_f64<V, AR, EX, NTM>), grid, blk, 0, st, a)
+#define GYMNET_L64_NT(V, AR, EX)                                  \
+    do {                                                          \
+        if (nt == 15) GYMNET_L64(V, AR, EX, 15);                  \
+        else if (nt == 12) GYMNET_L64(V, AR, EX, 12);             \
+        else GYMNET_L64(V, AR, EX, 0);                            \
+    } while (0)
+#define GYMNET_L64_EX(V, AR)                                      \
+    do {                                                          \
+        if (extras) GYMNET_L64_NT(V, AR, true);                   \
+        else GYMNET_L64_NT(V, AR, false);                         \
+    } while (0)
+    if (vec == 2) { if (autoreset) GYMNET_L64_EX(2, true); else GYMNET_L64_EX(2, false); }
+    else          { if (autoreset) GYMNET_L64_EX(1, true); else GYMNET_L64_EX(1, false); }
+#undef GYMNET_L64_EX
+#undef GYMNET_L64_NT
+#undef GYMNET_L64
+    return hipGetLastError();
+}
+
+int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, char *buf, size_t cap) {
+    if (vec != 2) vec = 1;
+    if (nt != 12 && nt != 15) nt = 0;
+    return std::snprintf(buf, cap, "step_kernel_f64<%d,%s,%s,%d>", vec, autoreset ? "true" : "false", extras ? "true" : "false", nt);
+}
+
+hipError_t launch_reset_f64(const ResetArgs64 &a, hipStream_t st) {
+    hipLaunchKernelGGL(reset_kernel_f64, dim3(grid64(a.n > 0 ? a.n : 1, 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_obs_f64(int obs_dim, const double *obs, int64_t stride, double *out, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (obs_dim != 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(export_f64_kernel, dim3(grid64(n, 256)), dim3(256), 0, st, obs, stride, (const float *)nullptr,
+                       (const uint8_t *)nullptr, out, (float *)nullptr, (uint8_t *)nullptr, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_small_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                                   double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (obs_dim != 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(export_f64_kernel, dim3(grid64(n, 256)), dim3(256), 0, st, obs, stride, reward, done, out_obs, out_reward, out_done, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_host_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                                  double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st) {
+    return launch_export_small_f64(obs_dim, obs, stride, reward, done, out_obs, out_reward, out_done, n, st);
+}
+
+}  // namespace gymnet

@@ -83,13 +83,21 @@ class VectorEnv:
     def __init__(self, env="CartPole-v1", num_envs=1, device=0, seed=0, auto_reset=False,
                  validate_actions=False, done_list=False, episode_stats=False, final_obs=False,
                  lane_offset=0, stream=None, ext_obs=None, ext_obs_stride=0, max_episode_steps=0,
-                 double_buffer=False, ext_obs_alt=None):
+                 double_buffer=False, ext_obs_alt=None, dtype=np.float32, compact_records_only=False, launch_policy=None):
+        """dtype=np.float64 (CartPole only) selects GYMNET_FLAG_F64: the reference's own float64 arithmetic, float64 state and
+        float64 observations (what CartPoleEnv.Step actually returns, CartPoleEnv.cs:166,185); the default float32 is the
+        engine's structure-of-arrays hot path.  launch_policy: dict for SetLaunchPolicy (probes / tests that pin a kernel form)."""
         env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
         self._lib = capi.load_library()
         self._info = capi.env_describe(env_id)
+        self._dtype = np.dtype(dtype)
+        if self._dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
         flags = ((capi.FLAG_AUTORESET if auto_reset else 0) | (capi.FLAG_VALIDATE_ACTIONS if validate_actions else 0)
                  | (capi.FLAG_DONE_LIST if done_list else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0)
-                 | (capi.FLAG_FINAL_OBS if final_obs else 0) | (capi.FLAG_DOUBLE_BUFFER if double_buffer else 0))
+                 | (capi.FLAG_FINAL_OBS if final_obs else 0) | (capi.FLAG_DOUBLE_BUFFER if double_buffer else 0)
+                 | (capi.FLAG_F64 if self._dtype == np.float64 else 0)
+                 | (capi.FLAG_COMPACT_RECORDS_ONLY if compact_records_only else 0))
         cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=env_id, num_envs=int(num_envs),
                           lane_offset=int(lane_offset), device=int(device), flags=flags,
                           seed=int(seed) & 0xFFFFFFFFFFFFFFFF, stream=_ptr(stream), d_ext_obs=_ptr(ext_obs),
@@ -99,9 +107,10 @@ class VectorEnv:
         self._owns_handle = True
         self._bookkeeping = bool(episode_stats or max_episode_steps)
         self._final_obs = bool(final_obs)
-        self._lane_seeds = False
         capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
         self._describe(env_id, num_envs, auto_reset)
+        if launch_policy:
+            self.SetLaunchPolicy(**launch_policy)
 
     @classmethod
     def _borrow(cls, handle, env_id, num_envs, auto_reset):
@@ -111,8 +120,9 @@ class VectorEnv:
         self._info = capi.env_describe(env_id)
         self._h = handle
         self._owns_handle = False
-        self._bookkeeping, self._lane_seeds = True, False     # a group member: flags unknown here, Checkpoint() refuses
+        self._bookkeeping = True            # a group member: flags unknown here (DoneRecords() asks for everything it may have)
         self._final_obs = False
+        self._dtype = np.dtype(np.float32)
         self._describe(env_id, num_envs, auto_reset)
         return self
 
@@ -130,7 +140,9 @@ class VectorEnv:
         else:
             self.ActionSpace = Discrete(int(i.action_n))
             self._adtype = np.int32
+        # the DECLARED dtype stays float32 (CartPoleEnv.cs:48) even when the arrays returned are float64, exactly as in the reference
         self.ObservationSpace = Box(np.array(i.obs_low[:self.ObsDim], np.float32), np.array(i.obs_high[:self.ObsDim], np.float32), dtype=np.float32)
+        self.Dtype = self._dtype            # dtype of the observation / state arrays this handle hands out
         self.Metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 50}   # CartPoleEnv.cs:51
         self.RewardRange = (float(i.reward_low), float(i.reward_high))
         self.Environments = []          # VecEnv.cs:17 — deliberately empty, see module docstring
@@ -162,25 +174,23 @@ class VectorEnv:
     def Seed(self, seed):                                                            # VecEnv.cs:44-53
         if isinstance(seed, (int, np.integer)):
             capi.check(self._lib.gymnet_vecenv_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
-            self._lane_seeds = False
         else:
             s = np.ascontiguousarray(np.asarray(seed, dtype=np.int64).astype(np.uint64))
             capi.check(self._lib.gymnet_vecenv_seed_lanes(self._h, _host(s), s.shape[0]))
-            self._lane_seeds = True
 
     # ---- host-boundary path ---------------------------------------------------------------------
     def _outs(self):
         n = self.NumberOfEnvironments
-        return (np.empty((n, self.ObsDim), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8))
+        return (np.empty((n, self.ObsDim), self._dtype), np.empty(n, np.float32), np.empty(n, np.uint8))
 
     def Reset(self):                                                                 # VecEnvWrapper.cs:18-20
-        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), self._dtype)
         capi.check(self._lib.gymnet_vecenv_reset(self._h, _host(obs)))
         return obs
 
     def ResetWhere(self, mask=None):
         """Batched `if (done) Reset()` (README.md:36-40). mask None = lanes whose last Done flag is set."""
-        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), self._dtype)
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
         if m is not None and m.shape[0] != self.NumberOfEnvironments:
             raise ValueError("mask length must equal NumberOfEnvironments")
@@ -216,7 +226,8 @@ class VectorEnv:
 
             def view(ptr, ctype, count, dtype, shape):
                 return np.frombuffer((ctype * count).from_address(ptr.value), dtype=dtype).reshape(shape)
-            self._pinned = (view(a, C.c_int32, n, self._adtype, (n,)), view(o, C.c_float, n * D, np.float32, (n, D)),
+            self._pinned = (view(a, C.c_int32, n, self._adtype, (n,)),
+                            view(o, C.c_double if self._dtype == np.float64 else C.c_float, n * D, self._dtype, (n, D)),
                             view(r, C.c_float, n, np.float32, (n,)), view(d, C.c_uint8, n, np.uint8, (n,)))
         return self._pinned
 
@@ -224,15 +235,15 @@ class VectorEnv:
         """gymnet_vecenv_step with CALLER-OWNED buffers (what a C# host with long-lived NDArrays does): actions [N] of the
         action dtype, obs_out float32 [N, D], reward_out float32 [N], done_out uint8 [N]; nothing is allocated."""
         n = self.NumberOfEnvironments
-        if (actions.dtype != self._adtype or obs_out.dtype != np.float32 or reward_out.dtype != np.float32 or done_out.dtype != np.uint8
+        if (actions.dtype != self._adtype or obs_out.dtype != self._dtype or reward_out.dtype != np.float32 or done_out.dtype != np.uint8
                 or actions.shape != (n,) or obs_out.shape != (n, self.ObsDim) or reward_out.shape != (n,) or done_out.shape != (n,)
                 or not (actions.flags.c_contiguous and obs_out.flags.c_contiguous and reward_out.flags.c_contiguous and done_out.flags.c_contiguous)):
             raise ValueError("StepInto needs C-contiguous buffers of the exact dtypes and shapes")
         capi.check(self._lib.gymnet_vecenv_step(self._h, _host(actions), _host(obs_out), _host(reward_out), _host(done_out)))
 
     def ResetInto(self, obs_out):
-        if obs_out.dtype != np.float32 or obs_out.shape != (self.NumberOfEnvironments, self.ObsDim) or not obs_out.flags.c_contiguous:
-            raise ValueError("ResetInto needs a C-contiguous float32 [N, D] buffer")
+        if obs_out.dtype != self._dtype or obs_out.shape != (self.NumberOfEnvironments, self.ObsDim) or not obs_out.flags.c_contiguous:
+            raise ValueError("ResetInto needs a C-contiguous [N, D] buffer of the handle's dtype")
         capi.check(self._lib.gymnet_vecenv_reset(self._h, _host(obs_out)))
 
     def StepAsync(self, action):                                                     # VecEnv.cs:63-65
@@ -318,6 +329,24 @@ class VectorEnv:
         capi.check(self._lib.gymnet_vecenv_launch_policy(self._h, C.byref(v), C.byref(b), C.byref(nt), C.byref(sq)))
         return {"envs_per_thread": v.value, "block": b.value, "nontemporal_mask": nt.value, "sequential_lanes_per_thread": sq.value}
 
+    _POLICY_FIELDS = ("vec", "block", "nt", "sequential_lanes", "reset_form", "lds_pipe", "occupancy_lds_bytes", "graph")
+
+    def SetLaunchPolicy(self, **fields):
+        """gymnet_vecenv_set_launch_policy: override fields of the step kernel's launch configuration (vec, block, nt,
+        sequential_lanes, reset_form, lds_pipe, occupancy_lds_bytes, graph; unnamed fields stay).  Every configuration computes
+        bit-identical results; a value the handle cannot run raises ValueError.  (This replaces the GYMNET_* environment
+        variables of rounds 1-3: the library no longer reads the process environment.)"""
+        unknown = set(fields) - set(self._POLICY_FIELDS)
+        if unknown:
+            raise TypeError(f"unknown launch policy field(s): {sorted(unknown)}")
+        p = capi.LaunchPolicy(struct_size=C.sizeof(capi.LaunchPolicy), **{k: int(fields.get(k, -1)) for k in self._POLICY_FIELDS})
+        capi.check(self._lib.gymnet_vecenv_set_launch_policy(self._h, C.byref(p)))
+
+    def GetLaunchPolicy(self):
+        p = capi.LaunchPolicy()
+        capi.check(self._lib.gymnet_vecenv_get_launch_policy(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k in self._POLICY_FIELDS}
+
     def KernelName(self):
         """The template instantiation the next step launch runs, as the launcher itself resolves it
         (e.g. "step_kernel<CartPole,4,true,false,15,1>")."""
@@ -327,12 +356,12 @@ class VectorEnv:
 
     # ---- state access / bookkeeping -----------------------------------------------------------------
     def GetState(self):
-        s = np.empty((self.StateDim, self.NumberOfEnvironments), np.float32)
+        s = np.empty((self.StateDim, self.NumberOfEnvironments), self._dtype)
         capi.check(self._lib.gymnet_vecenv_get_state(self._h, _host(s)))
         return s
 
     def SetState(self, state_soa):
-        s = np.ascontiguousarray(np.asarray(state_soa, dtype=np.float32))
+        s = np.ascontiguousarray(np.asarray(state_soa, dtype=self._dtype))
         if s.shape != (self.StateDim, self.NumberOfEnvironments):
             raise ValueError(f"state must have shape ({self.StateDim}, {self.NumberOfEnvironments})")
         capi.check(self._lib.gymnet_vecenv_set_state(self._h, _host(s)))
@@ -412,31 +441,63 @@ class VectorEnv:
         capi.check(self._lib.gymnet_vecenv_final_obs(self._h, _host(o)))
         return o
 
+    # ---- per-lane arrays by id (gymnet_vecenv_get_array / _set_array) -------------------------------------------------
+    _ARRAYS = {"reward": (capi.ARRAY_REWARD, np.float32), "done": (capi.ARRAY_DONE, np.uint8),
+               "steps_beyond_done": (capi.ARRAY_STEPS_BEYOND_DONE, np.int32),
+               "episode_return": (capi.ARRAY_EPISODE_RETURN, np.float32), "episode_length": (capi.ARRAY_EPISODE_LENGTH, np.int32),
+               "finished_return": (capi.ARRAY_FINISHED_RETURN, np.float32), "finished_length": (capi.ARRAY_FINISHED_LENGTH, np.int32),
+               "final_obs": (capi.ARRAY_FINAL_OBS, np.float32), "lane_seeds": (capi.ARRAY_LANE_SEEDS, np.uint64)}
+
+    def GetArray(self, name):
+        """One of the handle's per-lane arrays by name (see _ARRAYS); "final_obs" is structure-of-arrays [D, N].
+        Raises NotImplementedError when the handle's configuration does not keep that array."""
+        which, dt = self._ARRAYS[name]
+        shape = (self.ObsDim, self.NumberOfEnvironments) if name == "final_obs" else (self.NumberOfEnvironments,)
+        a = np.empty(shape, dt)
+        capi.check(self._lib.gymnet_vecenv_get_array(self._h, which, _host(a), a.nbytes))
+        return a
+
+    def SetArray(self, name, value):
+        which, dt = self._ARRAYS[name]
+        a = np.ascontiguousarray(np.asarray(value, dtype=dt))
+        capi.check(self._lib.gymnet_vecenv_set_array(self._h, which, _host(a), a.nbytes))
+
+    def GetSeed(self):
+        """(Philox key in use, whether per-lane keys from Seed(int[]) are active)."""
+        s, per = C.c_uint64(), C.c_int32()
+        capi.check(self._lib.gymnet_vecenv_get_seed(self._h, C.byref(s), C.byref(per)))
+        return s.value, bool(per.value)
+
     # ---- checkpoint / resume (an extension: the reference has none; everything the engine needs to continue bit for bit) ----
     def Checkpoint(self):
-        """State SoA, engine tick (the Philox counter word) and, without auto-reset, steps_beyond_done.  For a handle WITHOUT
-        episode bookkeeping (episode_stats / max_episode_steps) and without per-lane seeds, together with the seed the caller
-        already holds this determines every later step and reset draw: Restore() + the same actions reproduce the
-        continuation bit for bit (tests/test_gpu_cartpole.py::test_checkpoint_resume_is_bit_exact).  Other configurations
-        raise NotImplementedError rather than return a record that would not reproduce them.  (The done flags of the step
-        before the checkpoint are not part of it either: call ResetWhere() before Checkpoint(), not after Restore().)"""
-        if self._bookkeeping or self._lane_seeds:
-            # episode return / length (which drive max_episode_steps truncation), per-lane keys and the done flags ResetWhere(None)
-            # consumes are NOT in this record: a restored handle would truncate / draw differently (ADVICE r2)
-            raise NotImplementedError("Checkpoint() covers the plain configuration only: no episode_stats / max_episode_steps, "
-                                      "no Seed(int[]) keys")
-        ck = {"env_id": self.EnvId, "num_envs": self.NumberOfEnvironments, "state": self.GetState(), "tick": self.Tick}
-        if not self.AutoReset and self.EnvId == capi.ENV_CARTPOLE:
-            ck["steps_beyond_done"] = self.GetStepsBeyondDone()
+        """EVERY piece of state a handle carries, for ANY configuration (get_state / set_state double as checkpoint /
+        resume): the state SoA, the engine tick (the Philox counter word), the seed, and whichever per-lane arrays the handle
+        keeps — steps_beyond_done (CartPole without auto-reset), the reward / done flags of the last step (ResetWhere(None)
+        consumes them), running episode return / length (they drive the max_episode_steps truncation), the dense
+        finished-episode views, terminal observations, the per-lane Philox keys of Seed(int[]).  Restore() on a handle
+        created with the same arguments + the same actions reproduce the continuation bit for bit
+        (tests/test_gpu_cartpole.py::test_checkpoint_*).  Not part of it: the compacted done LIST of the step before the
+        checkpoint (a transient result; DoneLanes() on the restored handle reports none until the next step)."""
+        seed, per_lane = self.GetSeed()
+        ck = {"env_id": self.EnvId, "num_envs": self.NumberOfEnvironments, "dtype": self._dtype.name, "state": self.GetState(),
+              "tick": self.Tick, "seed": seed, "arrays": {}}
+        for name in self._ARRAYS:
+            if name == "lane_seeds" and not per_lane:
+                continue
+            try:
+                ck["arrays"][name] = self.GetArray(name)
+            except NotImplementedError:
+                pass                                   # this configuration does not keep that array
         return ck
 
     def Restore(self, ck):
-        if ck["env_id"] != self.EnvId or ck["num_envs"] != self.NumberOfEnvironments:
-            raise ValueError("checkpoint belongs to a different environment / batch size")
+        if ck["env_id"] != self.EnvId or ck["num_envs"] != self.NumberOfEnvironments or ck.get("dtype", "float32") != self._dtype.name:
+            raise ValueError("checkpoint belongs to a different environment / batch size / dtype")
+        self.Seed(int(ck["seed"]))                     # also rewinds the tick and drops per-lane keys; both are set again below
+        for name, value in ck["arrays"].items():
+            self.SetArray(name, value)                 # NotImplementedError: this handle lacks an array the checkpoint carries
         self.SetState(ck["state"])
         self.Tick = ck["tick"]
-        if "steps_beyond_done" in ck:
-            self.SetStepsBeyondDone(ck["steps_beyond_done"])
 
     # VecEnv.get_attr / set_attr (VecEnv.cs:74-92) select over IEnv objects; here the per-lane
     # attributes that exist are exposed by name.
@@ -594,13 +655,15 @@ class GpuEnv:
     Step(object action) -> Step.  Exists so an existing per-instance loop (README.md:32-52,
     tests/Gym.Tests/Envs/Classic/CartpoleEnvironment.cs:14-35) runs unmodified on the engine."""
     ENV = "CartPole-v1"
+    DTYPE = np.float32          # CartPoleEnv overrides: float64, the reference's own arithmetic
 
-    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0):
+    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0, dtype=None):
         """max_episode_steps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; an extension: the
         reference has no time limit): the step that reaches the limit returns Done with
         Information["TimeLimit.truncated"] = True — the same shape as the C# GpuEnv (csharp/GpuEnv.cs)."""
         self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions,
-                            episode_stats=max_episode_steps > 0, max_episode_steps=max_episode_steps)
+                            episode_stats=max_episode_steps > 0, max_episode_steps=max_episode_steps,
+                            dtype=self.DTYPE if dtype is None else dtype)
         self.ActionSpace, self.ObservationSpace = self._v.ActionSpace, self._v.ObservationSpace
         self.Metadata, self.RewardRange = self._v.Metadata, self._v.RewardRange
         self._pending = None
@@ -647,7 +710,12 @@ class GpuEnv:
 
 
 class CartPoleEnv(GpuEnv):
+    """Drop-in for `new CartPoleEnv()` (README.md:32-52).  Defaults to dtype=float64 — GYMNET_FLAG_F64, the reference's own
+    arithmetic (float64 state, the literal CartPoleEnv.cs:141-167 sequence) and its float64 observations (:166,185) — so an
+    existing per-instance loop sees the reference's states to the last few ulps and its exact episode lengths, free-running.
+    dtype=np.float32 selects the batched engine's float32 arithmetic (1e-5 per teacher-forced step)."""
     ENV = "CartPole-v1"
+    DTYPE = np.float64
 
 
 class PendulumEnv(GpuEnv):

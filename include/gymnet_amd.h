@@ -32,6 +32,10 @@
  *     float32[num_envs], done is uint8[num_envs] (0 / 1).
  *   - Dtypes: Discrete action int32; Box action float32; observation float32 (the DECLARED dtype
  *     of CartPoleEnv.ObservationSpace, CartPoleEnv.cs:48); reward float32 (Step.cs:9); done uint8.
+ *     A handle created with GYMNET_FLAG_F64 (CartPole) computes in the reference's ACTUAL arithmetic:
+ *     float64 state, and float64 observations at the boundary — what CartPoleEnv.Step really returns
+ *     (CartPoleEnv.cs:166,185: the float64 state NDArray itself).  Every `obs` / `state` buffer of
+ *     such a handle holds doubles; the parameters are typed void* for that reason.
  *   - A handle is single-caller-at-a-time (like an Env instance, which has no re-entrancy guard);
  *     different handles may be used from different threads.  All work of a handle is ordered on
  *     one HIP stream.
@@ -45,9 +49,12 @@
 extern "C" {
 #endif
 
-#define GYMNET_ABI_VERSION 3   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
+#define GYMNET_ABI_VERSION 4   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
                                   3: gymnet_env_info.{traffic_bytes_per_step,state_row_in_obs}, per-element Box sampling, compact
-                                     terminal observations, pinned host staging */
+                                     terminal observations, pinned host staging;
+                                  4: GYMNET_FLAG_F64 (float64 CartPole: observation / state buffers typed by the handle,
+                                     gymnet_device_view.state_dtype), GYMNET_FLAG_COMPACT_RECORDS_ONLY, gymnet_launch_policy +
+                                     set / get, gymnet_vecenv_get_array / _set_array / _get_seed (checkpoint of every array) */
 
 typedef enum gymnet_status {
     GYMNET_OK = 0,
@@ -76,6 +83,17 @@ typedef enum gymnet_env_id {
 #define GYMNET_FLAG_DONE_LIST        0x04u /* emit the compacted list of lanes that finished in the last step */
 #define GYMNET_FLAG_EPISODE_STATS    0x08u /* per-lane episode return / length bookkeeping (BasePlaySession.cs:58-69) */
 #define GYMNET_FLAG_FINAL_OBS        0x10u /* with AUTORESET: keep the terminal observation of lanes that finished */
+#define GYMNET_FLAG_F64              0x40u /* ABI 4, CartPole only: the reference's own arithmetic — float64 structure-of-arrays state, the literal
+                                              operation sequence of CartPoleEnv.cs:141-167 in binary64 (float32-valued constants widened at use),
+                                              reset draws with 53 random bits, float64 observations at the boundary.  Reproduces the reference's
+                                              episode lengths free-running (the float32 engine guarantees 1e-5 per teacher-forced step only).
+                                              73 B per env-step instead of 41.  Not combinable with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER /
+                                              d_ext_obs / the fused rollout / groups (GYMNET_ERR_UNSUPPORTED) */
+#define GYMNET_FLAG_COMPACT_RECORDS_ONLY 0x80u /* ABI 4, with DONE_LIST: the step kernel writes the finished lanes' episode records / terminal
+                                              observations ONLY as compact records (gymnet_vecenv_done_records); the dense per-lane views
+                                              (gymnet_vecenv_episode_stats / _final_obs, gymnet_device_view.d_finished_*) are then brought up to
+                                              date on demand, for the most recent step only.  Default (flag clear): the step kernel keeps the
+                                              dense views current itself, whatever the caller reads or skips */
 #define GYMNET_FLAG_DOUBLE_BUFFER    0x20u /* two observation buffers, written alternately: the step launched after buffer A was
                                               written reads A and writes B, so a consumer (an all-gather of A over xGMI, a policy
                                               reading A) may still be using A while the next step runs.  For envs whose observation
@@ -95,8 +113,11 @@ typedef struct gymnet_config {
     uint64_t seed;              /* Env.Seed(int) (CartPoleEnv.cs:196-198): Philox key */
     void    *stream;            /* hipStream_t to order all work on; NULL = the library creates its own */
     float   *d_ext_obs;         /* optional device buffer [obs_dim][ext_obs_stride] to keep observations in (e.g. this
-                                   rank's slice of an all-gather buffer); for envs whose observation IS the state
-                                   (CartPole, MountainCar) it becomes the live state storage.  NULL = library allocates */
+                                   rank's slice of an all-gather buffer).  It is LIVE STATE STORAGE, not an output copy: for
+                                   envs whose observation IS the state (CartPole, MountainCar) every row, and for the others
+                                   the rows listed in gymnet_env_info.state_row_in_obs (Pendulum obs[2]; Acrobot obs[4], obs[5]),
+                                   are read back by the next step.  A consumer must not modify them in place (normalise /
+                                   clip into its own buffer).  The same holds for d_ext_obs_alt.  NULL = library allocates */
     int64_t  ext_obs_stride;    /* elements between component arrays of d_ext_obs (>= num_envs) */
     int32_t  max_episode_steps; /* EXTENSION (the reference has no time limit): >0 truncates episodes;
                                    requires GYMNET_FLAG_EPISODE_STATS; done byte gets bit 1 (value 2) for truncation */
@@ -132,9 +153,9 @@ typedef struct gymnet_device_view {
     uint32_t struct_size;
     int32_t  state_dim, obs_dim, obs_aliases_state;
     int64_t  num_envs, state_stride, obs_stride;
-    float   *d_state;          /* [state_dim][state_stride]; rows listed in gymnet_env_info.state_row_in_obs are NOT kept here
-                                  (they are rows of d_obs) */
-    float   *d_obs;            /* [obs_dim][obs_stride] (== d_state when obs_aliases_state) */
+    void    *d_state;          /* [state_dim][state_stride] of state_dtype; rows listed in gymnet_env_info.state_row_in_obs are NOT
+                                  kept here (they are rows of d_obs) */
+    void    *d_obs;            /* [obs_dim][obs_stride] of state_dtype (== d_state when obs_aliases_state) */
     float   *d_reward;         /* [num_envs] */
     uint8_t *d_done;           /* [num_envs] */
     int32_t *d_steps_beyond_done; /* CartPole without AUTORESET: CartPoleEnv.cs:41 per lane; else NULL */
@@ -144,9 +165,27 @@ typedef struct gymnet_device_view {
     float   *d_finished_return; int32_t *d_finished_length;   /* last finished episode per lane */
     void    *stream;           /* hipStream_t all of the handle's work is ordered on */
     int32_t  obs_buffer;       /* GYMNET_FLAG_DOUBLE_BUFFER: index (0 / 1) of the buffer d_obs points at = the latest observation */
-    int32_t  reserved;
+    int32_t  state_dtype;      /* ABI 4: gymnet_dtype of d_state / d_obs — GYMNET_DTYPE_F32, or GYMNET_DTYPE_F64 for a GYMNET_FLAG_F64 handle */
     float   *d_obs_alt;        /* GYMNET_FLAG_DOUBLE_BUFFER: the other buffer = what the NEXT step will write; else NULL */
 } gymnet_device_view;
+
+typedef enum gymnet_dtype { GYMNET_DTYPE_F32 = 0, GYMNET_DTYPE_F64 = 1 } gymnet_dtype;
+
+/* ABI 4.  The step kernel's launch configuration.  The library chooses one at create from the batch size and the
+ * buffers' alignment; gymnet_vecenv_set_launch_policy overrides fields (every field: -1 = leave as it is).  All configurations
+ * of an env compute bit-identical results — this is a performance knob for probes, A/B timing and tests that pin a kernel form,
+ * set through the ABI so that a host process's ENVIRONMENT never changes which kernel the library runs. */
+typedef struct gymnet_launch_policy {
+    uint32_t struct_size;          /* = sizeof(gymnet_launch_policy) */
+    int32_t  vec;                  /* lanes per thread on wide accesses: 1, 4 (dwordx4 rows; not Acrobot), 2 (Acrobot packed-FP32 form; F64 handles) */
+    int32_t  block;                /* threads per workgroup: 64 / 128 / 256 */
+    int32_t  nt;                   /* non-temporal stream mask: 0 none, 12 action + reward / done, 15 every stream */
+    int32_t  sequential_lanes;     /* Acrobot's multi-lane kernel: lanes per thread, 1 (one-shot kernel) .. 5 */
+    int32_t  reset_form;           /* fused auto-reset: 0 per-thread drain loop, 1 wave-compacted (dwordx4 kernels of aliasing envs) */
+    int32_t  lds_pipe;             /* Acrobot: 1 = producer / consumer form of the multi-lane kernel (needs num_envs % 512 == 0) */
+    int32_t  occupancy_lds_bytes;  /* unused dynamic LDS per workgroup, for the one purpose of capping occupancy in probes */
+    int32_t  graph;                /* gymnet_vecenv_rollout_device: 0 eager launches, 1 hipGraph replay, -2 back to "by batch size" */
+} gymnet_launch_policy;
 
 typedef struct gymnet_counters {
     uint32_t struct_size;
@@ -181,25 +220,26 @@ int gymnet_vecenv_seed_lanes(gymnet_vecenv *h, const uint64_t *seeds, int64_t co
 
 /* ---- host-boundary path (what an NDArray-based caller uses) --------------------------------- */
 /* VecEnv.Reset() (VecEnvWrapper.cs:18-20) -> N x CartPoleEnv.Reset() (CartPoleEnv.cs:63-67): steps_beyond_done = -1,
- * state ~ U(-0.05,0.05)^4.  obs_out: host [num_envs, obs_dim] or NULL. */
-int gymnet_vecenv_reset(gymnet_vecenv *h, float *obs_out);
+ * state ~ U(-0.05,0.05)^4.  obs_out: host [num_envs, obs_dim] or NULL — float32, or float64 for a GYMNET_FLAG_F64 handle (here
+ * and in every call below that takes obs_out). */
+int gymnet_vecenv_reset(gymnet_vecenv *h, void *obs_out);
 /* The caller's `if (done) Reset()` (README.md:36-40), batched: resets exactly the lanes with mask[i] != 0;
  * mask == NULL resets the lanes whose last returned done flag is set.  obs_out as above (all lanes).
  * With GYMNET_FLAG_AUTORESET the step itself already re-drew every finished lane, so mask == NULL is a NO-OP that only
  * returns the current observations (it used to draw those lanes a second time); an explicit mask still resets. */
-int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, float *obs_out);
+int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, void *obs_out);
 /* EXTENSION of IVecEnv.Step (per-lane actions): N x CartPoleEnv.Step (CartPoleEnv.cs:137-186).
  * actions: host int32[num_envs] (Discrete) or float32[num_envs] (Box).  Outputs may each be NULL.  Blocks until
  * the outputs are written. */
-int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out);
+int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out);
 /* IVecEnv.Step(int action) (IVecEnv.cs:15, VecEnvWrapper.cs:22-24): ONE scalar action broadcast to all lanes. */
-int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, float *obs_out, float *reward_out, uint8_t *done_out);
+int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, void *obs_out, float *reward_out, uint8_t *done_out);
 /* VecEnv.StepAsync (VecEnv.cs:63-65) / Env.StepAsync (Env.cs:23-25): queue the step, return immediately.
  * A second call before gymnet_vecenv_step_wait -> GYMNET_ERR_ALREADY_STEPPING. */
 int gymnet_vecenv_step_async(gymnet_vecenv *h, const void *actions);
 /* step_wait(): block until the queued step finished and copy its results out.  Without a pending
  * gymnet_vecenv_step_async -> GYMNET_ERR_NOT_STEPPING. */
-int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
+int gymnet_vecenv_step_wait(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out);
 /* ABI 3.  Library-owned HOST buffers for this path, for a caller that can keep its NDArrays over unmanaged memory: actions
  * (int32 / float32 [num_envs]), obs (float32 [num_envs, obs_dim]), reward (float32 [num_envs]), done (uint8 [num_envs]) —
  * page-locked and mapped into the device, valid until gymnet_vecenv_destroy, allocated on the first call.  When the pointers
@@ -207,9 +247,9 @@ int gymnet_vecenv_step_wait(gymnet_vecenv *h, float *obs_out, float *reward_out,
  * the actions are DMA'd straight out of the pinned buffer and ONE kernel writes observations (row-major), rewards and done flags
  * across PCIe into the others (no device-side pack buffer, no per-array memcpy).  Ordinary caller-owned memory keeps working
  * (staged copies).  Any out pointer may be NULL. */
-int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, float **obs, float **reward, uint8_t **done);
+int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, void **obs, float **reward, uint8_t **done);
 /* Copy the results of the most recent step/reset again (Step record, Step.cs:8-10). */
-int gymnet_vecenv_read(gymnet_vecenv *h, float *obs_out, float *reward_out, uint8_t *done_out);
+int gymnet_vecenv_read(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out);
 
 /* ---- device-resident path (no PCIe on the hot path; everything stream-ordered, non-blocking) -- */
 int gymnet_vecenv_reset_device(gymnet_vecenv *h);
@@ -234,8 +274,9 @@ typedef struct gymnet_rollout_buffers {
  * per-lane seeds (GYMNET_ERR_UNSUPPORTED). */
 int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
                                        int64_t ring, const gymnet_rollout_buffers *rec);
-/* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout). */
-int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, float *d_obs_rowmajor);
+/* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout; float32, or float64 for a
+ * GYMNET_FLAG_F64 handle). */
+int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, void *d_obs_rowmajor);
 int gymnet_vecenv_sync(gymnet_vecenv *h);
 int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
 /* The launch configuration the handle chose for its step kernel (DESIGN.md §4 launch policy): lanes per thread on wide
@@ -243,6 +284,11 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out);
  * kernel that loads all of a thread's lanes first and then computes / stores them one after another (Acrobot; 1 = the
  * one-shot kernel).  Any out pointer may be NULL. */
 int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, int32_t *nt, int32_t *sequential_lanes);
+/* ABI 4.  Override / read back the whole launch configuration (struct above).  A value the handle cannot run (dwordx4 lanes on an
+ * unaligned external buffer, Acrobot's forms on another env, ...) -> GYMNET_ERR_INVALID_ARG and nothing changes.  Drops the
+ * handle's captured graphs.  Synchronizes the handle's stream. */
+int gymnet_vecenv_set_launch_policy(gymnet_vecenv *h, const gymnet_launch_policy *policy);
+int gymnet_vecenv_get_launch_policy(gymnet_vecenv *h, gymnet_launch_policy *out);
 /* ABI 3.  The kernel instantiation the handle's NEXT step launch runs, as text — e.g. "step_kernel<CartPole,4,true,false,15,1>"
  * (env, lanes per thread, AUTORESET, EXTRAS, non-temporal mask, reset form) or "step_kernel_pipe<Acrobot,4,true,15>".  It is
  * printed by the same function the launcher dispatches on, so a profile, a bench line or a parity test can name what ran
@@ -250,15 +296,39 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
 int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity);
 
 /* ---- state access: teacher-forced parity tests, checkpoint / resume -------------------------- */
-/* host float32 [state_dim][num_envs] (structure-of-arrays). CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */
-int gymnet_vecenv_get_state(gymnet_vecenv *h, float *state_soa);
-int gymnet_vecenv_set_state(gymnet_vecenv *h, const float *state_soa);
+/* host [state_dim][num_envs] (structure-of-arrays), float32 — float64 for a GYMNET_FLAG_F64 handle.
+ * CartPole: x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144). */
+int gymnet_vecenv_get_state(gymnet_vecenv *h, void *state_soa);
+int gymnet_vecenv_set_state(gymnet_vecenv *h, const void *state_soa);
 /* steps_beyond_done per lane (CartPoleEnv.cs:41); only for CartPole without AUTORESET, else GYMNET_ERR_UNSUPPORTED. */
 int gymnet_vecenv_get_steps_beyond_done(gymnet_vecenv *h, int32_t *out);
 int gymnet_vecenv_set_steps_beyond_done(gymnet_vecenv *h, const int32_t *in);
 int gymnet_vecenv_get_tick(gymnet_vecenv *h, uint64_t *tick);
 int gymnet_vecenv_set_tick(gymnet_vecenv *h, uint64_t tick);
 int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out);
+/* ABI 4.  Every per-lane array a handle keeps, by id — together with the state, the tick and the seed this is a COMPLETE
+ * checkpoint of any configuration (get_state / set_state double as checkpoint / resume): running episode return /
+ * length (which drive the max_episode_steps truncation), the reward / done flags of the last step (which reset_where(NULL)
+ * consumes), steps_beyond_done, the dense finished-episode views, the per-lane Philox keys of VecEnv.Seed(int[]).
+ * `bytes` must equal the array's size (num_envs x element size; FINAL_OBS: obs_dim x num_envs x 4, structure-of-arrays).
+ * An array the handle's configuration does not have -> GYMNET_ERR_UNSUPPORTED.  Both calls block.
+ * set(LANE_SEEDS) installs the keys WITHOUT rewinding the tick (gymnet_vecenv_seed_lanes rewinds it); set(DONE) also forgets the
+ * compacted done list of the step before (it described other flags). */
+typedef enum gymnet_array_id {
+    GYMNET_ARRAY_REWARD = 0,             /* float32 [num_envs] */
+    GYMNET_ARRAY_DONE = 1,               /* uint8   [num_envs]  (bit 0 terminated, bit 1 truncated) */
+    GYMNET_ARRAY_STEPS_BEYOND_DONE = 2,  /* int32   [num_envs]  CartPole without AUTORESET (CartPoleEnv.cs:41) */
+    GYMNET_ARRAY_EPISODE_RETURN = 3,     /* float32 [num_envs]  EPISODE_STATS: running */
+    GYMNET_ARRAY_EPISODE_LENGTH = 4,     /* int32   [num_envs] */
+    GYMNET_ARRAY_FINISHED_RETURN = 5,    /* float32 [num_envs]  EPISODE_STATS: last finished episode per lane */
+    GYMNET_ARRAY_FINISHED_LENGTH = 6,    /* int32   [num_envs] */
+    GYMNET_ARRAY_FINAL_OBS = 7,          /* float32 [obs_dim][num_envs]  FINAL_OBS */
+    GYMNET_ARRAY_LANE_SEEDS = 8          /* uint64  [num_envs]  after gymnet_vecenv_seed_lanes with distinct seeds */
+} gymnet_array_id;
+int gymnet_vecenv_get_array(gymnet_vecenv *h, int32_t which, void *out, int64_t bytes);
+int gymnet_vecenv_set_array(gymnet_vecenv *h, int32_t which, const void *in, int64_t bytes);
+/* The Philox key in use (Env.Seed(int), CartPoleEnv.cs:196-198) and whether per-lane keys are active.  Either out may be NULL. */
+int gymnet_vecenv_get_seed(gymnet_vecenv *h, uint64_t *seed, int32_t *per_lane);
 
 /* ---- episode bookkeeping (the step AFTER the path: BasePlaySession.cs:58-69) ------------------ */
 /* Lanes that finished in the most recent step (unordered). Needs GYMNET_FLAG_DONE_LIST. */
@@ -283,10 +353,10 @@ int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float 
                                       int64_t capacity, uint32_t *d_count);
 /* DENSE views, one row per lane.  Last finished episode's return and length per lane (0 length = none finished yet); needs
  * EPISODE_STATS.  Terminal observations, host [num_envs, obs_dim], rows of lanes that never finished are 0; needs FINAL_OBS.
- * Without GYMNET_FLAG_DONE_LIST the step kernel maintains these arrays itself (scattered stores).  WITH it the step writes the
- * compact records only, and each call of these getters first applies the records of the MOST RECENT step to the dense arrays:
- * a caller that reads them after every step sees the same values as before; records of steps it did not read are not in the
- * dense view (use gymnet_vecenv_done_records). */
+ * The step kernel maintains these arrays itself (scattered stores), so they are current after ANY sequence of steps, rollouts or
+ * graph replays, read or not.  Only with GYMNET_FLAG_COMPACT_RECORDS_ONLY (an opt-in beside DONE_LIST) does the step write the
+ * compact records alone; each call of these getters then first applies the records of the MOST RECENT step to the dense arrays,
+ * and records of steps the caller did not read are not in the dense view (use gymnet_vecenv_done_records every step). */
 int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length);
 int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out);
 

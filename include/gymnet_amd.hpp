@@ -239,7 +239,25 @@ public:
     std::string KernelName() const { char buf[128] = {0}; check(gymnet_vecenv_kernel_name(h_, buf, (int32_t)sizeof buf)); return buf; }
     /// Library-owned page-locked, device-mapped host buffers (valid until Close): stepping THROUGH them needs no staging copies.
     struct PinnedBuffers { void *actions; float *obs; float *reward; uint8_t *done; };
-    PinnedBuffers HostBuffers() { PinnedBuffers b{}; check(gymnet_vecenv_host_buffers(h_, &b.actions, &b.obs, &b.reward, &b.done)); return b; }
+    PinnedBuffers HostBuffers() {
+        PinnedBuffers b{};
+        void *obs = nullptr;                                                    // typed by the handle; this class creates float32 handles
+        check(gymnet_vecenv_host_buffers(h_, &b.actions, &obs, &b.reward, &b.done));
+        b.obs = static_cast<float *>(obs);
+        return b;
+    }
+    // ---- ABI 4 ------------------------------------------------------------------------------------------------------
+    /// Override fields of the step kernel's launch configuration (-1 = keep); every configuration is bit-identical.
+    void SetLaunchPolicy(gymnet_launch_policy p) { p.struct_size = sizeof p; check(gymnet_vecenv_set_launch_policy(h_, &p)); }
+    static gymnet_launch_policy KeepPolicy() { gymnet_launch_policy p; p.struct_size = sizeof p; p.vec = p.block = p.nt = p.sequential_lanes = p.reset_form = p.lds_pipe = p.occupancy_lds_bytes = p.graph = -1; return p; }
+    gymnet_launch_policy GetLaunchPolicy() const { gymnet_launch_policy p{}; check(gymnet_vecenv_get_launch_policy(h_, &p)); return p; }
+    /// Any per-lane array by id (checkpoint / resume of every configuration): T must be the array's element type.
+    template <class T> std::vector<T> GetArray(gymnet_array_id which, size_t count) const {
+        std::vector<T> a(count);
+        check(gymnet_vecenv_get_array(h_, (int32_t)which, a.data(), (int64_t)(count * sizeof(T))));
+        return a;
+    }
+    template <class T> void SetArray(gymnet_array_id which, const std::vector<T> &a) { check(gymnet_vecenv_set_array(h_, (int32_t)which, a.data(), (int64_t)(a.size() * sizeof(T)))); }
     /// gymnet_vecenv_step with caller-owned buffers (nothing is allocated): the pinned ones above, or any host memory.
     void StepInto(const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) { check(gymnet_vecenv_step(h_, actions, obs_out, reward_out, done_out)); }
     /// Compact records of the lanes that finished in the most recent step (DONE_LIST [+ EPISODE_STATS] [+ FINAL_OBS]).
@@ -336,8 +354,41 @@ private:
     int g_members_ = 0;
 };
 
-/// Single-instance Env façade (Env.cs:13-41; CartPoleEnv.cs:43-198) over a 1-lane VectorEnv, so the reference's
-/// own loop (README.md:32-52) compiles against it unchanged in shape.
+/// Single-instance Env façade in the reference's OWN arithmetic (GYMNET_FLAG_F64): float64 state, float64 observations — what
+/// `new CartPoleEnv().Step(a).Observation` really holds (CartPoleEnv.cs:141-166,185) — so the reference's loop
+/// (README.md:32-52) sees the reference's states to the last few ulps and its exact episode lengths, free-running.
+struct Step64 { std::vector<double> Observation; float Reward = 0.0f; bool Done = false; };
+class CartPoleEnv64 {
+public:
+    explicit CartPoleEnv64(int device = 0, uint64_t seed = 0, uint32_t extra_flags = 0) {
+        gymnet_config cfg{};
+        cfg.struct_size = sizeof cfg; cfg.env_id = GYMNET_ENV_CARTPOLE; cfg.num_envs = 1; cfg.device = device;
+        cfg.flags = GYMNET_FLAG_F64 | extra_flags; cfg.seed = seed;
+        check(gymnet_vecenv_create(&cfg, &h_));
+    }
+    CartPoleEnv64(const CartPoleEnv64 &) = delete;
+    CartPoleEnv64 &operator=(const CartPoleEnv64 &) = delete;
+    ~CartPoleEnv64() { CloseEnvironment(); }
+    std::vector<double> Reset() { std::vector<double> o(4); check(gymnet_vecenv_reset(h_, o.data())); return o; }   // CartPoleEnv.cs:63-67
+    Step64 Step(int action) {                                                   // CartPoleEnv.cs:137-186
+        Step64 s; s.Observation.resize(4);
+        uint8_t d = 0;
+        const int32_t a = action;
+        check(gymnet_vecenv_step(h_, &a, s.Observation.data(), &s.Reward, &d));
+        s.Done = d != 0;
+        return s;
+    }
+    void SetState(const std::vector<double> &x) { if (x.size() != 4) throw std::invalid_argument("state must hold 4 doubles"); check(gymnet_vecenv_set_state(h_, x.data())); }
+    std::vector<double> GetState() const { std::vector<double> x(4); check(gymnet_vecenv_get_state(h_, x.data())); return x; }
+    void Seed(int seed) { check(gymnet_vecenv_seed(h_, (uint64_t)seed)); }      // CartPoleEnv.cs:196-198
+    void CloseEnvironment() { if (h_) { gymnet_vecenv_destroy(h_); h_ = nullptr; } }   // CartPoleEnv.cs:189-194
+    gymnet_vecenv *handle() const { return h_; }
+private:
+    gymnet_vecenv *h_ = nullptr;
+};
+
+/// Single-instance Env façade (Env.cs:13-41; CartPoleEnv.cs:43-198) over a 1-lane float32 VectorEnv (the batched engine's
+/// arithmetic: 1e-5 per teacher-forced step; CartPoleEnv64 above is the reference-exact one).
 class CartPoleEnv {
 public:
     explicit CartPoleEnv(int device = 0, uint64_t seed = 0) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed) {}

@@ -62,6 +62,10 @@ def lib():
     L.ref_discrete_sample_masked_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _u8p, C.c_int64, _i32p, C.c_int64]
     L.ref_compose_discrete_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64]
     L.ref_box_uniform_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _f32p, C.c_int64]
+    L.ref_sincos_f64_kernel_batch.argtypes = [_f64p, _f64p, _f64p, C.c_int64]
+    L.ref_cartpole_step_batch_f64_kernel.argtypes = [_f64p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
+    L.ref_cartpole_reset_batch_f64.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, _f64p, C.c_int64]
+    L.ref_cartpole_autoreset_step_batch_f64.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, _f64p, _i32p, _f32p, _u8p, C.c_int64]
     L.ref_pendulum_step_f64.argtypes = [_f64p, C.c_double, _f64p, C.POINTER(C.c_double)]
     L.ref_pendulum_step_f32.argtypes = [_f32p, C.c_float, _f32p, C.POINTER(C.c_float)]
     L.ref_pendulum_reset_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
@@ -98,8 +102,10 @@ def cartpole_constants():
     return dict(zip(names, out.tolist()))
 
 
-def cartpole_step(state, action, sbd=None, dtype=np.float64):
-    """Batched CartPoleEnv.Step.  Returns (new_state[4,n] dtype, reward f32[n], done u8[n], sbd i32[n])."""
+def cartpole_step(state, action, sbd=None, dtype=np.float64, kernel_sincos=False):
+    """Batched CartPoleEnv.Step.  Returns (new_state[4,n] dtype, reward f32[n], done u8[n], sbd i32[n]).
+    dtype float64: the reference's arithmetic with libm sin / cos; kernel_sincos=True swaps in the GYMNET_FLAG_F64 kernel's own
+    sin / cos (the bit-identical twin of the float64 HIP kernel).  dtype float32: the float32 kernel's twin."""
     s = np.ascontiguousarray(np.array(state, dtype=dtype, copy=True))
     n = s.shape[1]
     a = np.ascontiguousarray(np.asarray(action, dtype=np.int32))
@@ -107,10 +113,44 @@ def cartpole_step(state, action, sbd=None, dtype=np.float64):
     reward = np.zeros(n, dtype=np.float32)
     done = np.zeros(n, dtype=np.uint8)
     if dtype == np.float64:
-        lib().ref_cartpole_step_batch_f64(s, a, b, reward, done, n)
+        (lib().ref_cartpole_step_batch_f64_kernel if kernel_sincos else lib().ref_cartpole_step_batch_f64)(s, a, b, reward, done, n)
     else:
         lib().ref_cartpole_step_batch_f32(s, a, b, reward, done, n)
     return s, reward, done, b
+
+
+def sincos_f64_kernel(x):
+    """The GYMNET_FLAG_F64 kernel's float64 sin/cos restated on the CPU (bit-identical to the GPU for |x| <= 823549)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    s = np.empty_like(x); c = np.empty_like(x)
+    lib().ref_sincos_f64_kernel_batch(x, s, c, x.shape[0])
+    return s, c
+
+
+def _lane_seed_ptr(lane_seed):
+    if lane_seed is None:
+        return None, None
+    keep = np.ascontiguousarray(np.asarray(lane_seed, dtype=np.uint64))
+    return keep, keep.ctypes.data_as(C.c_void_p)
+
+
+def cartpole_reset_f64(seed, lane0, tick, n, lane_seed=None):
+    """Reset draw of a GYMNET_FLAG_F64 handle: float64 SoA [4, n], 53-bit uniforms from two Philox calls per lane."""
+    out = np.zeros((4, n), dtype=np.float64)
+    keep, ls = _lane_seed_ptr(lane_seed)
+    lib().ref_cartpole_reset_batch_f64(seed, ls, lane0, tick, out, n)
+    return out
+
+
+def cartpole_autoreset_step_f64(seed, lane0, tick, state, action, lane_seed=None):
+    """One vector step of a GYMNET_FLAG_F64 handle with the fused auto-reset.  Returns (state[4,n] f64, reward, done u8)."""
+    s = np.ascontiguousarray(np.array(state, dtype=np.float64, copy=True))
+    n = s.shape[1]
+    a = np.ascontiguousarray(np.asarray(action, dtype=np.int32))
+    rew = np.zeros(n, dtype=np.float32); done = np.zeros(n, dtype=np.uint8)
+    keep, ls = _lane_seed_ptr(lane_seed)
+    lib().ref_cartpole_autoreset_step_batch_f64(seed, ls, lane0, tick, s, a, rew, done, n)
+    return s, rew, done
 
 
 def sincos_kernel(x, small=False):

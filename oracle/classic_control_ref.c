@@ -218,6 +218,82 @@ void ref_cartpole_step_batch_f32(float *soa, const int32_t *action, int32_t *sbd
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * GYMNET_FLAG_F64: the engine's float64 CartPole (gym.net_amd/csrc/cartpole64.hpp), restated operation for operation.
+ * It is ref_cartpole_step_f64 above — the literal CartPoleEnv.cs:141-167 sequence — with ONE substitution: Math.Sin / Math.Cos
+ * (libm there) become the kernel's own sin / cos below, built from IEEE mul / add / fma / rint only, so that this function and
+ * the HIP kernel agree BIT FOR BIT.  tests/test_oracle.py bounds the difference between the two sin/cos (<= 2 ulp) and hence
+ * between this function and ref_cartpole_step_f64.
+ * ---------------------------------------------------------------------------------------- */
+/* 3-part Cody-Waite reduction (pi/2 = P1 + P2 + P3 + ..., P1 / P2 cut to 33 bits: n * P1, n * P2 exact for |n| < 2^20) and the
+ * polynomial kernels published with Sun's fdlibm (k_sin.c / k_cos.c coefficients), Horner form.  |x| > 823549 -> libm. */
+void ref_sincos_f64_kernel(double x, double *s_out, double *c_out) {
+    if (!(fabs(x) <= 823549.0)) { *s_out = sin(x); *c_out = cos(x); return; }
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050630396597660e-11, r);
+    r = fma(-n, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *s_out = (q & 2) ? -ss : ss;
+    *c_out = ((q + 1) & 2) ? -cc : cc;
+}
+
+void ref_sincos_f64_kernel_batch(const double *x, double *s, double *c, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) ref_sincos_f64_kernel(x[i], &s[i], &c[i]);
+}
+
+int ref_cartpole_step_f64_kernel(double *state, int action, int *sbd, float *reward) {
+    double x = state[0], x_dot = state[1], theta = state[2], theta_dot = state[3];
+    float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;                           /* :146 */
+    double costheta, sintheta;
+    ref_sincos_f64_kernel(theta, &sintheta, &costheta);                                 /* :147-148, the kernel's own */
+    double temp = ((double)force + (double)CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta)
+                  / (double)CP_TOTAL_MASS;                                              /* :149 */
+    double thetaacc = ((double)CP_GRAVITY * sintheta - costheta * temp)
+                      / ((double)CP_LENGTH * (4.0 / 3.0 - (double)CP_MASSPOLE * costheta * costheta
+                                                            / (double)CP_TOTAL_MASS));  /* :150 */
+    double xacc = temp - (double)CP_POLEMASS_LENGTH * thetaacc * costheta
+                             / (double)CP_TOTAL_MASS;                                   /* :151 */
+    x = x + (double)CP_TAU * x_dot;                                                     /* :154 */
+    x_dot = x_dot + (double)CP_TAU * xacc;                                              /* :155 */
+    theta = theta + (double)CP_TAU * theta_dot;                                         /* :156 */
+    theta_dot = theta_dot + (double)CP_TAU * thetaacc;                                  /* :157 */
+    state[0] = x; state[1] = x_dot; state[2] = theta; state[3] = theta_dot;             /* :166 */
+    int done = x < -(double)CP_X_THRESHOLD || x > (double)CP_X_THRESHOLD
+            || theta < -(double)CP_THETA_THRESHOLD || theta > (double)CP_THETA_THRESHOLD; /* :167 */
+    if (!done) { *reward = 1.0f; }                                                      /* :168-183 */
+    else if (*sbd == -1) { *sbd = 0; *reward = 1.0f; }
+    else { *sbd += 1; *reward = 0.0f; }
+    return done;
+}
+
+void ref_cartpole_step_batch_f64_kernel(double *soa, const int32_t *action, int32_t *sbd,
+                                        float *reward, uint8_t *done, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        double s[4] = { soa[i], soa[n + i], soa[2 * n + i], soa[3 * n + i] };
+        int b = sbd[i];
+        done[i] = (uint8_t)ref_cartpole_step_f64_kernel(s, action[i], &b, &reward[i]);
+        sbd[i] = b;
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
 /* Discrete.Contains(int) — src/Gym/Spaces/Discrete.cs:38-40 (ignores Start, as the reference). */
 int ref_discrete_contains(int x, int n) { return x >= 0 && x < n; }
 
@@ -267,6 +343,41 @@ void ref_cartpole_reset_batch_f32(uint64_t seed, uint64_t lane0, uint64_t tick, 
     for (int64_t i = 0; i < n; ++i) {
         float s[4];
         ref_cartpole_reset_f32(seed, lane0 + (uint64_t)i, tick, s);
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
+/* GYMNET_FLAG_F64 reset draw (cartpole64.hpp CartPole64::reset): CartPoleEnv.cs:63-67 in float64, low + (high - low) * u
+ * with u a 53-bit uniform ((a >> 5) * 2^26 + (b >> 6)) / 2^53 — NumPy's random_sample() construction — where a is word k of
+ * the float32 engine's Philox call (key = seed) and b is word k of a second call with key ^ 0xC2B2AE3D27D4EB4F. */
+#define REF_RESET64_STREAM 0xC2B2AE3D27D4EB4Full
+void ref_cartpole_reset_f64(uint64_t seed, uint64_t lane, uint64_t tick, double state[4]) {
+    uint32_t a[4], b[4];
+    ref_reset_words(seed, lane, tick, a);
+    ref_reset_words(seed ^ REF_RESET64_STREAM, lane, tick, b);
+    for (int k = 0; k < 4; ++k) {
+        double u = ((double)(a[k] >> 5) * 67108864.0 + (double)(b[k] >> 6)) * (1.0 / 9007199254740992.0);
+        state[k] = -0.05 + (0.05 - -0.05) * u;
+    }
+}
+
+void ref_cartpole_reset_batch_f64(uint64_t seed, const uint64_t *lane_seed, uint64_t lane0, uint64_t tick, double *soa, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        double s[4];
+        ref_cartpole_reset_f64(lane_seed ? lane_seed[i] : seed, lane0 + (uint64_t)i, tick, s);
+        soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
+    }
+}
+
+/* One vector step of a GYMNET_FLAG_F64 handle with the fused auto-reset (the float64 twin of ref_env_autoreset_step_batch_f32). */
+void ref_cartpole_autoreset_step_batch_f64(uint64_t seed, const uint64_t *lane_seed, uint64_t lane0, uint64_t tick,
+                                           double *soa, const int32_t *action, float *reward, uint8_t *done, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        double s[4] = { soa[i], soa[n + i], soa[2 * n + i], soa[3 * n + i] };
+        int b = -1;
+        const int d = ref_cartpole_step_f64_kernel(s, action[i], &b, &reward[i]);
+        if (d) ref_cartpole_reset_f64(lane_seed ? lane_seed[i] : seed, lane0 + (uint64_t)i, tick, s);
+        done[i] = (uint8_t)d;
         soa[i] = s[0]; soa[n + i] = s[1]; soa[2 * n + i] = s[2]; soa[3 * n + i] = s[3];
     }
 }

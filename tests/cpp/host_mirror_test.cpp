@@ -217,6 +217,47 @@ static void gpu_tests() {
         }
         CHECK(throws<std::invalid_argument>([] { gymnet::GroupVectorEnv bad(GYMNET_ENV_CARTPOLE, 1001, {0, 0}); }), "N not a multiple of G -> ArgumentException");
     }
+    {   // ABI 4: the reference-exact float64 single instance; the float32 one beside it stays within 1e-5 per teacher-forced step
+        gymnet::CartPoleEnv64 e64(0, 11);
+        gymnet::CartPoleEnv e32(0, 11);
+        auto o = e64.Reset();
+        CHECK(o.size() == 4 && std::fabs(o[0]) < 0.05 && std::fabs(o[3]) < 0.05, "float64 Reset ~ U(-0.05, 0.05)^4");
+        e32.Reset();
+        bool close = true, done_same = true;
+        int steps = 0;
+        for (int i = 0; i < 200; ++i) {
+            const std::vector<double> s = e64.GetState();
+            e32.vector().SetState(std::vector<float>{(float)s[0], (float)s[1], (float)s[2], (float)s[3]});     // teacher-forced
+            e64.SetState({(double)(float)s[0], (double)(float)s[1], (double)(float)s[2], (double)(float)s[3]});
+            const gymnet::Step64 a = e64.Step(i % 2);
+            const gymnet::Step b = e32.Step(i % 2);
+            for (int k = 0; k < 4; ++k) close = close && std::fabs(a.Observation[k] - (double)b.Observation[k]) <= 1e-5;
+            done_same = done_same && a.Done == b.Done && a.Reward == b.Reward;
+            ++steps;
+            if (a.Done) { e64.Reset(); e32.Reset(); }
+        }
+        CHECK(close && done_same && steps == 200, "float32 engine within 1e-5 of the float64 one per teacher-forced step, same done / reward");
+        CHECK(throws<std::logic_error>([] { gymnet::CartPoleEnv64 bad(0, 1, GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_AUTORESET); }), "F64 + DONE_LIST -> NotSupportedException");
+    }
+    {   // ABI 4: launch policy through the ABI, arrays by id
+        gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 4096, 0, 5, GYMNET_FLAG_AUTORESET | GYMNET_FLAG_EPISODE_STATS);
+        gymnet_launch_policy p = gymnet::VectorEnv::KeepPolicy();
+        p.vec = 4; p.nt = 12; p.reset_form = 1;
+        env.SetLaunchPolicy(p);
+        CHECK(env.KernelName() == "step_kernel<CartPole,4,true,true,12,1>", "set_launch_policy selects the kernel form");
+        p = gymnet::VectorEnv::KeepPolicy(); p.vec = 2;
+        CHECK(throws<std::invalid_argument>([&] { env.SetLaunchPolicy(p); }), "vec = 2 is Acrobot's form -> ArgumentException");
+        CHECK(env.GetLaunchPolicy().vec == 4, "a refused policy changes nothing");
+        env.Reset();
+        for (int t = 0; t < 30; ++t) env.Step(t % 2);
+        auto len = env.GetArray<int32_t>(GYMNET_ARRAY_EPISODE_LENGTH, 4096);
+        auto ret = env.GetArray<float>(GYMNET_ARRAY_EPISODE_RETURN, 4096);
+        bool ok = true;
+        for (size_t i = 0; i < len.size(); ++i) ok = ok && len[i] >= 0 && len[i] <= 30 && ret[i] == (float)len[i];
+        CHECK(ok, "running episode return == length for CartPole (reward 1 per step)");
+        CHECK(throws<std::logic_error>([&] { env.GetArray<float>(GYMNET_ARRAY_FINAL_OBS, 4 * 4096); }), "array the configuration lacks -> NotSupportedException");
+        CHECK(throws<std::invalid_argument>([&] { env.GetArray<float>(GYMNET_ARRAY_REWARD, 17); }), "wrong size -> ArgumentException");
+    }
     {   // error behaviour
         gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_VALIDATE_ACTIONS);
         env.Reset();

@@ -47,3 +47,34 @@ def test_group_leg_child_reports_instead_of_raising_without_a_gpu():
     r = b.run_group_child(A, 2, timeout=240)
     assert isinstance(r, dict) and ("error" in r or any("error" in v for v in r.values() if isinstance(v, dict)))
     json.dumps(r)
+
+
+def test_a_fired_watchdog_prints_the_line_first_and_exits_non_zero():
+    """a secondary section that hangs (a collective waiting for a dead peer) ends the process through the
+    watchdog — the JSON line with the already-measured headline is printed FIRST, `watchdog_fired` names the section, and the
+    exit status is 3, not 0.  spawn_ranks() turns any rank's non-zero status into the launcher's."""
+    code = (
+        "import importlib.util, threading, time, sys\n"
+        f"spec = importlib.util.spec_from_file_location('bench_mod', r'{os.path.join(ROOT, 'bench.py')}')\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "out = {'metric': 'env-steps/sec', 'value': 1.0}\n"
+        "b.make_watchdog(0, out, threading.Lock(), 'with_obs_allgather', 0.2)\n"
+        "time.sleep(30)\n"                      # the 'hung collective'
+        "print('NOT REACHED')\n")
+    env = {k: v for k, v in os.environ.items() if k != "GYMNET_BENCH_WATCHDOG_RC"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-300:])
+    line = json.loads(r.stdout.strip().splitlines()[0])
+    assert line["value"] == 1.0 and line["watchdog_fired"] == "with_obs_allgather" and "timed out" in line["with_obs_allgather"]["error"]
+    assert "NOT REACHED" not in r.stdout and "timed out after 0.2 s" in r.stderr
+    b = _bench()
+    assert b.WATCHDOG_EXIT == 3 or "GYMNET_BENCH_WATCHDOG_RC" in os.environ
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src                         # never replaces a GPU process
+
+
+def test_xgmi_allgather_model_matches_the_survey_figures():
+    b = _bench()
+    m = b.allgather_model(8, 4 * (1 << 20) * 4)                                # 16 MiB per rank: CartPole, 2^20 lanes per GPU
+    assert 105 < m["direct_us"] < 115 and 740 < m["ring_us"] < 800            # SURVEY §8(e): ~110 us direct, ~770 us ring
+    assert b.parse_policy("vec=4, nt=12,block=128") == {"vec": 4, "nt": 12, "block": 128} and b.parse_policy("") == {}

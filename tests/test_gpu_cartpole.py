@@ -188,13 +188,13 @@ def test_mirror_symmetry_bitwise_at_full_batch(gpu_pkg):
 @pytest.mark.parametrize("force_graph", ["1", "0"])
 def test_graph_rollout_equals_eager_steps_bitwise(gpu_pkg, monkeypatch, force_graph):
     # hipGraph replay (frozen kernel arguments, device-side tick) must give the eager result, bit for bit.
-    # The library picks graph vs eager launches by batch size; GYMNET_GRAPH forces each path at full size.
+    # The library picks graph vs eager launches by batch size; gymnet_launch_policy.graph forces each path at full size.
     import torch
-    monkeypatch.setenv("GYMNET_GRAPH", force_graph)
     n, ring, steps = 1 << 20, 8, 8 * 5 + 3
     dev = torch.device("cuda", 0)
-    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as g, \
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, launch_policy={"graph": int(force_graph)}) as g, \
             gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as e:
+        assert g.GetLaunchPolicy()["graph"] == int(force_graph) and e.GetLaunchPolicy()["graph"] == -1
         acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         for t in range(ring):
@@ -252,9 +252,9 @@ def test_done_list_episode_stats_final_obs(gpu_pkg, oracle, with_list, vec, monk
     ret = np.zeros(n, np.float32); ln = np.zeros(n, np.int32)
     fin_ret = np.zeros(n, np.float32); fin_len = np.zeros(n, np.int32)
     fin_obs = np.zeros((n, 4), np.float32)
-    monkeypatch.setenv("GYMNET_VEC", str(vec))          # 4: the dwordx4 bookkeeping kernel a 2^20-lane batch runs (wave-compacted reset)
+    # vec 4: the dwordx4 bookkeeping kernel a 2^20-lane batch runs (wave-compacted reset)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, done_list=with_list, episode_stats=True,
-                           final_obs=True) as env:
+                           final_obs=True, launch_policy={"vec": vec, "reset_form": 1 if vec == 4 else 0}) as env:
         assert env.KernelName() == f"step_kernel<CartPole,{vec},true,true,15,{1 if vec == 4 else 0}>"
         env.Reset()
         for t in range(steps):
@@ -431,13 +431,11 @@ def test_launch_policy_variants_agree_bitwise(gpu_pkg, monkeypatch):
     results = []
     # (lanes per thread, non-temporal mask, reset form: 0 = per-thread drain loop, 1 = wave-compacted through LDS)
     for vec, nt, rf in ((1, 0, 0), (1, 12, 0), (1, 15, 0), (4, 0, 0), (4, 12, 0), (4, 15, 0), (4, 0, 1), (4, 12, 1), (4, 15, 1)):
-        monkeypatch.setenv("GYMNET_VEC", str(vec))
-        monkeypatch.setenv("GYMNET_NT", str(nt))
-        monkeypatch.setenv("GYMNET_RESET_FORM", str(rf))
+        pol = {"vec": vec, "nt": nt, "reset_form": rf}
         for auto in (True, False):
-            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto) as env:
+            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, launch_policy=pol) as env:
                 assert env.KernelName() == f"step_kernel<CartPole,{vec},{str(auto).lower()},false,{nt},{rf if auto else 0}>"
-                with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, done_list=True, episode_stats=True) as ex:
+                with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, done_list=True, episode_stats=True, launch_policy=pol) as ex:
                     assert ex.KernelName() == f"step_kernel<CartPole,{vec},{str(auto).lower()},true,{nt},{rf if auto else 0}>"
                 env.Reset()
                 dones = 0
@@ -609,6 +607,142 @@ def test_checkpoint_resume_is_bit_exact(gpu_pkg, name, auto):
     assert name != "CartPole-v1" or any(x.Done.any() for x in tail_a)       # random-action Acrobot does not finish in 90 steps
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("CartPole-v1", dict(auto_reset=True, episode_stats=True, max_episode_steps=13, done_list=True, final_obs=True)),
+    ("CartPole-v1", dict(auto_reset=False, episode_stats=True, max_episode_steps=13)),
+    ("Acrobot-v1", dict(auto_reset=True, episode_stats=True, max_episode_steps=7, final_obs=True)),
+    ("Pendulum-v1", dict(auto_reset=True, episode_stats=True, max_episode_steps=9, done_list=True)),
+    ("CartPole-v1", dict(auto_reset=True, episode_stats=True, max_episode_steps=11, dtype=np.float64)),
+])
+def test_checkpoint_of_every_configuration_is_bit_exact(gpu_pkg, name, kw):
+    """VERDICT r3 #5 / SURVEY §5: Checkpoint() used to refuse episode_stats / max_episode_steps / Seed(int[]) handles.  It now
+    carries every array such a handle keeps (gymnet_vecenv_get_array): running episode return / length — which decide WHEN the
+    time limit truncates — the done flags ResetWhere(None) consumes, the dense finished-episode views, terminal observations,
+    the per-lane Philox keys.  Restore() into a fresh handle, mid-episode, then the same actions: truncation steps, reset
+    draws, rewards, episode records and the dense views all continue bit for bit."""
+    n = 3000 + 5
+    rng = np.random.default_rng(31)
+    box = name == "Pendulum-v1"
+    nact = 2 if name == "CartPole-v1" else 3
+    acts = rng.uniform(-2, 2, (60, n)).astype(np.float32) if box else rng.integers(0, nact, (60, n)).astype(np.int32)
+    seeds = (np.arange(n, dtype=np.int64) * 2654435761) % (1 << 40) + 5
+    auto = kw["auto_reset"]
+
+    def drive(env, t0, t1):
+        out = []
+        for t in range(t0, t1):
+            o = env.Step(acts[t])
+            rec = env.DoneRecords() if kw.get("done_list") else None
+            out.append((o.Observation.copy(), o.Reward.copy(), o.Done.copy(), o.Truncated.copy(), rec))
+            if not auto:
+                env.ResetWhere()                                   # the caller's `if (done) Reset()`: consumes the done flags
+        return out
+
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, **kw) as a:
+        a.Seed(seeds)                                              # per-lane Philox keys (VecEnv.Seed(int[]), VecEnv.cs:48-53)
+        a.Reset()
+        drive(a, 0, 25)
+        if not auto:
+            a.Step(acts[25])                                       # checkpoint BETWEEN a step and its ResetWhere(): done flags pending
+        ck = a.Checkpoint()
+        assert {"episode_return", "episode_length", "finished_return", "finished_length", "done", "reward", "lane_seeds"} <= set(ck["arrays"])
+        assert ("final_obs" in ck["arrays"]) == bool(kw.get("final_obs")) and ("steps_beyond_done" in ck["arrays"]) == (name == "CartPole-v1" and not auto)
+        assert 0 < ck["arrays"]["episode_length"].max() < kw["max_episode_steps"] + 1 and ck["arrays"]["episode_length"].min() >= 0   # mid-episode
+        if not auto:
+            a.ResetWhere()
+        tail_a = drive(a, 26 if not auto else 25, 60)
+        end_a = (a.GetState(), a.EpisodeStats(), a.FinalObs() if kw.get("final_obs") else None, a.Tick)
+    with gpu_pkg.VectorEnv(name, n, seed=999, **kw) as b:          # a different seed: everything must come from the checkpoint
+        b.Reset()
+        b.Restore(ck)
+        assert b.GetSeed() == (SEED, True) and b.Tick == ck["tick"]          # Seed(int[]) keeps the scalar key; per-lane keys active
+        if not auto:
+            assert np.array_equal(b.Read().Done, ck["arrays"]["done"].astype(bool))
+            b.ResetWhere()
+        tail_b = drive(b, 26 if not auto else 25, 60)
+        end_b = (b.GetState(), b.EpisodeStats(), b.FinalObs() if kw.get("final_obs") else None, b.Tick)
+        with pytest.raises(ValueError):
+            b.Restore(dict(ck, dtype="float64" if ck["dtype"] == "float32" else "float32"))
+    assert np.array_equal(end_a[0], end_b[0], equal_nan=True) and end_a[3] == end_b[3]
+    assert np.array_equal(end_a[1][0], end_b[1][0]) and np.array_equal(end_a[1][1], end_b[1][1])
+    if end_a[2] is not None:
+        assert np.array_equal(end_a[2], end_b[2])
+    trunc = 0
+    for x, y in zip(tail_a, tail_b):
+        assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(x[:4], y[:4]))
+        trunc += int(x[3].sum())
+        if x[4] is not None:
+            ia, ib = np.argsort(x[4]["lanes"]), np.argsort(y[4]["lanes"])
+            for key in x[4]:
+                assert np.array_equal(x[4][key][ia], y[4][key][ib]), key
+    assert trunc > 0                                               # the time limit fired after the restore, on the same steps
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=auto, dtype=kw.get("dtype", np.float32)) as plain:   # a handle without the arrays the checkpoint carries
+        plain.Reset()
+        with pytest.raises(NotImplementedError):
+            plain.Restore(ck)
+
+
+def test_dense_episode_views_stay_current_without_caller_cooperation(gpu_pkg):
+    """with DONE_LIST the step kernel wrote compact records only, and the dense "last finished episode per
+    lane" arrays were refreshed by their getters for the most recent step alone — rollout_device(K > 1), graph replays and any
+    loop that skipped the getter lost episodes.  The kernel keeps the dense views itself again (compact-only is an explicit
+    opt-in): a K-step rollout with done_list + episode_stats + final_obs must leave exactly what a handle without the list
+    leaves, read once at the end; and with GYMNET_FLAG_COMPACT_RECORDS_ONLY the documented on-demand behaviour holds."""
+    import torch
+    n, ring, K = 20_000, 8, 64
+    acts = torch.randint(0, 2, (ring, n), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    views = {}
+    for label, kw in (("list", dict(done_list=True)), ("nolist", {}), ("compact", dict(done_list=True, compact_records_only=True))):
+        for graph in (1, 0):
+            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True, final_obs=True,
+                                   launch_policy={"graph": graph}, **kw) as env:
+                env.ResetDevice()
+                env.RolloutDevice(acts, K, n, ring)                 # K steps, no getter in between
+                env.Sync()
+                dv = env.DeviceView()
+                assert dv.d_finished_return and dv.d_finished_length
+                ret, ln = env.EpisodeStats()
+                views[(label, graph)] = (ret, ln, env.FinalObs(), env.GetArray("finished_length"))
+    ref = views[("nolist", 0)]
+    assert (ref[1] > 0).mean() > 0.9                                # nearly every lane finished at least one episode in 64 steps
+    for key in (("list", 1), ("list", 0), ("nolist", 1)):
+        assert all(np.array_equal(u, v) for u, v in zip(ref, views[key])), key
+    comp = views[("compact", 0)]
+    last_only = comp[1] != ref[1]
+    assert last_only.any() and np.array_equal(comp[1][~last_only], ref[1][~last_only])     # opt-in: only the last step's records were applied
+
+
+def test_launch_policy_through_the_abi(gpu_pkg, monkeypatch):
+    """the launch policy is set through gymnet_vecenv_set_launch_policy, and the shipped library no longer reads
+    GYMNET_* from the process environment (a host's environment must not change which kernel a library runs)."""
+    for var, val in (("GYMNET_VEC", "1"), ("GYMNET_NT", "0"), ("GYMNET_RESET_FORM", "0"), ("GYMNET_BLOCK", "64"), ("GYMNET_GRAPH", "0")):
+        monkeypatch.setenv(var, val)
+    n = 1 << 20
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as env:
+        assert env.KernelName() == "step_kernel<CartPole,4,true,false,15,1>"            # the environment changed nothing
+        assert env.GetLaunchPolicy() == {"vec": 4, "block": 256, "nt": 15, "sequential_lanes": 1, "reset_form": 1, "lds_pipe": 0,
+                                         "occupancy_lds_bytes": 0, "graph": -1}
+        env.SetLaunchPolicy(vec=1, nt=12)
+        assert env.KernelName() == "step_kernel<CartPole,1,true,false,12,0>" and env.LaunchPolicy()["envs_per_thread"] == 1
+        env.SetLaunchPolicy(vec=4, reset_form=1, block=128, graph=1)
+        assert env.KernelName() == "step_kernel<CartPole,4,true,false,12,1>" and env.GetLaunchPolicy()["block"] == 128
+        for bad in (dict(vec=2), dict(vec=3), dict(block=96), dict(nt=7), dict(sequential_lanes=4), dict(lds_pipe=1), dict(graph=5)):
+            with pytest.raises(ValueError):
+                env.SetLaunchPolicy(**bad)
+        assert env.KernelName() == "step_kernel<CartPole,4,true,false,12,1>"             # a refused policy changes nothing
+        with pytest.raises(TypeError):
+            env.SetLaunchPolicy(lanes=4)
+        env.SetLaunchPolicy(graph=-2)
+        assert env.GetLaunchPolicy()["graph"] == -1
+    with gpu_pkg.VectorEnv("Acrobot-v1", 1 << 20, seed=SEED, auto_reset=True) as env:
+        assert env.KernelName() == "step_kernel_pipe<Acrobot,4,true,15>"
+        env.SetLaunchPolicy(sequential_lanes=1, vec=2)
+        assert env.KernelName() == "step_kernel<Acrobot,2,true,false,15,0>"
+        with pytest.raises(ValueError):
+            env.SetLaunchPolicy(vec=4)
+
+
 def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg):
     """VecEnv.Seed(int) reaches a VecEnv-typed C# caller's lanes as N equal seeds (VecEnv.cs:44-46 walks Environments); round 2
     turned that into the per-lane-key kernel variant (slower, no fused rollout) although it computes the same bits.  An
@@ -649,9 +783,7 @@ def test_wave_compacted_reset_when_every_lane_finishes_and_the_last_wave_is_part
     s[0] = 2.39; s[1] = 3.0                                        # x' = 2.39 + 0.02 * 3 > x_threshold for every lane
     got = {}
     for rf in (1, 0):
-        monkeypatch.setenv("GYMNET_VEC", "4")
-        monkeypatch.setenv("GYMNET_RESET_FORM", str(rf))
-        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=12345) as env:
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=12345, launch_policy={"vec": 4, "reset_form": rf}) as env:
             assert env.KernelName() == f"step_kernel<CartPole,4,true,false,15,{rf}>"
             env.Reset(); env.SetState(s)
             tick = env.Tick

@@ -248,9 +248,9 @@ def test_scalar_broadcast_on_a_box_action_space(gpu_pkg):
 
 
 def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
-    """Acrobot's step has three kernel forms: one lane per thread (one-shot), GYMNET_VEC=2 — both envs of a thread ride the
+    """Acrobot's step has three kernel forms: one lane per thread (one-shot), launch policy vec = 2 — both envs of a thread ride the
     v_pk_*_f32 instructions (envs.hpp step_observe_x2, dwordx2 streams; opt-in: half the VALU count and still slower,
-    DESIGN.md §4a) — and GYMNET_ITEMS=k — k lanes per thread, all loads first, then compute / store lane after lane
+    DESIGN.md §4a) — and sequential_lanes = k — k lanes per thread, all loads first, then compute / store lane after lane
     (step_kernel_pipe; the default around 2^20 lanes).  Per lane all three run the same IEEE sequence, so everything must
     agree bit for bit: one-launch steps with an odd lane count (clamped loads / suppressed stores in the tail), the
     bookkeeping variant (which falls back to the one-shot kernel), the fused rollout, with and without auto-reset."""
@@ -258,12 +258,10 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
     n, ring = 8192 + 7, 6
     out = {}
     for vec, items in ((1, 1), (2, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
-        monkeypatch.setenv("GYMNET_VEC", str(vec))
-        monkeypatch.setenv("GYMNET_ITEMS", str(items))
-        monkeypatch.setenv("GYMNET_LDS_PIPE", "0")
         res = []
         for auto, stats in ((True, False), (False, False), (True, True)):
-            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats) as env:
+            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats,
+                                   launch_policy={"vec": vec, "sequential_lanes": items, "lds_pipe": 0}) as env:
                 pol = env.LaunchPolicy()
                 assert pol["envs_per_thread"] == vec and pol["sequential_lanes_per_thread"] == (1 if stats else items)
                 acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
@@ -282,9 +280,7 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
                 res.append((env.GetState(), r.Observation, r.Reward, r.Done, env.EpisodeStats() if stats else None))
         out[(vec, items)] = res
     # the multi-lane kernel writing into the OTHER observation buffer (GYMNET_FLAG_DOUBLE_BUFFER)
-    monkeypatch.setenv("GYMNET_VEC", "1")
-    monkeypatch.setenv("GYMNET_ITEMS", "4")
-    with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=True, double_buffer=True) as env:
+    with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=True, double_buffer=True, launch_policy={"vec": 1, "sequential_lanes": 4}) as env:
         acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for t in range(ring):
@@ -310,7 +306,7 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
 
 @pytest.mark.parametrize("tiles", [2, 3, 4, 5])
 def test_acrobot_producer_consumer_kernel_is_bit_identical(gpu_pkg, monkeypatch, tiles):
-    """step_kernel_lds (GYMNET_LDS_PIPE=1): computing waves prefetch the next tile and hand results to a storing wave through
+    """step_kernel_lds (launch policy lds_pipe = 1): computing waves prefetch the next tile and hand results to a storing wave through
     LDS.  Same per-lane code and Philox counters as the one-shot kernel, so states, observations, rewards and done flags must
     agree bit for bit — workgroups with fewer tiles than TPB (ragged grid), with and without auto-reset, energetic states so the
     fused reset runs."""
@@ -320,12 +316,10 @@ def test_acrobot_producer_consumer_kernel_is_bit_identical(gpu_pkg, monkeypatch,
     s0 = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
     res = {}
     for form in ("one-shot", "lds"):
-        monkeypatch.setenv("GYMNET_VEC", "1")
-        monkeypatch.setenv("GYMNET_ITEMS", "1" if form == "one-shot" else str(tiles))
-        monkeypatch.setenv("GYMNET_LDS_PIPE", "0" if form == "one-shot" else "1")
+        pol = {"vec": 1, "sequential_lanes": 1 if form == "one-shot" else tiles, "lds_pipe": 0 if form == "one-shot" else 1}
         out = []
         for auto in (True, False):
-            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto) as env:
+            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, launch_policy=pol) as env:
                 want = f"step_kernel_lds<Acrobot,{tiles},{str(auto).lower()},15>" if form == "lds" else f"step_kernel<Acrobot,1,{str(auto).lower()},false,15,0>"
                 assert env.KernelName() == want, env.KernelName()
                 acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
@@ -343,6 +337,7 @@ def test_acrobot_producer_consumer_kernel_is_bit_identical(gpu_pkg, monkeypatch,
     for x, y in zip(res["one-shot"], res["lds"]):
         for u, v in zip(x, y):
             assert np.array_equal(u, v, equal_nan=True)
-    monkeypatch.setenv("GYMNET_ITEMS", "4")
-    with gpu_pkg.VectorEnv("Acrobot-v1", 512 * 8 + 3, seed=SEED, auto_reset=True) as env:      # not whole tiles: falls back
-        assert env.KernelName() == "step_kernel_pipe<Acrobot,4,true,15>"
+    with gpu_pkg.VectorEnv("Acrobot-v1", 512 * 8 + 3, seed=SEED, auto_reset=True, launch_policy={"sequential_lanes": 4}) as env:
+        with pytest.raises(ValueError):                                                        # not whole 512-lane tiles: refused ...
+            env.SetLaunchPolicy(lds_pipe=1)
+        assert env.KernelName() == "step_kernel_pipe<Acrobot,4,true,15>"                         # ... and nothing changed

@@ -21,7 +21,7 @@ def test_header_symbols_are_all_exported(gymnet):
     assert not missing, missing
     # and the ctypes binding covers exactly the declared set
     assert declared == set(gymnet._capi.PROTOTYPES)
-    assert lib.gymnet_abi_version() == 3 == gymnet._capi.ABI_VERSION
+    assert lib.gymnet_abi_version() == 4 == gymnet._capi.ABI_VERSION
 
 
 def abi_manifest():
@@ -37,7 +37,7 @@ def abi_manifest():
 
 CTYPES_OF = {"gymnet_config": "Config", "gymnet_env_info": "EnvInfo", "gymnet_device_view": "DeviceView",
              "gymnet_counters": "Counters", "gymnet_rollout_buffers": "RolloutBuffers", "gymnet_group_config": "GroupConfig",
-             "gymnet_ipc_handle": "IpcHandle"}
+             "gymnet_ipc_handle": "IpcHandle", "gymnet_launch_policy": "LaunchPolicy"}
 
 
 def test_struct_layouts_match_the_header(gymnet):
@@ -92,6 +92,23 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "liboracle" not in text and "classic_control_ref" not in text, f
+
+
+def test_library_does_not_read_the_process_environment_for_its_launch_policy():
+    """`getenv` may appear in the native sources only inside `#ifdef GYMNET_PROBE_ENV` blocks (probe builds,
+    GYMNET_BUILD_PROBE_ENV=1), and the default build does not define that macro."""
+    csrc = os.path.join(ROOT, "gym.net_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        shipped = re.sub(r"#ifdef GYMNET_PROBE_ENV.*?#endif", "", text, flags=re.S)
+        assert "getenv" not in shipped, f
+    build = open(os.path.join(ROOT, "gym.net_amd", "build.py")).read()
+    flags = re.search(r"^FLAGS = \[(.*?)\]", build, flags=re.M).group(1)
+    assert "GYMNET_PROBE_ENV" not in flags and 'os.environ.get("GYMNET_BUILD_PROBE_ENV") == "1"' in build
+    # the built library really has no such string in it (the variable names would sit in .rodata)
+    import __graft_entry__ as ge
+    blob = open(ge.load_package().LIB_PATH, "rb").read()
+    assert b"GYMNET_RESET_FORM" not in blob and b"GYMNET_GRAPH" not in blob
 
 
 # ---- Box / Discrete: tests/Gym.Tests/Spaces/BoxTest.cs:14-42 and Discrete.cs:38-40 -----------------
@@ -196,7 +213,8 @@ def test_missing_extension_raises_instead_of_falling_back(tmp_path):
 CS_SIZES = {"uint": 4, "int": 4, "long": 8, "ulong": 8, "float": 4, "IntPtr": 8, "byte": 1}
 CS_STRUCT_OF = {"gymnet_config": "GymnetConfig", "gymnet_env_info": "GymnetEnvInfo", "gymnet_device_view": "GymnetDeviceView",
                 "gymnet_counters": "GymnetCounters", "gymnet_rollout_buffers": "GymnetRolloutBuffers",
-                "gymnet_group_config": "GymnetGroupConfig", "gymnet_ipc_handle": "GymnetIpcHandle"}
+                "gymnet_group_config": "GymnetGroupConfig", "gymnet_ipc_handle": "GymnetIpcHandle",
+                "gymnet_launch_policy": "GymnetLaunchPolicy"}
 
 
 def _csharp_sources():
@@ -254,7 +272,9 @@ def test_csharp_binding_sources_lex_cleanly_and_cover_the_header():
         assert fields == [tuple(f) for f in man[cname]["fields"]], csname
     assert set(CS_STRUCT_OF) == set(CTYPES_OF)
     # status / flag enums carry the header's values
-    for cs, c in (("Rccl = -9", "GYMNET_ERR_RCCL = -9"), ("DoubleBuffer = 0x20", "GYMNET_FLAG_DOUBLE_BUFFER    0x20u")):
+    for cs, c in (("Rccl = -9", "GYMNET_ERR_RCCL = -9"), ("DoubleBuffer = 0x20", "GYMNET_FLAG_DOUBLE_BUFFER    0x20u"),
+                  ("F64 = 0x40", "GYMNET_FLAG_F64              0x40u"), ("CompactRecordsOnly = 0x80", "GYMNET_FLAG_COMPACT_RECORDS_ONLY 0x80u"),
+                  ("LaneSeeds = 8", "GYMNET_ARRAY_LANE_SEEDS = 8")):
         assert cs in srcs["Native.cs"] and c in open(os.path.join(ROOT, "include", "gymnet_amd.h")).read()
 
 

@@ -593,3 +593,85 @@ def test_reset_distribution_parameters_evaluated_from_the_reference_text(oracle)
     assert abs(float(s.mean()) - (low.v + high.v) / 2) < 2e-4 and abs(float(s.std()) - (high.v - low.v) / np.sqrt(12)) < 2e-4
     st, r, d, b = oracle.cartpole_step(s.astype(np.float64), np.ones(s.shape[1], np.int32))
     assert (b[d == 0] == sbd0.v).all()                                  # a fresh episode starts from the text's steps_beyond_done
+
+
+# ------------------------------------------------------------------------------------------------
+# GYMNET_FLAG_F64: the float64 "kernel semantics" twin (the HIP kernel's own sin / cos, 53-bit reset draws)
+# ------------------------------------------------------------------------------------------------
+def test_f64_kernel_sincos_accuracy_against_200_bit_arithmetic(oracle):
+    """ref_sincos_f64_kernel (= gym.net_amd/csrc/cartpole64.hpp sincos_f64, operation for operation): < 0.75 ulp for
+    |x| <= pi/4 — every CartPole pole angle of a live episode — and <= 2.1 ulp over the reduced range |x| <= 8e5; exact
+    identities at 0; libm beyond the range."""
+    import mpmath
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(0)
+
+    def worst_ulp(xs):
+        s, c = oracle.sincos_f64_kernel(xs)
+        ws = wc = 0.0
+        for x, gs, gc in zip(xs, s, c):
+            ts, tc = mpmath.sin(mpmath.mpf(float(x))), mpmath.cos(mpmath.mpf(float(x)))
+            ws = max(ws, float(abs(mpmath.mpf(float(gs)) - ts) / mpmath.mpf(float(np.spacing(abs(float(ts)))))))
+            wc = max(wc, float(abs(mpmath.mpf(float(gc)) - tc) / mpmath.mpf(float(np.spacing(abs(float(tc)))))))
+        return ws, wc
+    small = np.concatenate([rng.uniform(-0.785, 0.785, 4000), rng.uniform(-0.21, 0.21, 2000), rng.uniform(-1e-4, 1e-4, 500)])
+    assert max(worst_ulp(small)) < 0.75
+    wide = np.concatenate([rng.uniform(-10, 10, 3000), rng.uniform(-8e5, 8e5, 3000), np.arange(-40, 41) * (np.pi / 2)])
+    assert max(worst_ulp(wide)) <= 2.1
+    s, c = oracle.sincos_f64_kernel([0.0, 1e-300, -1e-300])
+    assert s[0] == 0.0 and c[0] == 1.0 and s[1] == 1e-300 and s[2] == -1e-300 and c[1] == 1.0
+    big = np.array([1e6, -3e9, 1e300])
+    s, c = oracle.sincos_f64_kernel(big)
+    assert np.array_equal(s, np.sin(big)) and np.array_equal(c, np.cos(big))                 # beyond the reduced range: libm
+    s, c = oracle.sincos_f64_kernel([np.inf, np.nan])
+    assert np.isnan(s).all() and np.isnan(c).all()
+
+
+def test_f64_kernel_semantics_twin_against_the_reference_arithmetic(oracle, golden):
+    """The float64 twin (kernel's own sin / cos) against the reference-arithmetic restatement (libm) and hence against the
+    vectors evaluated from the reference's text: integer outputs identical on all 3200, x' and theta' bit-identical (no
+    transcendental in them), velocities within 4 ulp-ish (1e-13 relative)."""
+    g = golden("cartpole_reference_text")
+    s, r, d, b = oracle.cartpole_step(g["state"], g["action"], g["sbd"], dtype=np.float64, kernel_sincos=True)
+    assert np.array_equal(d, g["done"]) and np.array_equal(r, g["reward"]) and np.array_equal(b, g["sbd_out"])
+    assert np.array_equal(s[[0, 2]], g["next_state"][[0, 2]])
+    rel = np.abs(s - g["next_state"]) / np.maximum(1.0, np.abs(g["next_state"]))
+    assert rel.max() <= 1e-13, rel.max()
+    # free-running on the recorded reference-test-shaped trace: every done flag and episode length, states within 1e-12
+    t = golden("cartpole_reference_test_trace")
+    done, k, lens, cur, worst = True, 0, [], 0, 0.0
+    st = np.zeros((4, 1)); sbd = np.array([-1], np.int32)
+    for i in range(1000):
+        if done:
+            st = t["resets"][k].reshape(4, 1).copy(); k += 1
+            sbd[:] = -1; done = False
+            if cur:
+                lens.append(cur)
+            cur = 0
+        else:
+            st, _, dd, sbd = oracle.cartpole_step(st, np.array([i % 2], np.int32), sbd, dtype=np.float64, kernel_sincos=True)
+            done = bool(dd[0]); cur += 1
+            worst = max(worst, float(np.abs(st[:, 0] - t["it_state"][i]).max()))
+        assert int(done) == t["it_done"][i]
+    assert lens == list(t["episode_lengths"]) and worst <= 1e-12
+
+
+def test_f64_reset_draw_is_a_53_bit_uniform_on_the_reference_interval(oracle):
+    """CartPoleEnv.cs:63-67 in float64: low + (high - low) * u, u = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two Philox calls
+    (key, key ^ 0xC2B2AE3D27D4EB4F) at the lane's counter; the first call is the float32 engine's."""
+    n = 200_000
+    s = oracle.cartpole_reset_f64(0x5EED, 12345, 3, n)
+    assert s.shape == (4, n) and s.min() >= -0.05 and s.max() < 0.05
+    assert abs(s.mean()) < 2e-4 and abs(s.std() - 0.1 / np.sqrt(12)) < 2e-4
+    assert len(np.unique(s)) == 4 * n                                                        # 53 random bits: no collisions
+    # reconstructed from the pinned Philox words (NumPy restatement): bit-identical
+    lanes = np.arange(12345, 12345 + n, dtype=np.uint64)
+    a = nr.reset_words(0x5EED, lanes, 3).astype(np.uint64)
+    b = nr.reset_words(0x5EED ^ 0xC2B2AE3D27D4EB4F, lanes, 3).astype(np.uint64)
+    u = ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
+    assert np.array_equal(s, -0.05 + (0.05 - -0.05) * u)
+    # the float32 engine's draw uses the top 24 bits of the same first word: the two agree to float32 resolution
+    s32 = oracle.cartpole_reset(0x5EED, 12345, 3, n)
+    assert np.abs(s - s32.astype(np.float64)).max() < 2e-8
+    per_lane = np.arange(n, dtype=np.uint64) + 9
+    assert np.array_equal(oracle.cartpole_reset_f64(0, 0, 3, n, lane_seed=per_lane)[:, 5], oracle.cartpole_reset_f64(int(per_lane[5]), 5, 3, 1)[:, 0])

@@ -34,7 +34,7 @@ int main(void) {
     F(gymnet_device_view, d_reward); F(gymnet_device_view, d_done); F(gymnet_device_view, d_steps_beyond_done);
     F(gymnet_device_view, d_final_obs); F(gymnet_device_view, d_done_list); F(gymnet_device_view, d_episode_return);
     F(gymnet_device_view, d_episode_length); F(gymnet_device_view, d_finished_return); F(gymnet_device_view, d_finished_length);
-    F(gymnet_device_view, stream); F(gymnet_device_view, obs_buffer); F(gymnet_device_view, reserved); F(gymnet_device_view, d_obs_alt);
+    F(gymnet_device_view, stream); F(gymnet_device_view, obs_buffer); F(gymnet_device_view, state_dtype); F(gymnet_device_view, d_obs_alt);
     END();
     BEGIN(gymnet_counters);
     F(gymnet_counters, struct_size); F(gymnet_counters, reserved); F(gymnet_counters, tick); F(gymnet_counters, lane_steps);
@@ -47,6 +47,11 @@ int main(void) {
     F(gymnet_group_config, struct_size); F(gymnet_group_config, env_id); F(gymnet_group_config, global_num_envs);
     F(gymnet_group_config, num_members); F(gymnet_group_config, flags); F(gymnet_group_config, seed);
     F(gymnet_group_config, devices); F(gymnet_group_config, gather); F(gymnet_group_config, max_episode_steps);
+    END();
+    BEGIN(gymnet_launch_policy);
+    F(gymnet_launch_policy, struct_size); F(gymnet_launch_policy, vec); F(gymnet_launch_policy, block); F(gymnet_launch_policy, nt);
+    F(gymnet_launch_policy, sequential_lanes); F(gymnet_launch_policy, reset_form); F(gymnet_launch_policy, lds_pipe);
+    F(gymnet_launch_policy, occupancy_lds_bytes); F(gymnet_launch_policy, graph);
     END();
     BEGIN(gymnet_ipc_handle);
     F(gymnet_ipc_handle, bytes);
