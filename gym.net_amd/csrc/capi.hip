@@ -48,8 +48,9 @@ int fail(gymnet_vecenv *h, int status, const char *fmt, ...) {
     g_last_error = buf;
     if (h) h->err = buf;
     // HIP keeps the last error of the calling thread until somebody reads it, and the launchers end with `return
-    // hipGetLastError()`: a failure reported here must not make the NEXT (valid) launch on this thread fail too
-    (void)hipGetLastError();
+    // hipGetLastError()`: a HIP failure reported here must not make the NEXT (valid) launch on this thread fail too.
+    // A pure argument-validation failure made no HIP call and does not touch the runtime.
+    if (status == GYMNET_ERR_HIP || status == GYMNET_ERR_OOM || status == GYMNET_ERR_RCCL) (void)hipGetLastError();
     return status;
 }
 

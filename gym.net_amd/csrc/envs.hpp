@@ -522,11 +522,13 @@ struct Acrobot {
         for (int k = 0; k < 4; ++k) s[k] = -0.1f + 0.2f * u01_24(r.w[k]);
     }
 
-    // any state (set_state hands over arbitrary angles): full-range sincos
+    // any state (set_state hands over arbitrary angles).  Angles a step or a reset can produce (|x| <= pi, far inside sincos_small's
+    // |x| < 24) take the step's OWN sin / cos, so SetState(GetState()) reproduces the observation the step wrote bit for bit
+    // (sincos_f32 and sincos_small differ in the last bit for some arguments); anything larger keeps the full-range form.
     __device__ __forceinline__ static void observe(const float (&s)[S], float (&o)[O]) {
         float s1, c1, s2, c2;
-        sincos_f32(s[0], s1, c1);
-        sincos_f32(s[1], s2, c2);
+        if (fabsf(s[0]) < 24.0f) sincos_small<float>(s[0], s1, c1); else sincos_f32(s[0], s1, c1);
+        if (fabsf(s[1]) < 24.0f) sincos_small<float>(s[1], s2, c2); else sincos_f32(s[1], s2, c2);
         o[0] = c1; o[1] = s1; o[2] = c2; o[3] = s2; o[4] = s[2]; o[5] = s[3];
     }
     // a freshly reset state: angles in [-0.1, 0.1) — the step's own small-argument sin/cos

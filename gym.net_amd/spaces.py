@@ -101,7 +101,9 @@ class Box(Space):                                               # Box.cs:15-96
         sample[low_bounded] = rs.exponential(1.0, int(low_bounded.sum())) + self.Low[low_bounded]     # Box.cs:83
         sample[upp_bounded] = rs.exponential(1.0, int(upp_bounded.sum())) + self.High[upp_bounded]    # Box.cs:84 (sic)
         sample[bounded] = rs.uniform(self.Low[bounded], self.High[bounded])                           # Box.cs:85
-        if self.DType.kind in "iu":
+        # Box.cs:86-89: np.floor for EXACTLY int32 / uint32 / byte; any other integer dtype goes straight to astype, which truncates
+        # toward zero (floor(-0.5) = -1 but (long) -0.5 = 0) — mirrored, quirk included
+        if self.DType in (np.dtype(np.int32), np.dtype(np.uint32), np.dtype(np.uint8)):
             sample = np.floor(sample)
         return sample.astype(self.DType)
 

@@ -78,6 +78,7 @@ def lib():
     L.ref_acrobot_step_f64.restype = C.c_int
     L.ref_acrobot_step_f32.argtypes = [_f32p, C.c_int, _f32p, C.POINTER(C.c_float)]
     L.ref_acrobot_step_f32.restype = C.c_int
+    L.ref_acrobot_step_batch_f32_literal.argtypes = [_f32p, _i32p, _f32p, _f32p, _u8p, C.c_int64]
     L.ref_acrobot_reset_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
     L.ref_env_step_batch_f32.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_void_p, _f32p, _f32p, _u8p, C.c_int64]
     L.ref_env_step_batch_f64.argtypes = [C.c_int, _f64p, C.c_void_p, C.c_void_p, _f64p, _f64p, _u8p, C.c_int64]
@@ -298,6 +299,17 @@ def mountaincar_step(state, action, dtype=np.float64):
 def acrobot_step(state, action, dtype=np.float64):
     """Returns (new_state[4,n], obs[6,n], reward[n], done u8[n])."""
     return env_step(3, state, action, dtype=dtype)
+
+
+def acrobot_step_f32_literal(state, action):
+    """One Acrobot step in a LITERAL float32 transcription of upstream's formulas (libm sinf / cosf, IEEE division, upstream's
+    association) — not what the kernel runs; the yardstick of tools/acrobot_accuracy.py.  Returns (state[4,n], obs[6,n], reward, done)."""
+    s = np.ascontiguousarray(np.array(state, dtype=np.float32, copy=True))
+    n = s.shape[1]
+    a = np.ascontiguousarray(np.asarray(action, dtype=np.int32))
+    obs = np.zeros((6, n), np.float32); rew = np.zeros(n, np.float32); done = np.zeros(n, np.uint8)
+    lib().ref_acrobot_step_batch_f32_literal(s, a, obs, rew, done, n)
+    return s, obs, rew, done
 
 
 def cpu_baseline(n_envs, steps, threads, alloc_faithful=True, seed=0x5EED):

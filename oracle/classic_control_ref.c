@@ -670,6 +670,61 @@ int ref_acrobot_step_f32(float *state, int a, float *obs6, float *reward) {
     return done;
 }
 
+/* A LITERAL binary32 transcription of upstream's dsdt / rk4 (the float64 code above with every double replaced by float, libm
+ * sinf / cosf, IEEE division, upstream's association order) — NOT what the kernel runs.  It exists for one purpose: the accuracy
+ * budget of tools/acrobot_accuracy.py, which compares the error of THIS against the float64 restatement with the
+ * error of the shipped instruction-diet form (acrobot_dsdt_f32 above), to show how much of the float32-vs-float64 difference is
+ * RK4 amplifying float32 rounding and how much the diet adds. */
+static void acrobot_dsdt_f32_literal(const float s[4], float tau, float d[4]) {
+    const float m1 = 1.0f, m2 = 1.0f, l1 = 1.0f, lc1 = 0.5f, lc2 = 0.5f, I1 = 1.0f, I2 = 1.0f, g = 9.8f;
+    float th1 = s[0], th2 = s[1], dth1 = s[2], dth2 = s[3];
+    float d1 = m1 * lc1 * lc1 + m2 * (l1 * l1 + lc2 * lc2 + 2.0f * l1 * lc2 * cosf(th2)) + I1 + I2;
+    float d2 = m2 * (lc2 * lc2 + l1 * lc2 * cosf(th2)) + I2;
+    float phi2 = m2 * lc2 * g * cosf(th1 + th2 - PI_F / 2.0f);
+    float phi1 = -m2 * l1 * lc2 * dth2 * dth2 * sinf(th2)
+                 - 2.0f * m2 * l1 * lc2 * dth2 * dth1 * sinf(th2)
+                 + (m1 * lc1 + m2 * l1) * g * cosf(th1 - PI_F / 2.0f) + phi2;
+    float ddth2 = (tau + d2 / d1 * phi1 - m2 * l1 * lc2 * dth1 * dth1 * sinf(th2) - phi2)
+                  / (m2 * lc2 * lc2 + I2 - d2 * d2 / d1);
+    float ddth1 = -(d2 * ddth2 + phi1) / d1;
+    d[0] = dth1; d[1] = dth2; d[2] = ddth1; d[3] = ddth2;
+}
+
+int ref_acrobot_step_f32_literal(float *state, int a, float *obs6, float *reward) {
+    const float dt = 0.2f, mv1 = 4.0f * PI_F, mv2 = 9.0f * PI_F;
+    float tau = (float)(a - 1);
+    float k1[4], k2[4], k3[4], k4[4], y[4];
+    acrobot_dsdt_f32_literal(state, tau, k1);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k1[i];
+    acrobot_dsdt_f32_literal(y, tau, k2);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 2.0f * k2[i];
+    acrobot_dsdt_f32_literal(y, tau, k3);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt * k3[i];
+    acrobot_dsdt_f32_literal(y, tau, k4);
+    for (int i = 0; i < 4; ++i) y[i] = state[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+    y[0] = wrap_f(y[0], -PI_F, PI_F);
+    y[1] = wrap_f(y[1], -PI_F, PI_F);
+    y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+    y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+    for (int i = 0; i < 4; ++i) state[i] = y[i];
+    int done = (-cosf(y[0]) - cosf(y[1] + y[0])) > 1.0f;
+    *reward = done ? 0.0f : -1.0f;
+    obs6[0] = cosf(y[0]); obs6[1] = sinf(y[0]); obs6[2] = cosf(y[1]); obs6[3] = sinf(y[1]);
+    obs6[4] = y[2]; obs6[5] = y[3];
+    return done;
+}
+
+void ref_acrobot_step_batch_f32_literal(float *state_soa, const int32_t *action, float *obs_soa, float *reward, uint8_t *done, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        float s[4], o[6], r;
+        for (int k = 0; k < 4; ++k) s[k] = state_soa[(int64_t)k * n + i];
+        done[i] = (uint8_t)ref_acrobot_step_f32_literal(s, action[i], o, &r);
+        reward[i] = r;
+        for (int k = 0; k < 4; ++k) state_soa[(int64_t)k * n + i] = s[k];
+        for (int k = 0; k < 6; ++k) obs_soa[(int64_t)k * n + i] = o[k];
+    }
+}
+
 void ref_acrobot_reset_f32(uint64_t seed, uint64_t lane, uint64_t tick, float state[4]) {
     uint32_t w[4];
     ref_reset_words(seed, lane, tick, w);

@@ -77,6 +77,7 @@ def _pin(gpu_pkg, oracle, name, kernel, steps, init=None, min_done_frac=0.0):
         s32, o32, r32, d32 = oracle.env_autoreset_step(name, SEED, 0, tick + steps, got, a_host[0])
         got1, out = env.GetState(), env.Read()
         assert np.array_equal(got1, s32) and np.array_equal(out.Done, d32.astype(bool)) and np.array_equal(out.Reward, r32)
+        _pin.last_actions = a_host[0]                 # the actions of the teacher-forced launch (3)
         return got, got1.astype(np.float64), out, s64, o64, r64, d64.astype(bool)
 
 
@@ -128,7 +129,14 @@ def test_step_kernel_pipe_Acrobot_items4_autoreset_nt15_at_2p20_lanes_matches_th
     keep = ~out.Done
     dang = np.abs(np.angle(np.exp(1j * (got1[:2] - s64[:2]))))[:, keep]            # angles wrap at +-pi: compare on the circle
     dvel = np.abs(got1[2:] - s64[2:])[:, keep]
-    assert dang.max() <= 1e-4 and dvel.max() <= 1e-3                                # float32 rounding through RK4, dt = 0.2
+    # float32 rounding through RK4 (dt = 0.2), measured not assumed: the kernel's instruction-diet form within 2 x the error of a
+    # LITERAL float32 transcription of upstream's formulas evaluated on the same 2^20 inputs (profiles/acrobot_accuracy_r04.txt)
+    lit = oracle.acrobot_step_f32_literal(got0, _pin.last_actions)[0].astype(np.float64)
+    lang = np.abs(np.angle(np.exp(1j * (lit[:2] - s64[:2]))))[:, keep]
+    lvel = np.abs(lit[2:] - s64[2:])[:, keep]
+    for q in (0.5, 0.99, 0.9999):          # typical lanes: no worse than the literal form (+25 % slack); the worst of 2^20: within 4 x
+        assert np.quantile(dang, q) <= 1.25 * np.quantile(lang, q) and np.quantile(dvel, q) <= 1.25 * np.quantile(lvel, q), q
+    assert dang.max() <= 4 * lang.max() and dvel.max() <= 4 * lvel.max(), (dang.max(), lang.max(), dvel.max(), lvel.max())
     calm = ((np.abs(got0[2]) < 2) & (np.abs(got0[3]) < 2))[keep]
     assert calm.sum() > 1000 and dang[:, calm].max() <= 1e-5 and dvel[:, calm].max() <= 2e-5
     margin = np.abs((-np.cos(s64[0]) - np.cos(s64[1] + s64[0])) - 1.0) < 1e-4

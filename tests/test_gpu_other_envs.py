@@ -54,9 +54,21 @@ def test_acrobot_teacher_forced(gpu_pkg, golden, oracle):
         out = env.Step(g["ac_action"])
         got = env.GetState().astype(np.float64)
     want = g["ac_next"]
-    # angles wrap at +-pi: compare on the circle; RK4 over dt=0.2 with |velocities| up to 28 amplifies rounding
+    # angles wrap at +-pi: compare on the circle.  RK4 over dt = 0.2 with |velocities| up to 28 amplifies float32 rounding; how
+    # much is MEASURED, not assumed: a literal float32 transcription of upstream's formulas (libm sinf / cosf, IEEE division,
+    # upstream's association: oracle ref_acrobot_step_f32_literal) is evaluated on the same inputs, and the kernel's instruction-diet
+    # form must stay within 2 x its error (profiles/acrobot_accuracy_r04.txt: the diet is not the cause)
     dang = np.abs(np.angle(np.exp(1j * (got[:2] - want[:2]))))
-    assert dang.max() <= 1e-4 and np.abs(got[2:] - want[2:]).max() <= 1e-3
+    dvel = np.abs(got[2:] - want[2:])
+    lit = oracle.acrobot_step_f32_literal(g["ac_state"], g["ac_action"])[0].astype(np.float64)
+    lang = np.abs(np.angle(np.exp(1j * (lit[:2] - want[:2]))))
+    lvel = np.abs(lit[2:] - want[2:])
+    # typical lanes (median, 99th percentile): the kernel is no worse than the literal transcription (+25 % sampling slack);
+    # the single worst of 1024 lanes is a tail statistic of an ill-conditioned map: within 4 x
+    for q in (0.5, 0.99):
+        assert np.quantile(dang, q) <= 1.25 * np.quantile(lang, q) and np.quantile(dvel, q) <= 1.25 * np.quantile(lvel, q), q
+    assert dang.max() <= 4 * lang.max() and dvel.max() <= 4 * lvel.max(), (dang.max(), lang.max(), dvel.max(), lvel.max())
+    assert lang.max() <= 2e-5 and lvel.max() <= 2e-4                                  # the yardstick itself: 5 x tighter than round 3's 1e-4 / 1e-3
     calm = (np.abs(g["ac_state"][2]) < 2) & (np.abs(g["ac_state"][3]) < 2)
     assert np.abs(got[2:, calm] - want[2:, calm]).max() <= 2e-5 and dang[:, calm].max() <= 1e-5
     s32 = oracle.acrobot_step(g["ac_state"], g["ac_action"], dtype=np.float32)       # kernel semantics: tight
@@ -341,3 +353,26 @@ def test_acrobot_producer_consumer_kernel_is_bit_identical(gpu_pkg, monkeypatch,
         with pytest.raises(ValueError):                                                        # not whole 512-lane tiles: refused ...
             env.SetLaunchPolicy(lds_pipe=1)
         assert env.KernelName() == "step_kernel_pipe<Acrobot,4,true,15>"                         # ... and nothing changed
+
+
+@pytest.mark.parametrize("name", ["Acrobot-v1", "Pendulum-v1"])
+def test_set_state_of_get_state_leaves_the_observation_unchanged(gpu_pkg, name):
+    """Acrobot's step / reset write their observation with sincos_small, set_state recomputed it with
+    sincos_f32 — a last-bit difference for some angles, which broke the bit-exactness Checkpoint / Restore promise for
+    observations.  observe() now uses the step's own sin / cos for every angle a step can produce: after stepping into energetic
+    states, SetState(GetState()) must leave every observation bit unchanged."""
+    n = 50_000
+    rng = np.random.default_rng(12)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True) as env:
+        env.Reset()
+        if name == "Acrobot-v1":
+            env.SetState(np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32))
+            acts = rng.integers(0, 3, (6, n)).astype(np.int32)
+        else:
+            acts = rng.uniform(-2, 2, (6, n)).astype(np.float32)
+        for t in range(6):
+            env.Step(acts[t])
+        before = env.Read().Observation.copy()
+        env.SetState(env.GetState())
+        after = env.Read().Observation
+        assert np.array_equal(before, after)

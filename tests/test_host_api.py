@@ -141,6 +141,20 @@ def test_box_bounded_sampling(gymnet):
         lo.Contains([3.0, 1.0])
 
 
+def test_box_sample_integer_dtypes_floor_like_the_reference(gymnet):
+    """Box.cs:86-89: `if (DType == np.int32 || DType == np.uint32 || DType == np.@byte) sample = np.floor(sample)` and then
+    astype(DType).  For those three dtypes negative samples round DOWN (uniform(-3, 0) never yields 0 except from -0.x -> -1);
+    for any other integer dtype the reference only casts, which truncates toward zero."""
+    i32 = gymnet.Box(-3.0, 0.0, (4000,), dtype=np.int32, seed=1).Sample()
+    assert i32.dtype == np.int32 and set(np.unique(i32)) == {-3, -2, -1}                 # floor: (-1, 0) -> -1, 0 is never produced
+    i64 = gymnet.Box(-3.0, 0.0, (4000,), dtype=np.int64, seed=1).Sample()
+    assert i64.dtype == np.int64 and set(np.unique(i64)) == {-2, -1, 0}                  # cast only: (-1, 0) -> 0, (-3, -2) -> -2
+    u8 = gymnet.Box(0.0, 3.0, (4000,), dtype=np.uint8, seed=2).Sample()
+    assert u8.dtype == np.uint8 and set(np.unique(u8)) == {0, 1, 2}
+    f = gymnet.Box(-3.0, 0.0, (1000,), dtype=np.float32, seed=3).Sample()
+    assert f.dtype == np.float32 and (f != np.floor(f)).any()
+
+
 def test_discrete(gymnet):
     d = gymnet.Discrete(2, seed=5)
     assert d.Contains(0) and d.Contains(1) and not d.Contains(2) and not d.Contains(-1)    # 0 <= x < N

@@ -1,4 +1,4 @@
-"""world_size-2 test of the multi-GPU path on CPU (gloo): one process per rank, each owning a contiguous
+"""world_size-2 and world_size-8 tests of the multi-GPU path on CPU (gloo): one process per rank, each owning a contiguous
 lane block whose observations live inside the rank-major all-gather buffer; after every step the gathered
 [G][D][N/G] buffer on EVERY rank must equal the single-shard batch bit for bit (sharding invariance,
 SURVEY.md §8(e)).  Compute is the oracle-backed stand-in from tests/_oracle_local_env.py — the HIP engine
@@ -67,14 +67,19 @@ def _worker(rank, world, port, out_dir, overlap=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_rank_sharded_rollout_equals_single_shard(tmp_path, oracle, overlap):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (8, False), (8, True)])
+def test_sharded_rollout_equals_single_shard(tmp_path, oracle, world, overlap):
+    """World sizes 2 and 8 (BASELINE config 5's shape: 8 ranks, rank-major [8][4][N/8] gather buffer), with and without the
+    double-buffered overlap: ShardPlan's lane blocks, the per-rank Philox lane offsets, the overlap bookkeeping and the
+    all-gather — every rank must end up holding the single-shard batch, bit for bit, after every step."""
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     got = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
-    assert np.array_equal(got[0], got[1])                 # every rank holds the same gathered observations
+    assert got[0].shape == (STEPS, world, 4, N // world)
+    for r in range(1, world):
+        assert np.array_equal(got[0], got[r]), r          # every rank holds the same gathered observations
     # single shard, same seed, same global actions, same float32 kernel-semantics oracle
     rng = np.random.default_rng(99)
     acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
