@@ -71,6 +71,8 @@ def parse():
     p.add_argument("--no-group-leg", action="store_true", help="N > 1: skip the single-process gymnet_group_* leg")
     p.add_argument("--no-host-boundary", action="store_true", help="skip the NDArray-shaped host path figure (gymnet_vecenv_step)")
     p.add_argument("--group-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run the gymnet_group_* leg over this many members
+    p.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes "
+                   "(the constant from profiles/traffic.json is reported instead, labelled)")
     p.add_argument("--policy", default="", help="launch policy overrides for the headline handle, e.g. vec=4,nt=12,block=128 "
                    "(gymnet_vecenv_set_launch_policy; every configuration computes the same bits)")
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: CartPole in the reference's own float64 arithmetic "
@@ -250,6 +252,54 @@ def allgather_model(world, bytes_per_rank):
     direct_us = bytes_per_rank / (XGMI_LINK_GBPS * 1e9) * 1e6
     return {"link_GBps": XGMI_LINK_GBPS, "bytes_per_rank": bytes_per_rank, "direct_us": direct_us, "ring_us": direct_us * max(0, world - 1),
             "note": "analytic: 16 MiB per rank at 2^20 CartPole lanes -> ~110 us direct, ~770 us ring at 8 GPUs"}
+
+
+def measure_traffic(args, timeout=150):
+    """roofline.traffic measured IN THIS RUN: HBM-side bytes per launch of the step kernel from the PMC counters, collected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (no trace
+    flags beside --pmc), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both count KiB; on gfx950 FETCH_SIZE reports half the bytes
+    of a wide coalesced streaming read).  Each pass is a fresh CHILD process (`rocprofv3 ... -- python3 bench.py ...`: the
+    program after `--` is python3 itself, started with subprocess — never an exec from this GPU process) running 10 + 3 x 100
+    eager launches of the same kernel on the same batch.  Returns (bytes per launch, description); raises on any failure — the
+    caller then falls back to the committed constant and says so."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix=f"gymnet_pmc_{counter}_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "-d", out_dir, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu-baseline", "--no-extras", "--no-traffic", "--no-graph", "--steps", "100", "--warmup", "10", "--min-seconds", "0",
+                   "--env", args.env, "--num-envs", str(args.num_envs), "--dtype", args.dtype]
+            if args.policy:
+                cmd += ["--policy", args.policy]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            db = None
+            for dirpath, _, files in os.walk(out_dir):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(dirpath, f)
+            if r.returncode != 0 or db is None:
+                raise RuntimeError(f"rocprofv3 --pmc {counter}: rc {r.returncode}, {(r.stderr or r.stdout)[-200:]}")
+            c = sqlite3.connect(db)
+            row = c.execute("select avg(value), count(*) from counters_collection where kernel_name like '%step_kernel%' and counter_name = ?",
+                            (counter,)).fetchone()
+            c.close()
+            if not row or row[0] is None or row[1] < 50:
+                raise RuntimeError(f"rocprofv3 --pmc {counter}: no step-kernel dispatches in the database")
+            vals[counter] = (row[0], row[1])
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return traffic, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes "
+                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} step-kernel dispatches), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch")
 
 
 def parse_policy(text):
@@ -577,7 +627,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.env, {}).get(str(n))
+                traffic = tj.get(args.env + ("-f64" if f64 else ""), {}).get(str(n))
                 if traffic is not None:
                     traffic_source = ("NOT measured in this run: constant read from profiles/traffic.json — "
                                       + str(tj.get("_source", "rocprofv3 --pmc passes")))
@@ -922,6 +972,14 @@ def main():
                 out["same_box_n1"] = {"error": repr(e)[:300]}
             if not args.no_group_leg and not gather_in_region:
                 out["group_single_process"] = run_group_child(args, world, timeout=180)
+        if world == 1 and not args.no_traffic and not args.no_extras and not gather_in_region:
+            try:
+                tr, how = measure_traffic(args)
+                out["roofline"]["traffic_constant_from_profiles"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, how
+                out["roofline"]["traffic_over_moved_bytes"] = tr / out["roofline"]["bytes_per_launch"]
+            except Exception as e:                               # noqa: BLE001 - the constant (labelled) stays in the line
+                out["roofline"]["traffic_measurement_error"] = repr(e)[:300]
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
