@@ -32,16 +32,28 @@ namespace gymnet {
 // (the reduced argument is kept in one double, without a tail).
 // Larger arguments (a pole left spinning for ~1e5 steps after `done`), infinities and NaN take the OCML routines.
 // ---------------------------------------------------------------------------------------------
+// SMALL = true: the caller guarantees |x| <= kSmallAngle64 (< pi/4).  There n = rint(x * 2/pi) = +-0, each fma(-n, P, r) returns r
+// bit for bit — for r = +-0 it returns +0, which `x + 0.0` reproduces (IEEE: (-0) + (+0) = +0; never folded away without
+// fast-math) — and the quadrant fix-up with q = 0 changes nothing: the SAME bits as the general path, without the multiply, the
+// rint, three fma, the float -> int conversion and the quadrant selects.  CartPole's pole angle is below 0.21 rad until the
+// episode ends, so the step takes this path whenever every lane of the wave qualifies (kernels64.hip), like the float32 kernel.
+constexpr double kSmallAngle64 = 0.785;
+template <bool SMALL = false>
 __device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out) {
-    if (__builtin_expect(!(__builtin_fabs(x) <= 823549.0), 0)) {
-        s_out = ::sin(x);
-        c_out = ::cos(x);
-        return;
+    double n = 0.0, r;
+    if constexpr (SMALL) {
+        r = x + 0.0;
+    } else {
+        if (__builtin_expect(!(__builtin_fabs(x) <= 823549.0), 0)) {
+            s_out = ::sin(x);
+            c_out = ::cos(x);
+            return;
+        }
+        n = __builtin_rint(x * 6.36619772367581382433e-01);
+        r = __builtin_fma(-n, 1.57079632673412561417e+00, x);         // P1: first 33 bits of pi/2  (0x3FF921FB54400000)
+        r = __builtin_fma(-n, 6.07710050630396597660e-11, r);         // P2: next 33 bits            (0x3DD0B4611A600000)
+        r = __builtin_fma(-n, 2.02226624879595063154e-21, r);         // P3: pi/2 - P1 - P2 rounded  (0x3BA3198A2E037073)
     }
-    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
-    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);      // P1: first 33 bits of pi/2  (0x3FF921FB54400000)
-    r = __builtin_fma(-n, 6.07710050630396597660e-11, r);             // P2: next 33 bits            (0x3DD0B4611A600000)
-    r = __builtin_fma(-n, 2.02226624879595063154e-21, r);             // P3: pi/2 - P1 - P2 rounded  (0x3BA3198A2E037073)
     const double z = r * r;
     // sin r = r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
     double ps = __builtin_fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
@@ -59,6 +71,7 @@ __device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_ou
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double c = w + (((1.0 - w) - hz) + z * (z * pc));
+    if constexpr (SMALL) { s_out = s; c_out = c; return; }
     // quadrant: sin x = {s, c, -s, -c}[n mod 4], cos x = {c, -s, -c, s}[n mod 4]
     const int q = (int)n & 3;
     const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
@@ -89,11 +102,12 @@ struct CartPole64 {
     static constexpr float x_threshold = 2.4f;
 
     // :141-167, statement for statement; C#'s usual arithmetic conversions written out (float op double -> double)
+    template <bool SMALL_ANGLE = false>
     __device__ __forceinline__ static void step(double (&st)[S], int32_t a, bool &done) {
         double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];                                  // :141-144
         const float force = a == 1 ? force_mag : -force_mag;                                                // :146
         double sintheta, costheta;
-        sincos_f64(theta, sintheta, costheta);                                                              // :147-148
+        sincos_f64<SMALL_ANGLE>(theta, sintheta, costheta);                                                 // :147-148
         const double temp = ((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta) / (double)total_mass;   // :149
         const double thetaacc = ((double)gravity * sintheta - costheta * temp)
                                 / ((double)length * (4.0 / 3.0 - (double)masspole * costheta * costheta / (double)total_mass)); // :150

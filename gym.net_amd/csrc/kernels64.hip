@@ -95,13 +95,19 @@ __global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
     float reward[VEC];
     uint8_t done[VEC];
     uint32_t after = 0;            // lanes of this thread stepped although they had already returned done (CartPoleEnv.cs:176-179)
+    // wave-uniform: every pole angle of the wave inside the range where sin / cos need no reduction (identical bits either way)
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) small = small && (__builtin_fabs(s[2][j]) <= kSmallAngle64);
+    const bool wave_small = __ballot(!small) == 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         double sj[S];
 #pragma unroll
         for (int k = 0; k < S; ++k) sj[k] = s[k][j];
         bool dn;
-        CartPole64::step(sj, act[j], dn);
+        if (wave_small) CartPole64::step<true>(sj, act[j], dn);
+        else CartPole64::step<false>(sj, act[j], dn);
         float rw = 1.0f;                                                             // :168-183
         if constexpr (!AUTORESET) {
             if (dn) {

@@ -263,3 +263,63 @@ def test_pinned_host_buffers_give_the_same_results_as_caller_memory(gpu_pkg, nam
         assert np.array_equal(o2, out.Observation) and np.array_equal(r2, out.Reward)
         with pytest.raises(ValueError):
             a.StepInto(pa.astype(np.int64), po, pr, pd)
+
+
+def test_abi4_entry_points_reject_bad_arguments_without_side_effects(gpu_pkg):
+    """Error behaviour of the ABI 4 additions, straight through ctypes: null pointers, a struct_size from another ABI, sizes that do
+    not match the array, ids out of range, arrays the configuration lacks — every one a status code (never a crash), the right
+    reference-style exception class in the binding, and no change to the handle."""
+    import ctypes as C
+    capi = gpu_pkg._capi
+    lib = capi.load_library()
+    n = 1000
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True) as env:
+        env.Reset()
+        name0, pol0 = env.KernelName(), env.GetLaunchPolicy()
+        assert lib.gymnet_vecenv_set_launch_policy(env._h, None) == capi.ERR_INVALID_ARG
+        bad = capi.LaunchPolicy(struct_size=8, vec=1, block=-1, nt=-1, sequential_lanes=-1, reset_form=-1, lds_pipe=-1, occupancy_lds_bytes=-1, graph=-1)
+        assert lib.gymnet_vecenv_set_launch_policy(env._h, C.byref(bad)) == capi.ERR_INVALID_ARG and b"ABI mismatch" in lib.gymnet_last_error()
+        assert lib.gymnet_vecenv_get_launch_policy(env._h, None) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_launch_policy(None, C.byref(bad)) == capi.ERR_INVALID_ARG
+        assert env.KernelName() == name0 and env.GetLaunchPolicy() == pol0
+        buf = np.zeros(n, np.float32)
+        p = buf.ctypes.data_as(C.c_void_p)
+        assert lib.gymnet_vecenv_get_array(env._h, capi.ARRAY_REWARD, None, n * 4) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_array(env._h, capi.ARRAY_REWARD, p, n * 4 - 1) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_array(env._h, 99, p, n * 4) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_array(env._h, -1, p, n * 4) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_array(env._h, capi.ARRAY_STEPS_BEYOND_DONE, p, n * 4) == capi.ERR_UNSUPPORTED      # auto-reset: no sbd
+        assert lib.gymnet_vecenv_get_array(env._h, capi.ARRAY_FINAL_OBS, p, n * 16) == capi.ERR_UNSUPPORTED
+        assert lib.gymnet_vecenv_get_array(env._h, capi.ARRAY_LANE_SEEDS, p, n * 8) == capi.ERR_UNSUPPORTED             # one key for all lanes
+        assert lib.gymnet_vecenv_set_array(env._h, capi.ARRAY_EPISODE_LENGTH, None, n * 4) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_set_array(env._h, capi.ARRAY_EPISODE_LENGTH, p, n * 8) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_array(None, capi.ARRAY_REWARD, p, n * 4) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_seed(None, None, None) == capi.ERR_INVALID_ARG
+        assert lib.gymnet_vecenv_get_seed(env._h, None, None) == capi.OK                                                 # both outs optional
+        assert env.GetSeed() == (SEED, False)
+        with pytest.raises(NotImplementedError):
+            env.GetArray("final_obs")
+        assert env.GetArray("episode_length").max() == 0 and env.GetArray("done").dtype == np.uint8
+        # set(LANE_SEEDS) on a handle without per-lane keys INSTALLS them, without rewinding the tick
+        tick = env.Tick
+        env.SetArray("lane_seeds", np.arange(n, dtype=np.uint64) + 5)
+        assert env.GetSeed() == (SEED, True) and env.Tick == tick and env.KernelName().split(",")[3] == "true"
+        assert np.array_equal(env.GetArray("lane_seeds"), np.arange(n, dtype=np.uint64) + 5)
+    # float64 handles: the flag's documented exclusions, and float buffers are the caller's responsibility (typed void*)
+    cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=0, num_envs=64, lane_offset=0, device=0,
+                      flags=capi.FLAG_F64 | capi.FLAG_AUTORESET | capi.FLAG_DONE_LIST, seed=1)
+    h = C.c_void_p()
+    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_UNSUPPORTED and not h.value
+    cfg.flags = capi.FLAG_COMPACT_RECORDS_ONLY | capi.FLAG_AUTORESET
+    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG and b"DONE_LIST" in lib.gymnet_last_error()
+    cfg.flags, cfg.env_id = capi.FLAG_F64, 3
+    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_UNSUPPORTED
+    with gpu_pkg.VectorEnv("CartPole-v1", 64, seed=1, dtype=np.float64) as e64:
+        v = e64.DeviceView()
+        assert v.state_dtype == capi.DTYPE_F64 and v.d_state == v.d_obs and v.d_state and not v.d_obs_alt and v.obs_aliases_state == 1
+        with gpu_pkg.VectorEnv("CartPole-v1", 64, seed=1) as e32:
+            assert e32.DeviceView().state_dtype == capi.DTYPE_F32
+    gcfg = capi.GroupConfig(struct_size=C.sizeof(capi.GroupConfig), env_id=0, global_num_envs=128, num_members=2,
+                            flags=capi.FLAG_AUTORESET | capi.FLAG_F64, seed=1, devices=None, gather=capi.GATHER_NONE, max_episode_steps=0)
+    g = C.c_void_p()
+    assert lib.gymnet_group_create(C.byref(gcfg), C.byref(g)) == capi.ERR_UNSUPPORTED and not g.value    # float64 handles cannot be group members

@@ -237,3 +237,52 @@ def test_f64_at_2p20_lanes_matches_the_twin_and_the_float32_engine_statistically
             o32 = f32.Step(a_host[0])
             w, _, wd, _ = oracle.cartpole_step(s32.astype(np.float64), a_host[0], dtype=np.float64)
             assert np.abs(f32.GetState().astype(np.float64) - w).max() <= 1e-5 and np.array_equal(o32.Done, wd.astype(bool))
+
+
+def test_f64_kernel_reproduces_the_committed_twin_trace(gpu_pkg, golden):
+    """The HIP float64 kernel against tests/golden/cartpole_f64_kernel.npz (bit patterns committed from the oracle's twin): reset
+    draws at lane offsets above 2^32 and large ticks, and a 250-step free-running auto-reset trace of 16 lanes."""
+    g = golden("cartpole_f64_kernel")
+    for k, (off, tick) in enumerate(((0, 0), (123_456_789_000, 7), (1 << 40, 2 ** 33 + 5))):
+        with gpu_pkg.VectorEnv("CartPole-v1", 64, seed=SEED, auto_reset=True, lane_offset=off, dtype=np.float64) as env:
+            env.Tick = tick
+            assert np.array_equal(env.Reset().T, g["resets"][k]), k
+    seed, off = int(g["trace_seed"]), int(g["trace_offset"])
+    with gpu_pkg.VectorEnv("CartPole-v1", 16, seed=seed, auto_reset=True, lane_offset=off, dtype=np.float64) as env:
+        env.Reset()
+        for t in range(g["trace_actions"].shape[0]):
+            out = env.Step(g["trace_actions"][t])
+            assert np.array_equal(out.Observation.T, g["trace_states"][t]) and np.array_equal(out.Done, g["trace_done"][t].astype(bool)), t
+
+
+def test_f64_steps_beyond_done_reward_stream_and_counter(gpu_pkg, golden):
+    """CartPoleEnv.cs:168-183 in the float64 mode: reward 1, ..., 1, 1 (done), 0, 0, ... when the caller keeps stepping without a
+    reset, steps_beyond_done -1, ..., -1, 0, 1, 2, ..., and the console warning counted instead of printed — the recorded
+    sequence of tests/golden/cartpole_steps_beyond_done.npz, free-running, states within 1e-12; plus a ragged batch whose
+    lanes fall at different times (two-lane and tail paths of the kernel, one atomic per wave for the counter)."""
+    g = golden("cartpole_steps_beyond_done")
+    with gpu_pkg.VectorEnv("CartPole-v1", 1, seed=SEED, dtype=np.float64) as env:
+        env.Reset()
+        env.SetState(g["start"].reshape(4, 1))
+        for t in range(g["reward"].shape[0]):
+            out = env.Step(1)
+            assert out.Reward[0] == g["reward"][t] and bool(out.Done[0]) == bool(g["done"][t])
+            assert env.GetStepsBeyondDone()[0] == g["sbd"][t]
+            assert np.abs(env.GetState()[:, 0] - g["states"][t]).max() <= 1e-12
+        assert env.Counters()["stepped_after_done"] == int(g["done"].sum()) - 1
+    n, steps = 1000 + 1, 40
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, dtype=np.float64) as a, gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED) as b:
+        a.Reset(); b.Reset()
+        b.SetState(a.GetState().astype(np.float32))
+        a.SetState(b.GetState().astype(np.float64))                  # both start from the same float32-representable states
+        after = 0
+        sbd = np.full(n, -1)
+        for t in range(steps):
+            oa, ob = a.Step(1), b.Step(1)                            # always push right: every lane falls within ~15 steps
+            if t < 8:                                                # before float32 drift can move a termination by a step
+                assert np.array_equal(oa.Done, ob.Done) and np.array_equal(oa.Reward, ob.Reward)
+            after += int((oa.Done & (sbd >= 0)).sum())
+            sbd = np.where(oa.Done, sbd + 1, sbd)
+            assert np.array_equal(a.GetStepsBeyondDone(), sbd)
+        assert oa.Done.all() and (oa.Reward == 0).all()
+        assert a.Counters()["stepped_after_done"] == after > n

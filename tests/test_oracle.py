@@ -675,3 +675,20 @@ def test_f64_reset_draw_is_a_53_bit_uniform_on_the_reference_interval(oracle):
     assert np.abs(s - s32.astype(np.float64)).max() < 2e-8
     per_lane = np.arange(n, dtype=np.uint64) + 9
     assert np.array_equal(oracle.cartpole_reset_f64(0, 0, 3, n, lane_seed=per_lane)[:, 5], oracle.cartpole_reset_f64(int(per_lane[5]), 5, 3, 1)[:, 0])
+
+
+def test_f64_twin_reproduces_its_committed_bit_patterns(oracle, golden):
+    """tests/golden/cartpole_f64_kernel.npz (tests/golden/make_f64_golden.py): sin / cos bit patterns, reset draws and a
+    250-step auto-reset trace of the float64 twin.  The HIP kernel is compared with the twin live (tests/test_gpu_f64.py) and
+    with this fixture; here the twin itself is pinned, so kernel and twin cannot drift together unnoticed."""
+    g = golden("cartpole_f64_kernel")
+    s, c = oracle.sincos_f64_kernel(g["sincos_x"])
+    assert np.array_equal(s.view(np.uint64), g["sincos_s"].view(np.uint64)) and np.array_equal(c.view(np.uint64), g["sincos_c"].view(np.uint64))
+    for k, (off, tick) in enumerate(((0, 0), (123_456_789_000, 7), (1 << 40, 2 ** 33 + 5))):
+        assert np.array_equal(oracle.cartpole_reset_f64(0x5EED, off, tick, 64), g["resets"][k])
+    seed, off = int(g["trace_seed"]), int(g["trace_offset"])
+    st = oracle.cartpole_reset_f64(seed, off, 0, 16)
+    for t in range(g["trace_actions"].shape[0]):
+        st, r, d = oracle.cartpole_autoreset_step_f64(seed, off, 1 + t, st, g["trace_actions"][t])
+        assert np.array_equal(st, g["trace_states"][t]) and np.array_equal(d, g["trace_done"][t]), t
+    assert 5 < int(g["trace_done"].sum()) < 16 * 250 / 8                                      # episodes do end and restart in it
