@@ -748,6 +748,32 @@ def main():
         except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
             host_boundary = {"error": repr(e)[:300]}
 
+    # Secondary figure, NEVER `value`: BASELINE config 1's shape on the GPU — ONE instance stepped through the single-instance façade
+    # (README.md:32-52: Step, `if (done) Reset()`), which is latency-bound by construction (a kernel launch + a host round trip
+    # per step): the honest counterpart of cpu_baseline.single_instance_100k_steps_per_sec.  float64 = the façade's default.
+    facade = None
+    if extras and args.env == "CartPole-v1":
+        try:
+            facade = {"note": "N = 1 through the host boundary: launch + synchronize per step; the engine is built for batches"}
+            for label, dt in (("float64_default", "float64"), ("float32", "float32")):
+                cp = pkg.CartPoleEnv(device=dev_index, seed=seed, dtype=dt)
+                try:
+                    cp.Reset()
+                    for i in range(200):
+                        if cp.Step(i % 2).Done:
+                            cp.Reset()
+                    t0 = time.perf_counter()
+                    m, eps = 3000, 0
+                    for i in range(m):
+                        if cp.Step(i % 2).Done:
+                            cp.Reset(); eps += 1
+                    dt_s = time.perf_counter() - t0
+                    facade[label] = {"steps_per_sec": m / dt_s, "us_per_step": dt_s / m * 1e6, "episodes": eps}
+                finally:
+                    cp.CloseEnvironment()
+        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
+            facade = {"error": repr(e)[:300]}
+
     # Secondary figures for N > 1, NOT the headline: the same stepping with the RCCL all-gather of observations
     # north_star mentions after EVERY step (in place, rank-major [G][D][N/G] buffer).  The stepping path itself needs no
     # collective; this shows what a consumer that wants every rank to see all observations pays over xGMI —
@@ -926,6 +952,8 @@ def main():
             out["fused_rollout"] = fused
         if host_boundary:
             out["host_boundary"] = host_boundary
+        if facade:
+            out["single_instance_gpu_facade"] = facade
         if gathered:
             out["with_obs_allgather"] = gathered
     if use_dist:
