@@ -244,9 +244,9 @@ def test_sharding_invariance_bitwise(gpu_pkg):
 def test_done_list_episode_stats_final_obs(gpu_pkg, oracle, with_list, vec, monkeypatch):
     """Episode bookkeeping.  With the done list the step kernel writes COMPACT records — (lane, return, length,
     terminal observation) at the lane's position in the list — checked per step against the host-side bookkeeping of
-    BasePlaySession.cs:58-69; the dense per-lane getters apply the latest step's records on each call, so a caller that reads
-    them every step sees every lane's last finished episode.  Without the list the kernel maintains the dense arrays itself
-    and they are complete even when read only at the end."""
+    BasePlaySession.cs:58-69.  With or without the list the kernel maintains the dense per-lane arrays itself (round 4; the
+    compact-records-only behaviour of round 3 is an opt-in, tested in test_dense_episode_views_stay_current_...), so they are
+    complete whether read every step or only at the end."""
     n, steps = 20_000, 60
     rng = np.random.default_rng(9)
     ret = np.zeros(n, np.float32); ln = np.zeros(n, np.int32)
@@ -290,7 +290,7 @@ def test_done_list_episode_stats_final_obs(gpu_pkg, oracle, with_list, vec, monk
                     env.DoneRecordsDevice(d_l, None, None, None, 3, d_c); env.Sync()      # a short buffer: true count, first records only
                     assert int(d_c.item()) == c
                 assert env.Counters()["last_done_count"] == int(d.sum())
-                env.EpisodeStats(); env.FinalObs()                                    # dense views: the latest records are applied per call
+                # (no dense-view getter inside the loop: the kernel keeps those arrays current without the caller's help — ADVICE r3)
             ret[d] = 0; ln[d] = 0
         got_ret, got_len = env.EpisodeStats()
         assert np.array_equal(got_len, fin_len) and np.array_equal(got_ret, fin_ret)   # integer step counts exact
