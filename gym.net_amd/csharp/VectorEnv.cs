@@ -26,6 +26,8 @@ namespace Gym.Envs.Amd {
         private IntPtr _h;
         private readonly int _obsDim;
         private readonly bool _boxAction;
+        private readonly bool _f64;                 // GymnetFlags.F64 (CartPole): every observation buffer holds doubles — the reference's
+                                                    // actual dtype (CartPoleEnv.cs:166,185); the library writes 8 bytes per element
         internal ulong[] PendingLaneSeeds;          // filled by the lane proxies when the base-class Seed runs
         internal int PendingLaneSeedCount;
 
@@ -33,6 +35,7 @@ namespace Gym.Envs.Amd {
                          long laneOffset = 0)
             : base(numEnvs, MakeObservationSpace(env, out int obsDim), MakeActionSpace(env, out bool box)) {
             _obsDim = obsDim; _boxAction = box;
+            _f64 = (flags & GymnetFlags.F64) != 0;
             var cfg = new GymnetConfig {
                 struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = numEnvs, lane_offset = laneOffset,
                 device = device, flags = (uint) flags, seed = seed
@@ -60,11 +63,25 @@ namespace Gym.Envs.Amd {
             return box ? (Space) new Box(i.action_low, i.action_high, new Shape(1), np.float32) : new Discrete(i.action_n);
         }
 
-        /// IVecEnv.Reset() (IVecEnv.cs:14).  Batched form: one NDArray of shape (N, D).
+        /// An observation buffer of the handle's dtype (float32, or float64 with GymnetFlags.F64), pinned for one native call.
+        /// EVERY call that hands the library an `obs_out` goes through here, so the element size can never disagree with the handle.
+        private delegate int ObsCall(void* obs);
+        private NDArray WithObs(ObsCall call) {
+            int n = NumberOfEnvironments;
+            if (_f64) {
+                var obs = new double[n * _obsDim];
+                fixed (double* p = obs) Native.Check(call(p));
+                return np.array(obs).reshape(n, _obsDim);
+            } else {
+                var obs = new float[n * _obsDim];
+                fixed (float* p = obs) Native.Check(call(p));
+                return np.array(obs).reshape(n, _obsDim);
+            }
+        }
+
+        /// IVecEnv.Reset() (IVecEnv.cs:14).  Batched form: one NDArray of shape (N, D), float32 — float64 for an F64 handle.
         public NDArray ResetBatch() {
-            var obs = new float[NumberOfEnvironments * _obsDim];
-            fixed (float* p = obs) Native.Check(Native.gymnet_vecenv_reset(_h, p));
-            return np.array(obs).reshape(NumberOfEnvironments, _obsDim);
+            return WithObs(p => Native.gymnet_vecenv_reset(_h, p));
         }
 
         public override NDArray[] Reset() {                                                                       // VecEnvWrapper.cs:18-20
@@ -77,13 +94,10 @@ namespace Gym.Envs.Amd {
         /// The caller's `if (done) Reset()` (README.md:36-40) for the lanes in mask (null = lanes whose last done flag is set).
         public NDArray ResetWhere(byte[] mask = null) {
             if (mask != null && mask.Length != NumberOfEnvironments) throw new ArgumentException("mask length must equal NumberOfEnvironments");
-            var obs = new float[NumberOfEnvironments * _obsDim];
-            fixed (float* p = obs) fixed (byte* m = mask) Native.Check(Native.gymnet_vecenv_reset_where(_h, m, p));
-            return np.array(obs).reshape(NumberOfEnvironments, _obsDim);
+            return WithObs(p => { fixed (byte* m = mask) return Native.gymnet_vecenv_reset_where(_h, m, p); });
         }
 
-        private Step[] ToSteps(float[] obs, float[] rew, byte[] done) {
-            var all = np.array(obs).reshape(NumberOfEnvironments, _obsDim);
+        private Step[] ToSteps(NDArray all, float[] rew, byte[] done) {
             var steps = new Step[NumberOfEnvironments];
             for (int i = 0; i < steps.Length; i++) steps[i] = new Step(all[i], rew[i], done[i] != 0, null);       // Step.cs:15-20
             return steps;
@@ -92,9 +106,8 @@ namespace Gym.Envs.Amd {
         /// IVecEnv.Step(int) (IVecEnv.cs:15): ONE scalar action broadcast to every lane; Step[] materialised per lane.
         public override Step[] Step(int action) {                                                                 // VecEnvWrapper.cs:22-24
             int n = NumberOfEnvironments;
-            var obs = new float[n * _obsDim]; var rew = new float[n]; var done = new byte[n];
-            fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done)
-                Native.Check(Native.gymnet_vecenv_step_broadcast(_h, action, po, pr, pd));
+            var rew = new float[n]; var done = new byte[n];
+            var obs = WithObs(po => { fixed (float* pr = rew) fixed (byte* pd = done) return Native.gymnet_vecenv_step_broadcast(_h, action, po, pr, pd); });
             return ToSteps(obs, rew, done);
         }
 
@@ -105,16 +118,18 @@ namespace Gym.Envs.Amd {
         public (NDArray obs, NDArray reward, NDArray done) Step(NDArray actions) {
             int n = NumberOfEnvironments;
             if (actions.size != n) throw new ArgumentException("Number of actions passed should be equals to number of environments");
-            var obs = new float[n * _obsDim]; var rew = new float[n]; var done = new byte[n];
-            fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done) {
-                if (_boxAction) { var a = actions.astype(np.float32).ToArray<float>(); fixed (float* pa = a) Native.Check(Native.gymnet_vecenv_step(_h, pa, po, pr, pd)); }
-                else { var a = actions.astype(np.int32).ToArray<int>(); fixed (int* pa = a) Native.Check(Native.gymnet_vecenv_step(_h, pa, po, pr, pd)); }
-            }
-            return (np.array(obs).reshape(n, _obsDim), np.array(rew), np.array(done));
+            var rew = new float[n]; var done = new byte[n];
+            var obs = WithObs(po => {
+                fixed (float* pr = rew) fixed (byte* pd = done) {
+                    if (_boxAction) { var a = actions.astype(np.float32).ToArray<float>(); fixed (float* pa = a) return Native.gymnet_vecenv_step(_h, pa, po, pr, pd); }
+                    else { var a = actions.astype(np.int32).ToArray<int>(); fixed (int* pa = a) return Native.gymnet_vecenv_step(_h, pa, po, pr, pd); }
+                }
+            });
+            return (obs, np.array(rew), np.array(done));
         }
 
         /// ABI 3: the library's page-locked, device-mapped host buffers (valid until Close): actions int32 / float32 [N], obs
-        /// float32 [N, D] row-major, reward float32 [N], done uint8 [N].  A caller that keeps its NDArrays over this memory
+        /// float32 [N, D] row-major (float64 for an F64 handle), reward float32 [N], done uint8 [N].  A caller that keeps its NDArrays over this memory
         /// (or reads it through spans) steps with StepPinned(): no managed arrays, no staging copies — the export kernel writes
         /// the results straight across PCIe (0.50 ms per 2^20-lane step instead of 0.57-0.58 ms through pageable arrays).
         public struct PinnedBuffers { public IntPtr Actions; public IntPtr Obs; public IntPtr Reward; public IntPtr Done; }
@@ -127,7 +142,7 @@ namespace Gym.Envs.Amd {
         /// One vector step over the pinned buffers: reads HostBuffers().Actions, fills Obs / Reward / Done.  Blocks until they are written.
         public void StepPinned() {
             var b = HostBuffers();
-            Native.Check(Native.gymnet_vecenv_step(_h, (void*) b.Actions, (float*) b.Obs, (float*) b.Reward, (byte*) b.Done));
+            Native.Check(Native.gymnet_vecenv_step(_h, (void*) b.Actions, (void*) b.Obs, (float*) b.Reward, (byte*) b.Done));
         }
 
         /// ABI 4: override fields of the step kernel's launch configuration (every field of `policy` that is -1 stays as it is;
@@ -179,9 +194,8 @@ namespace Gym.Envs.Amd {
             if (_boxAction) { var a = new float[n]; for (int i = 0; i < n; i++) a[i] = action; fixed (float* pa = a) Native.Check(Native.gymnet_vecenv_step_async(_h, pa)); }
             else { var a = new int[n]; for (int i = 0; i < n; i++) a[i] = action; fixed (int* pa = a) Native.Check(Native.gymnet_vecenv_step_async(_h, pa)); }
             return Task.Run(() => {
-                var obs = new float[n * _obsDim]; var rew = new float[n]; var done = new byte[n];
-                fixed (float* po = obs) fixed (float* pr = rew) fixed (byte* pd = done)
-                    Native.Check(Native.gymnet_vecenv_step_wait(_h, po, pr, pd));
+                var rew = new float[n]; var done = new byte[n];
+                var obs = WithObs(po => { fixed (float* pr = rew) fixed (byte* pd = done) return Native.gymnet_vecenv_step_wait(_h, po, pr, pd); });
                 return ToSteps(obs, rew, done);
             });
         }

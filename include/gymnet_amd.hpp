@@ -146,6 +146,9 @@ class VectorEnv {
 public:
     VectorEnv(gymnet_env_id env, int64_t num_envs, int device = 0, uint64_t seed = 0, uint32_t flags = 0,
               int64_t lane_offset = 0, void *stream = nullptr) {
+        // this class hands the library std::vector<float> observation buffers: a float64 handle (8 bytes per element) would overrun
+        // them, so the flag is refused HERE; CartPoleEnv64 below is the float64 host class
+        if (flags & GYMNET_FLAG_F64) throw std::logic_error("gymnet::VectorEnv is the float32 host class; GYMNET_FLAG_F64 handles: use gymnet::CartPoleEnv64 or the C ABI");
         check(gymnet_env_describe((int)env, &info_));
         // everything that can throw is built BEFORE the native handle exists: a constructor that throws runs no
         // destructor, so an allocation failing after gymnet_vecenv_create would leak the handle

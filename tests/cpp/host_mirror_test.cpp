@@ -238,6 +238,7 @@ static void gpu_tests() {
         }
         CHECK(close && done_same && steps == 200, "float32 engine within 1e-5 of the float64 one per teacher-forced step, same done / reward");
         CHECK(throws<std::logic_error>([] { gymnet::CartPoleEnv64 bad(0, 1, GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_AUTORESET); }), "F64 + DONE_LIST -> NotSupportedException");
+        CHECK(throws<std::logic_error>([] { gymnet::VectorEnv bad(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_F64); }), "the float32 host class refuses a float64 handle (its buffers are float)");
     }
     {   // ABI 4: launch policy through the ABI, arrays by id
         gymnet::VectorEnv env(GYMNET_ENV_CARTPOLE, 4096, 0, 5, GYMNET_FLAG_AUTORESET | GYMNET_FLAG_EPISODE_STATS);
