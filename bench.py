@@ -254,7 +254,7 @@ def allgather_model(world, bytes_per_rank):
             "note": "analytic: 16 MiB per rank at 2^20 CartPole lanes -> ~110 us direct, ~770 us ring at 8 GPUs"}
 
 
-def measure_traffic(args, timeout=150):
+def measure_traffic(args, timeout=90):
     """roofline.traffic measured IN THIS RUN: HBM-side bytes per launch of the step kernel from the PMC counters, collected as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (no trace
     flags beside --pmc), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both count KiB; on gfx950 FETCH_SIZE reports half the bytes

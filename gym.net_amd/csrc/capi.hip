@@ -181,7 +181,7 @@ int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
     if (p.block != -1) { if (p.block == 64 || p.block == 128 || p.block == 256) c.block = p.block; else ST_TRY(bad("block", p.block)); }
     if (p.nt != -1) { if (p.nt == 0 || p.nt == 12 || p.nt == 15) c.nt = p.nt; else ST_TRY(bad("nt", p.nt)); }
     if (p.sequential_lanes != -1) {
-        if (p.sequential_lanes >= 1 && p.sequential_lanes <= 5 && (acrobot || p.sequential_lanes == 1)) c.items = p.sequential_lanes;
+        if (p.sequential_lanes >= 1 && p.sequential_lanes <= (h->f64 ? 4 : 5) && (acrobot || h->f64 || p.sequential_lanes == 1)) c.items = p.sequential_lanes;
         else ST_TRY(bad("sequential_lanes", p.sequential_lanes));
     }
     if (p.reset_form != -1) { if (p.reset_form == 0 || p.reset_form == 1) c.reset_form = p.reset_form; else ST_TRY(bad("reset_form", p.reset_form)); }
@@ -213,6 +213,12 @@ void default_policy(gymnet_vecenv *h) {
         // nothing non-temporal 16.2, one lane per thread 15.6
         h->lcfg = LaunchCfg{2, 256, 15, 0, 1, 0, 0};
         if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
+        // The multi-item kernel (step_kernel_f64_pipe: a thread owns 2 lane pairs, all loads first, then advance / store pair after
+        // pair) wins exactly where the one-shot kernel is ONE full lock-step generation of waves — 2^20 lanes = 2^19 threads = 8 waves
+        // on every SIMD: 14.4 -> 13.1-13.2 us (0.67 -> 0.73 of 8 TB/s on its 73 B; profiles/f64_forms_r04.txt).  Below (2^19: 8.9 vs
+        // 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the generations overlap by
+        // themselves.  Lean variant and whole 1024-lane groups only (the launcher falls back otherwise).
+        if (h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = 2;
         return;
     }
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
@@ -295,7 +301,7 @@ int seed_handle(gymnet_vecenv *h, uint64_t seed) {
 int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
     if (h->f64) {
         StepArgs64 a = make_step_args64(h, d_actions);
-        HIP_TRY(h, launch_step_f64(h->autoreset, h->extras, a, h->lcfg.vec, h->lcfg.nt, h->stream));
+        HIP_TRY(h, launch_step_f64(h->autoreset, h->extras, a, h->lcfg.vec, h->lcfg.nt, h->lcfg.items, h->stream));
         h->tick += 1; h->tslot ^= 1; h->step_launches += 1; h->lane_steps += (uint64_t)h->n;
         return GYMNET_OK;
     }
@@ -990,7 +996,7 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
 int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity) {
     return guarded([&]() -> int {
     if (!h || !buf || capacity < 1) return fail(h, GYMNET_ERR_INVALID_ARG, "null handle / buffer");
-    if (h->f64) { describe_step_kernel_f64(h->autoreset, h->extras, h->lcfg.vec, h->lcfg.nt, buf, (size_t)capacity); return GYMNET_OK; }
+    if (h->f64) { describe_step_kernel_f64(h->autoreset, h->extras, h->lcfg.vec, h->lcfg.nt, h->lcfg.items, h->n, buf, (size_t)capacity); return GYMNET_OK; }
     if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, buf, (size_t)capacity) < 0)
         return fail(h, GYMNET_ERR_INVALID_ARG, "unknown env");
     return GYMNET_OK;

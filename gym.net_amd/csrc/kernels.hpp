@@ -76,9 +76,10 @@ struct StepArgs64 {
     uint64_t lane_offset, seed;
     int32_t parity, max_episode_steps;
 };
-// vec: 2 (16-byte accesses on the state rows) or 1; nt as LaunchCfg::nt
-hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, hipStream_t st);
-int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, char *buf, size_t cap);
+// vec: 2 (16-byte accesses on the state rows) or 1; nt as LaunchCfg::nt; items: lane pairs per thread of the multi-item kernel
+// (2..4: lean variant, vec 2, n a multiple of 2 * items * 256 — else the one-shot kernel runs)
+hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, int items, hipStream_t st);
+int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, int items, int64_t n, char *buf, size_t cap);
 struct ResetArgs64 {
     double *state; int32_t *sbd; uint8_t *done;
     const uint8_t *mask;      // NULL = all lanes

@@ -62,69 +62,69 @@ __device__ __forceinline__ uint32_t lane_id64() {
 
 }  // namespace
 
-// ONE launch advances every lane by one env-step.  NT as in kernels.hip: 1 state loads, 2 state stores, 4 action load,
+// What one thread reads for its VEC lanes before it can advance them
+template <int VEC>
+struct Lanes64 {
+    double s[CartPole64::S][VEC];
+    int32_t act[VEC], sbd[VEC], ep_len[VEC];
+    float ep_ret[VEC];
+};
+
+template <int VEC, bool AUTORESET, bool EXTRAS, int NT>
+__device__ __forceinline__ void load_lanes64(const StepArgs64 &a, int64_t i0, bool full, bool stats, Lanes64<VEC> &L) {
+    constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
+    const int64_t n = a.n;
+#pragma unroll
+    for (int k = 0; k < CartPole64::S; ++k) load_row<double, VEC, NT_SL>(a.state + k * a.stride, i0, n, full, L.s[k]);
+    load_row<int32_t, VEC, NT_A>(a.action, i0, n, full, L.act);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) L.sbd[j] = -1;
+    if constexpr (!AUTORESET) load_row<int32_t, VEC, NT_SL>(a.sbd, i0, n, full, L.sbd);
+    if constexpr (EXTRAS) {
+        if (stats) { load_row<float, VEC, NT_SL>(a.ep_ret, i0, n, full, L.ep_ret); load_row<int32_t, VEC, NT_SL>(a.ep_len, i0, n, full, L.ep_len); }
+    }
+}
+
+// advance the VEC lanes and write everything back.  NT as in kernels.hip: 1 state loads, 2 state stores, 4 action load,
 // 8 reward / done stores.  EXTRAS: episode return / length bookkeeping, the max_episode_steps truncation, per-lane seeds.
 template <int VEC, bool AUTORESET, bool EXTRAS, int NT>
-__global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
+__device__ __forceinline__ void advance_and_store64(const StepArgs64 &a, int64_t i0, bool full, bool stats, uint64_t tick, Lanes64<VEC> &L) {
     constexpr int S = CartPole64::S;
-    constexpr bool NT_SL = (NT & 1) != 0, NT_SS = (NT & 2) != 0, NT_A = (NT & 4) != 0, NT_O = (NT & 8) != 0;
-    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    const uint64_t tick = a.tick2[a.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
     const int64_t n = a.n;
-    if (i0 >= n) return;
-    const bool full = i0 + VEC <= n;
-
-    double s[S][VEC];
-#pragma unroll
-    for (int k = 0; k < S; ++k) load_row<double, VEC, NT_SL>(a.state + k * a.stride, i0, n, full, s[k]);
-    int32_t act[VEC];
-    load_row<int32_t, VEC, NT_A>(a.action, i0, n, full, act);
-    int32_t sbd[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) sbd[j] = -1;
-    if constexpr (!AUTORESET) load_row<int32_t, VEC, NT_SL>(a.sbd, i0, n, full, sbd);
-    float ep_ret[VEC];
-    int32_t ep_len[VEC];
-    bool stats = false;
-    if constexpr (EXTRAS) {
-        stats = a.ep_ret != nullptr;
-        if (stats) { load_row<float, VEC, NT_SL>(a.ep_ret, i0, n, full, ep_ret); load_row<int32_t, VEC, NT_SL>(a.ep_len, i0, n, full, ep_len); }
-    }
-
     float reward[VEC];
     uint8_t done[VEC];
     uint32_t after = 0;            // lanes of this thread stepped although they had already returned done (CartPoleEnv.cs:176-179)
     // wave-uniform: every pole angle of the wave inside the range where sin / cos need no reduction (identical bits either way)
     bool small = true;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) small = small && (__builtin_fabs(s[2][j]) <= kSmallAngle64);
+    for (int j = 0; j < VEC; ++j) small = small && (__builtin_fabs(L.s[2][j]) <= kSmallAngle64);
     const bool wave_small = __ballot(!small) == 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         double sj[S];
 #pragma unroll
-        for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+        for (int k = 0; k < S; ++k) sj[k] = L.s[k][j];
         bool dn;
-        if (wave_small) CartPole64::step<true>(sj, act[j], dn);
-        else CartPole64::step<false>(sj, act[j], dn);
+        if (wave_small) CartPole64::step<true>(sj, L.act[j], dn);
+        else CartPole64::step<false>(sj, L.act[j], dn);
         float rw = 1.0f;                                                             // :168-183
         if constexpr (!AUTORESET) {
             if (dn) {
-                if (sbd[j] == -1) sbd[j] = 0;
-                else { after += (i0 + j < n) ? 1u : 0u; sbd[j] += 1; rw = 0.0f; }
+                if (L.sbd[j] == -1) L.sbd[j] = 0;
+                else { after += (i0 + j < n) ? 1u : 0u; L.sbd[j] += 1; rw = 0.0f; }
             }
         }
         uint8_t db = dn ? 1 : 0;
         if constexpr (EXTRAS) {
             if (stats) {
-                ep_ret[j] += rw;
-                ep_len[j] += 1;
-                if (a.max_episode_steps > 0 && ep_len[j] >= a.max_episode_steps) db |= 2;      // truncated (extension)
+                L.ep_ret[j] += rw;
+                L.ep_len[j] += 1;
+                if (a.max_episode_steps > 0 && L.ep_len[j] >= a.max_episode_steps) db |= 2;      // truncated (extension)
                 if (db && i0 + j < n) {
-                    a.fin_ret[i0 + j] = ep_ret[j];
-                    a.fin_len[i0 + j] = ep_len[j];
-                    if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
+                    a.fin_ret[i0 + j] = L.ep_ret[j];
+                    a.fin_len[i0 + j] = L.ep_len[j];
+                    if constexpr (AUTORESET) { L.ep_ret[j] = 0.0f; L.ep_len[j] = 0; }
                 }
             }
         }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+        for (int k = 0; k < S; ++k) L.s[k][j] = sj[k];
         reward[j] = rw;
         done[j] = db;
     }
@@ -154,10 +154,51 @@ __global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
     store_row<float, VEC, NT_O>(a.reward, i0, n, full, reward);
     store_row<uint8_t, VEC, NT_O>(a.done, i0, n, full, done);
 #pragma unroll
-    for (int k = 0; k < S; ++k) store_row<double, VEC, NT_SS>(a.state + k * a.stride, i0, n, full, s[k]);
-    if constexpr (!AUTORESET) store_row<int32_t, VEC, NT_SS>(a.sbd, i0, n, full, sbd);
+    for (int k = 0; k < S; ++k) store_row<double, VEC, NT_SS>(a.state + k * a.stride, i0, n, full, L.s[k]);
+    if constexpr (!AUTORESET) store_row<int32_t, VEC, NT_SS>(a.sbd, i0, n, full, L.sbd);
     if constexpr (EXTRAS) {
-        if (stats) { store_row<float, VEC, NT_SS>(a.ep_ret, i0, n, full, ep_ret); store_row<int32_t, VEC, NT_SS>(a.ep_len, i0, n, full, ep_len); }
+        if (stats) { store_row<float, VEC, NT_SS>(a.ep_ret, i0, n, full, L.ep_ret); store_row<int32_t, VEC, NT_SS>(a.ep_len, i0, n, full, L.ep_len); }
+    }
+}
+
+// ONE launch advances every lane by one env-step: a thread owns VEC consecutive lanes.
+template <int VEC, bool AUTORESET, bool EXTRAS, int NT>
+__global__ __launch_bounds__(256) void step_kernel_f64(const StepArgs64 a) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    if (i0 >= a.n) return;
+    const bool full = i0 + VEC <= a.n;
+    bool stats = false;
+    if constexpr (EXTRAS) stats = a.ep_ret != nullptr;
+    Lanes64<VEC> L;
+    load_lanes64<VEC, AUTORESET, EXTRAS, NT>(a, i0, full, stats, L);
+    advance_and_store64<VEC, AUTORESET, EXTRAS, NT>(a, i0, full, stats, tick, L);
+}
+
+// Multi-item form (the float64 kernel has real arithmetic: ~270 binary64 VALU per env-step against 73 B): a thread owns ITEMS
+// lane pairs (pair k at thread index + k * T, coalesced per item), issues the loads of ALL its pairs first, then advances and
+// stores pair after pair — pair k's stores drain under pair k + 1's arithmetic, the shape that works for Acrobot
+// (kernels.hip step_kernel_pipe; every load before the first store, so the one full vmcnt wait sits after pair 0's
+// arithmetic).  Whole batches only (n a multiple of 2 * ITEMS * 256: the launcher falls back to the one-shot kernel
+// otherwise); lean variant.  Same per-lane code and Philox counters: bit-identical.
+template <int ITEMS, bool AUTORESET, int NT>
+__global__ __launch_bounds__(256) void step_kernel_f64_pipe(const StepArgs64 a) {
+    constexpr int VEC = 2;
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Lanes64<VEC> L[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) load_lanes64<VEC, AUTORESET, false, NT>(a, (t + k * T) * VEC, true, false, L[k]);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (k == 0) {   // pair 0's inputs are needed now (their first uses must not be hoisted into the load block)
+#pragma unroll
+            for (int c = 0; c < CartPole64::S; ++c) asm volatile("" : "+v"(L[0].s[c][0]), "+v"(L[0].s[c][1]));
+        }
+        advance_and_store64<VEC, AUTORESET, false, NT>(a, (t + k * T) * VEC, true, false, tick, L[k]);
     }
 }
 
@@ -200,9 +241,36 @@ __global__ __launch_bounds__(256) void export_f64_kernel(const double *__restric
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid64(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
 
-hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, hipStream_t st) {
+// items > 1: the multi-item kernel (lean variant, vec 2, whole batches only)
+static bool f64_pipe_ok(bool extras, const StepArgs64 &a, int vec, int items) {
+    return items > 1 && items <= 4 && !extras && vec == 2 && a.n > 0 && (a.n % (2 * (int64_t)items * 256)) == 0;
+}
+
+hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, int items, hipStream_t st) {
     if (vec != 2) vec = 1;
     if (nt != 12 && nt != 15) nt = 0;
+    if (f64_pipe_ok(extras, a, vec, items)) {
+        const dim3 pgrid((unsigned)(a.n / (2 * (int64_t)items * 256))), pblk(256);
+#define GYMNET_P64(I, NTM)                                                                                     \
+    do {                                                                                                       \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_f64_pipe<I, true, NTM>), pgrid, pblk, 0, st, a);         \
+        else hipLaunchKernelGGL((step_kernel_f64_pipe<I, false, NTM>), pgrid, pblk, 0, st, a);                  \
+    } while (0)
+#define GYMNET_P64_NT(I)                                          \
+    do {                                                          \
+        if (nt == 15) GYMNET_P64(I, 15);                          \
+        else if (nt == 12) GYMNET_P64(I, 12);                     \
+        else GYMNET_P64(I, 0);                                    \
+    } while (0)
+        switch (items) {
+            case 2: GYMNET_P64_NT(2); break;
+            case 3: GYMNET_P64_NT(3); break;
+            default: GYMNET_P64_NT(4); break;
+        }
+#undef GYMNET_P64_NT
+#undef GYMNET_P64
+        return hipGetLastError();
+    }
     const int64_t threads = (a.n + vec - 1) / vec;
     const dim3 grid(grid64(threads > 0 ? threads : 1, 256)), blk(256);
 #define GYMNET_L64(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel_f64<V, AR, EX, NTM>), grid, blk, 0, st, a)
@@ -225,9 +293,12 @@ hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int
     return hipGetLastError();
 }
 
-int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, char *buf, size_t cap) {
+int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, int items, int64_t n, char *buf, size_t cap) {
     if (vec != 2) vec = 1;
     if (nt != 12 && nt != 15) nt = 0;
+    StepArgs64 probe{};
+    probe.n = n;
+    if (f64_pipe_ok(extras, probe, vec, items)) return std::snprintf(buf, cap, "step_kernel_f64_pipe<%d,%s,%d>", items, autoreset ? "true" : "false", nt);
     return std::snprintf(buf, cap, "step_kernel_f64<%d,%s,%s,%d>", vec, autoreset ? "true" : "false", extras ? "true" : "false", nt);
 }
 

@@ -210,7 +210,7 @@ def test_f64_at_2p20_lanes_matches_the_twin_and_the_float32_engine_statistically
     import torch
     n, steps, ring = 1 << 20, 24, 8
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64) as env:
-        assert env.KernelName() == "step_kernel_f64<2,true,false,15>"
+        assert env.KernelName() == "step_kernel_f64_pipe<2,true,15>"        # the default at this size (one lock-step generation otherwise)
         acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for t in range(ring):
@@ -286,3 +286,37 @@ def test_f64_steps_beyond_done_reward_stream_and_counter(gpu_pkg, golden):
             assert np.array_equal(a.GetStepsBeyondDone(), sbd)
         assert oa.Done.all() and (oa.Reward == 0).all()
         assert a.Counters()["stepped_after_done"] == after > n
+
+
+def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
+    """step_kernel_f64_pipe<ITEMS> (launch policy sequential_lanes = 2..4: a thread owns ITEMS lane pairs, all loads first, then
+    advance / store pair after pair) runs the same per-lane code with the same Philox counters as the one-shot kernel: states,
+    rewards, done flags and reset draws must agree bit for bit, with and without auto-reset; batches that are not whole multiples
+    of 2 * ITEMS * 256 lanes, and the bookkeeping variant, fall back to the one-shot kernel."""
+    import torch
+    n, ring, steps = 2 * 256 * 12 * 5, 6, 37
+    acts = torch.randint(0, 2, (ring, n), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    out = {}
+    for auto in (True, False):
+        for items in (1, 2, 3, 4):
+            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, launch_policy={"sequential_lanes": items}) as env:
+                want = f"step_kernel_f64<2,{str(auto).lower()},false,15>" if items == 1 else f"step_kernel_f64_pipe<{items},{str(auto).lower()},15>"
+                assert env.KernelName() == want, env.KernelName()
+                env.ResetDevice()
+                env.RolloutDevice(acts, steps, n, ring)
+                env.Sync()
+                r = env.Read()
+                out[(auto, items)] = (env.GetState(), r.Reward, r.Done, env.GetStepsBeyondDone() if not auto else None, env.Counters()["stepped_after_done"])
+        ref = out[(auto, 1)]
+        assert ref[2].any()
+        for items in (2, 3, 4):
+            got = out[(auto, items)]
+            assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(ref[:3], got[:3])), (auto, items)
+            assert (ref[3] is None or np.array_equal(ref[3], got[3])) and ref[4] == got[4]
+    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64, launch_policy={"sequential_lanes": 4}) as env:
+        assert env.KernelName() == "step_kernel_f64<2,true,false,15>"                 # not whole 2 * 4 * 256-lane groups: one-shot kernel
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True, launch_policy={"sequential_lanes": 2}) as env:
+        assert env.KernelName() == "step_kernel_f64<2,true,true,15>"                  # bookkeeping: one-shot kernel
+        with pytest.raises(ValueError):
+            env.SetLaunchPolicy(sequential_lanes=5)
