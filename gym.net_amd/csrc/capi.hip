@@ -988,7 +988,11 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
     if (vec) *vec = h->lcfg.vec;
     if (block) *block = h->lcfg.block;
     if (nt) *nt = h->lcfg.nt;
-    if (sequential_lanes) *sequential_lanes = (h->cfg.env_id == GYMNET_ENV_ACROBOT && h->lcfg.items > 1 && h->lcfg.vec == 1 && !h->extras) ? h->lcfg.items : 1;
+    if (sequential_lanes) {
+        const int it = h->lcfg.items;
+        if (h->f64) *sequential_lanes = (it > 1 && it <= 4 && !h->extras && h->lcfg.vec == 2 && h->n % (2 * (int64_t)it * 256) == 0) ? it : 1;   // lane PAIRS per thread
+        else *sequential_lanes = (h->cfg.env_id == GYMNET_ENV_ACROBOT && it > 1 && h->lcfg.vec == 1 && !h->extras) ? it : 1;
+    }
     return GYMNET_OK;
     });
 }
