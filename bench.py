@@ -876,6 +876,22 @@ def main():
         except Exception as e:
             big = {"error": repr(e)[:200]}
 
+    def timed_rollouts(e, acts, ring_len, launches=1024, reps=3):
+        """(HIP-event us per launch, wall seconds per region): median of `reps` back-to-back regions of `launches` one-launch steps
+        (the first region after a short warm-up still runs ~5 % slow: clocks and caches)."""
+        evs, walls = [], []
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            q0.record(stream)
+            e.RolloutDevice(acts.data_ptr(), launches, n, ring_len)
+            q1.record(stream)
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)
+            evs.append(q0.elapsed_time(q1) * 1e3 / launches)
+        return median(evs), median(walls)
+
     # Secondary figures, NOT the headline: BASELINE.json's other single-GPU configs (3: Pendulum-v1, 4: Acrobot-v1 at 2^20 lanes) and
     # MountainCar, each through its own bench-shaped rollout — HIP events over 1024 back-to-back launches — so that the driver's
     # record carries their roofline fractions too (they are parity-test cases; their full lines come from `--env E`).
@@ -891,20 +907,14 @@ def main():
                         e3.SampleActionsDevice(a3[t].data_ptr(), seed=seed + 1, tick=t)
                     e3.ResetDevice()
                     e3.RolloutDevice(a3.data_ptr(), 128, n, r3)
-                    torch.cuda.synchronize(dev)
-                    o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    o0.record(stream)
-                    e3.RolloutDevice(a3.data_ptr(), 1024, n, r3)
-                    o1.record(stream)
-                    torch.cuda.synchronize(dev)
-                    us = o0.elapsed_time(o1) * 1e3 / 1024
+                    us, _ = timed_rollouts(e3, a3, r3)
                     gb = e3.TrafficBytesPerStep * n / (us * 1e-6) / 1e9              # the bytes the kernel MOVES
                     gba = e3.AlgorithmicBytesPerStep * n / (us * 1e-6) / 1e9
                     other[name] = {"kernel": e3.KernelName(), "launch_us": us, "env_steps_per_sec": n / (us * 1e-6),
                                    "algorithmic_bytes_per_step": e3.AlgorithmicBytesPerStep, "moved_bytes_per_step": e3.TrafficBytesPerStep,
                                    "achieved_GBps": gb, "frac_of_peak": gb / HBM_PEAK_GBPS,
                                    "algorithmic_GBps": gba, "frac_of_peak_algorithmic_bytes": gba / HBM_PEAK_GBPS,
-                                   "clock": "HIP events over 1024 back-to-back launches"}
+                                   "clock": "HIP events over 1024 back-to-back launches, median of 3 such regions"}
                     del a3
             except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
                 other[name] = {"error": repr(e)[:200]}
@@ -921,15 +931,7 @@ def main():
                     e4.SampleActionsDevice(a4[t].data_ptr(), seed=seed + 1, tick=t)
                 e4.ResetDevice()
                 e4.RolloutDevice(a4.data_ptr(), 128, n, r4)
-                torch.cuda.synchronize(dev)
-                q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0 = time.perf_counter()
-                q0.record(stream)
-                e4.RolloutDevice(a4.data_ptr(), 1024, n, r4)
-                q1.record(stream)
-                torch.cuda.synchronize(dev)
-                w4 = time.perf_counter() - t0
-                us = q0.elapsed_time(q1) * 1e3 / 1024
+                us, w4 = timed_rollouts(e4, a4, r4)
                 f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
                            "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
                            "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
