@@ -738,6 +738,78 @@ def main():
         except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
             fused = {"error": repr(e)[:300]}
 
+    # (The per-configuration figures below run BEFORE the sections that allocate and free gigabytes — the 2 GiB copy probe, the
+    # 2^27-lane batch: measured after them, the very same kernels ran 4-8 % slower (Acrobot 12.4-13.0 vs 11.5-11.9 us, the float64
+    # kernel 14.3-14.8 vs 13.1 us standalone), a placement effect of buffers allocated out of a fragmented pool.)
+    def timed_rollouts(e, acts, ring_len, launches=1024, reps=5):
+        """(HIP-event us per launch, wall seconds per region): 2048 untimed launches, then the median of `reps` back-to-back regions
+        of `launches` one-launch steps.  The arithmetic-heavy kernels (Acrobot, the float64 CartPole) keep speeding up over the
+        first ~50 ms of sustained launches — 14.1, 12.3, 12.2, 12.1, 11.9 us in consecutive 1024-launch regions
+        (tools/acrobot_alloc_probe.py) — so a figure taken right after a 128-launch warm-up reads 5-8 % slow against the
+        headline protocol's (`--env E`: 512 warm-up launches, median of >= 50 ms of regions)."""
+        e.RolloutDevice(acts.data_ptr(), 2048, n, ring_len)
+        evs, walls = [], []
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            q0.record(stream)
+            e.RolloutDevice(acts.data_ptr(), launches, n, ring_len)
+            q1.record(stream)
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)
+            evs.append(q0.elapsed_time(q1) * 1e3 / launches)
+        return median(evs), median(walls)
+
+    # Secondary figures, NOT the headline: BASELINE.json's other single-GPU configs (3: Pendulum-v1, 4: Acrobot-v1 at 2^20 lanes) and
+    # MountainCar, each through its own bench-shaped rollout — HIP events over 1024 back-to-back launches — so that the driver's
+    # record carries their roofline fractions too (they are parity-test cases; their full lines come from `--env E`).
+    other = None
+    if extras and args.env == "CartPole-v1" and n == (1 << 20):
+        other = {}
+        for name in ("Pendulum-v1", "Acrobot-v1", "MountainCar-v0"):
+            try:
+                with pkg.VectorEnv(name, n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream) as e3:
+                    r3 = 32
+                    a3 = torch.empty((r3, n), dtype=torch.float32 if name == "Pendulum-v1" else torch.int32, device=dev)
+                    for t in range(r3):
+                        e3.SampleActionsDevice(a3[t].data_ptr(), seed=seed + 1, tick=t)
+                    e3.ResetDevice()
+                    e3.RolloutDevice(a3.data_ptr(), 128, n, r3)
+                    us, _ = timed_rollouts(e3, a3, r3)
+                    gb = e3.TrafficBytesPerStep * n / (us * 1e-6) / 1e9              # the bytes the kernel MOVES (ADVICE r3)
+                    gba = e3.AlgorithmicBytesPerStep * n / (us * 1e-6) / 1e9
+                    other[name] = {"kernel": e3.KernelName(), "launch_us": us, "env_steps_per_sec": n / (us * 1e-6),
+                                   "algorithmic_bytes_per_step": e3.AlgorithmicBytesPerStep, "moved_bytes_per_step": e3.TrafficBytesPerStep,
+                                   "achieved_GBps": gb, "frac_of_peak": gb / HBM_PEAK_GBPS,
+                                   "algorithmic_GBps": gba, "frac_of_peak_algorithmic_bytes": gba / HBM_PEAK_GBPS,
+                                   "clock": "HIP events over 1024 back-to-back launches, median of 5 such regions after 2048 warm-up launches"}
+                    del a3
+            except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
+                other[name] = {"error": repr(e)[:200]}
+
+    # Secondary figure, NEVER `value`: CartPole at the same batch in the reference's own float64 arithmetic (GYMNET_FLAG_F64,
+    # cartpole64.hpp) — 73 B per env-step: 32 + 4 read, 32 + 4 + 1 written — with its own 73 B roofline fraction.
+    f64_fig = None
+    if extras and args.env == "CartPole-v1":
+        try:
+            with pkg.VectorEnv("CartPole-v1", n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream, dtype="float64") as e4:
+                r4 = 32
+                a4 = torch.empty((r4, n), dtype=torch.int32, device=dev)
+                for t in range(r4):
+                    e4.SampleActionsDevice(a4[t].data_ptr(), seed=seed + 1, tick=t)
+                e4.ResetDevice()
+                e4.RolloutDevice(a4.data_ptr(), 128, n, r4)
+                us, w4 = timed_rollouts(e4, a4, r4)
+                f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
+                           "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
+                           "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
+                           "frac_of_peak_by_events": 73 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                           "note": "reference-exact float64 mode; reported beside, never as, `value`"}
+                del a4
+        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
+            f64_fig = {"error": repr(e)[:300]}
+
     # Secondary figure, NEVER `value`: the NDArray-shaped host boundary a C# VectorEnv.Step(NDArray) reaches — gymnet_vecenv_step
     # with caller-owned host buffers, PCIe both ways inside the call (VecEnvWrapper.cs:22-24, Step.cs:8-10): (a) ordinary
     # pageable caller memory, (b) the library's pinned, device-mapped buffers (gymnet_vecenv_host_buffers: zero staging).
@@ -875,71 +947,6 @@ def main():
                 del a2
         except Exception as e:
             big = {"error": repr(e)[:200]}
-
-    def timed_rollouts(e, acts, ring_len, launches=1024, reps=3):
-        """(HIP-event us per launch, wall seconds per region): median of `reps` back-to-back regions of `launches` one-launch steps
-        (the first region after a short warm-up still runs ~5 % slow: clocks and caches)."""
-        evs, walls = [], []
-        for _ in range(reps):
-            torch.cuda.synchronize(dev)
-            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            q0.record(stream)
-            e.RolloutDevice(acts.data_ptr(), launches, n, ring_len)
-            q1.record(stream)
-            torch.cuda.synchronize(dev)
-            walls.append(time.perf_counter() - t0)
-            evs.append(q0.elapsed_time(q1) * 1e3 / launches)
-        return median(evs), median(walls)
-
-    # Secondary figures, NOT the headline: BASELINE.json's other single-GPU configs (3: Pendulum-v1, 4: Acrobot-v1 at 2^20 lanes) and
-    # MountainCar, each through its own bench-shaped rollout — HIP events over 1024 back-to-back launches — so that the driver's
-    # record carries their roofline fractions too (they are parity-test cases; their full lines come from `--env E`).
-    other = None
-    if extras and args.env == "CartPole-v1" and n == (1 << 20):
-        other = {}
-        for name in ("Pendulum-v1", "Acrobot-v1", "MountainCar-v0"):
-            try:
-                with pkg.VectorEnv(name, n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream) as e3:
-                    r3 = 32
-                    a3 = torch.empty((r3, n), dtype=torch.float32 if name == "Pendulum-v1" else torch.int32, device=dev)
-                    for t in range(r3):
-                        e3.SampleActionsDevice(a3[t].data_ptr(), seed=seed + 1, tick=t)
-                    e3.ResetDevice()
-                    e3.RolloutDevice(a3.data_ptr(), 128, n, r3)
-                    us, _ = timed_rollouts(e3, a3, r3)
-                    gb = e3.TrafficBytesPerStep * n / (us * 1e-6) / 1e9              # the bytes the kernel MOVES (ADVICE r3)
-                    gba = e3.AlgorithmicBytesPerStep * n / (us * 1e-6) / 1e9
-                    other[name] = {"kernel": e3.KernelName(), "launch_us": us, "env_steps_per_sec": n / (us * 1e-6),
-                                   "algorithmic_bytes_per_step": e3.AlgorithmicBytesPerStep, "moved_bytes_per_step": e3.TrafficBytesPerStep,
-                                   "achieved_GBps": gb, "frac_of_peak": gb / HBM_PEAK_GBPS,
-                                   "algorithmic_GBps": gba, "frac_of_peak_algorithmic_bytes": gba / HBM_PEAK_GBPS,
-                                   "clock": "HIP events over 1024 back-to-back launches, median of 3 such regions"}
-                    del a3
-            except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
-                other[name] = {"error": repr(e)[:200]}
-
-    # Secondary figure, NEVER `value`: CartPole at the same batch in the reference's own float64 arithmetic (GYMNET_FLAG_F64,
-    # cartpole64.hpp) — 73 B per env-step: 32 + 4 read, 32 + 4 + 1 written — with its own 73 B roofline fraction.
-    f64_fig = None
-    if extras and args.env == "CartPole-v1":
-        try:
-            with pkg.VectorEnv("CartPole-v1", n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream, dtype="float64") as e4:
-                r4 = 32
-                a4 = torch.empty((r4, n), dtype=torch.int32, device=dev)
-                for t in range(r4):
-                    e4.SampleActionsDevice(a4[t].data_ptr(), seed=seed + 1, tick=t)
-                e4.ResetDevice()
-                e4.RolloutDevice(a4.data_ptr(), 128, n, r4)
-                us, w4 = timed_rollouts(e4, a4, r4)
-                f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
-                           "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
-                           "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
-                           "frac_of_peak_by_events": 73 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                           "note": "reference-exact float64 mode; reported beside, never as, `value`"}
-                del a4
-        except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
-            f64_fig = {"error": repr(e)[:300]}
 
     if rank == 0:
         if f64_fig:
