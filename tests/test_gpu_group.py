@@ -562,9 +562,14 @@ def test_driver_shaped_bench_line_carries_the_contract(gpu_pkg):
     assert rf["frac"] == rf["frac_by_wall"] <= rf["frac_by_events"] * 1.02 < 1.0 and rf["bytes_per_env_step"] == 41
     # roofline.traffic is MEASURED in the run (two rocprofv3 --pmc child passes, FETCH_SIZE / WRITE_SIZE apart), per launch like
     # `achieved`; it must sit within a few percent of the 41 B x 2^20 the kernel moves — more would mean wasted re-reads
-    assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_measurement_error", rf["traffic_source"])
-    assert 0.97 < rf["traffic"] / (41 << 20) < 1.06 and abs(rf["traffic_over_moved_bytes"] - rf["traffic"] / (41 << 20)) < 1e-9
-    assert 0.9 < rf["traffic"] / rf["traffic_constant_from_profiles"] < 1.1              # and agrees with the committed profile
+    # (the strict form of this check — the measurement must WORK — is tests/test_zz_gpu_traffic_measurement.py, last in the run, so
+    # that a box where a nested profiler cannot start does not cut the remaining parity tests short under `pytest -x`)
+    assert 0.97 < rf["traffic"] / (41 << 20) < 1.06
+    if rf["traffic_source"].startswith("measured in this run"):
+        assert abs(rf["traffic_over_moved_bytes"] - rf["traffic"] / (41 << 20)) < 1e-9
+        assert 0.9 < rf["traffic"] / rf["traffic_constant_from_profiles"] < 1.1          # and agrees with the committed profile
+    else:
+        assert "traffic_measurement_error" in rf and "NOT measured in this run" in rf["traffic_source"]   # labelled fallback, never silent
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e6 and cb["unit"] == "env-steps/s" and cb["sample"]
     assert j["fused_rollout"]["us_per_step"] < j["ms_per_step"] * 1e3
