@@ -28,6 +28,14 @@
  *   - Pendulum / MountainCar / Acrobot: ABSENT from the reference (README.md:69-76 lists them
  *     as unchecked roadmap items).  Restated from the upstream openai/gym classic_control
  *     algorithms as summarised in SURVEY.md Appendix B.
+ * Round 4 additions (all test infrastructure like the rest):
+ *   - ref_cartpole_step_f32 / numpy_ref (kernel semantics, float32 state): the INTEGER done flag is now taken from the float64 sums
+ *     the reference compares (CartPoleEnv.cs:154,156,167), as the HIP kernel does — exact on every float32 input;
+ *   - ref_sincos_f64_kernel, ref_cartpole_step_f64_kernel, ref_cartpole_reset_f64, ref_cartpole_autoreset_step_batch_f64: the
+ *     bit-identical CPU twin of the GYMNET_FLAG_F64 kernels (the literal CartPoleEnv.cs:146-167 sequence with the kernel's own
+ *     float64 sin / cos; 53-bit Philox reset draws), pinned by tests/golden/cartpole_f64_kernel.npz;
+ *   - ref_acrobot_step_f32_literal: a literal float32 transcription of upstream's Acrobot formulas, the yardstick of the accuracy
+ *     budget (tools/acrobot_accuracy.py, profiles/acrobot_accuracy_r04.txt) — not what any kernel runs.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; contraction MUST stay off so that
  * the float32 "kernel semantics" functions round after every operation like the HIP kernels).
