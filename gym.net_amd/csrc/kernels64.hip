@@ -2,7 +2,7 @@
 //
 // Same design rules as kernels.hip (one env per lane, SoA rows, 16-byte accesses where the row allows, static block -> lane map,
 // one ballot + one atomic per wave for the step-after-done counter), for the path whose ARITHMETIC is the reference's own
-// (cartpole64.hpp): 73 B per env-step against ~45 binary64 operations, three of them IEEE divisions.  A thread owns VEC = 2
+// (cartpole64.hpp): 73 B per env-step against ~45 binary64 operations, four of them IEEE divisions (three by the constant total_mass).  A thread owns VEC = 2
 // consecutive lanes: one dwordx4 per state row and direction, one dwordx2 for the actions and the rewards, one 16-bit store
 // for the done flags.  Compiled with -ffp-contract=off.
 #include "kernels.hpp"
