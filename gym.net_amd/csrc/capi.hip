@@ -1001,7 +1001,7 @@ int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity) {
     return guarded([&]() -> int {
     if (!h || !buf || capacity < 1) return fail(h, GYMNET_ERR_INVALID_ARG, "null handle / buffer");
     if (h->f64) { describe_step_kernel_f64(h->autoreset, h->extras, h->lcfg.vec, h->lcfg.nt, h->lcfg.items, h->n, buf, (size_t)capacity); return GYMNET_OK; }
-    if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, buf, (size_t)capacity) < 0)
+    if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, h->n, buf, (size_t)capacity) < 0)
         return fail(h, GYMNET_ERR_INVALID_ARG, "unknown env");
     return GYMNET_OK;
     });

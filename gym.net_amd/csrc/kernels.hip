@@ -227,7 +227,7 @@ __device__ __forceinline__ bool wave_angles_small(const float (&s)[Env::S][VEC])
 // One env-step of ALL VEC sub-lanes of a thread.  Generic: sub-lane after sub-lane.  Envs that provide a two-lane packed
 // form (Acrobot: both envs of a thread ride the v_pk_*_f32 instructions, envs.hpp) take it when VEC == 2; per element the
 // arithmetic is the same IEEE sequence, so the results are bit-identical to the sub-lane loop.
-template <class Env, int VEC, bool AUTORESET, bool GUARD>
+template <class Env, int VEC, bool AUTORESET, bool GUARD, bool PACK = true>
 __device__ __forceinline__ void advance_all(float (&s)[Env::S][VEC], typename Env::Action (&act)[VEC], int32_t (&sbd)[VEC],
                                             float (&rw)[VEC], bool (&dn)[VEC], bool (&after)[VEC], float (&o)[Env::O][VEC],
                                             int64_t i0, int64_t n) {
@@ -237,7 +237,7 @@ __device__ __forceinline__ void advance_all(float (&s)[Env::S][VEC], typename En
 #else
     constexpr bool kPack = false;
 #endif
-    if constexpr (Env::PACKED2 && VEC == 2 && kPack) {
+    if constexpr (Env::PACKED2 && VEC == 2 && kPack && PACK) {
         Env::step_observe_x2(s, act, rw, dn, o);
     } else {
         auto all_sublanes = [&](auto small_tag) {
@@ -410,7 +410,7 @@ __device__ __forceinline__ void load_inputs(const StepArgs &a, const int64_t i0,
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, in.sbd);
 }
 
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD, int RESETF = 0>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD, int RESETF = 0, bool PACK = true>
 __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64_t i0, const uint64_t tick, LaneInputs<Env, VEC> &in,
                                                   ResetScratch<Env> *sc = nullptr) {
     constexpr int S = Env::S, O = Env::O;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void advance_and_store(const StepArgs &a, const int64
 
     float rwv[VEC];
     bool dnv[VEC];
-    advance_all<Env, VEC, AUTORESET, GUARD>(s, act, sbd, rwv, dnv, after, o, i0, n);
+    advance_all<Env, VEC, AUTORESET, GUARD, PACK>(s, act, sbd, rwv, dnv, after, o, i0, n);
 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -634,6 +634,30 @@ __global__ __launch_bounds__(256) void step_kernel_pipe(const StepArgs a) {
             }
         }
         if (i + k * T < a.n) store_lane<Env, AUTORESET, NT>(a, i + k * T, out);
+    }
+}
+
+// Round 4 probe (launch policy vec = 2 together with sequential_lanes = k): the multi-lane kernel over lane PAIRS — a thread owns
+// ITEMS pairs of consecutive lanes (pair k at thread index + k * T), 8-byte accesses on every stream, scalar arithmetic lane after
+// lane (NOT the packed-FP32 form: PACK = false), all loads first, then advance / store pair after pair.  The shape that took the
+// float64 CartPole kernel from 14.4 to 13.1 us.  Whole batches only (n a multiple of 2 * ITEMS * 256); lean variant.  Same
+// per-lane code and Philox counters as every other form: bit-identical.  Measured: profiles/acrobot_forms_r04.txt.
+template <class Env, int ITEMS, bool AUTORESET, int NT>
+__global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgs a) {
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneInputs<Env, 2> in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) load_inputs<Env, 2, AUTORESET, NT, false>(a, (t + k * T) * 2, in[k]);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (k == 0) {   // pair 0's inputs are needed now (their first uses must not be hoisted into the load block)
+#pragma unroll
+            for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]), "+v"(in[0].s[c][1]));
+        }
+        advance_and_store<Env, 2, AUTORESET, false, NT, false, 0, false>(a, (t + k * T) * 2, tick, in[k]);
     }
 }
 
@@ -1196,7 +1220,8 @@ static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((i
 // not from a copy of this policy).
 struct StepVariant {
     int lds_tiles;      // > 1: step_kernel_lds<Env, lds_tiles, AUTORESET, 15> (producer / consumer form of the multi-lane kernel)
-    int pipe_items;     // > 1: step_kernel_pipe<Env, pipe_items, AUTORESET, 15>; else step_kernel
+    int pipe_items;     // > 1: step_kernel_pipe<Env, pipe_items, AUTORESET, 15> (or step_kernel_pipe2 with pipe_pairs); else step_kernel
+    bool pipe_pairs = false;   // the multi-lane kernel over lane PAIRS (step_kernel_pipe2)
     int vec, nt;        // step_kernel<Env, vec, AUTORESET, EXTRAS, nt, resetf>
     int resetf;
 };
@@ -1209,12 +1234,18 @@ static LaunchCfg normalized(LaunchCfg cfg) {
 }
 
 template <class Env>
-static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg) {
-    StepVariant v{1, 1, 1, cfg.nt, 0};
+static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg, int64_t n) {
+    StepVariant v{};
+    v.lds_tiles = 1; v.pipe_items = 1; v.vec = 1; v.nt = cfg.nt; v.resetf = 0;
     if constexpr (Env::PIPELINED) {        // multi-lane kernel, cfg.items lanes per thread (2..5)
         if (cfg.items > 1 && cfg.items <= 5 && !extras && cfg.vec == 1) {
             v.nt = 15;
             if (cfg.lds_pipe) v.lds_tiles = cfg.items; else v.pipe_items = cfg.items;
+            return v;
+        }
+        // lane pairs (probe form): 2..4 pairs per thread, whole batches only — otherwise the ordinary forms below
+        if (cfg.items > 1 && cfg.items <= 4 && !extras && cfg.vec == 2 && !cfg.lds_pipe && n > 0 && n % (2 * (int64_t)cfg.items * 256) == 0) {
+            v.nt = 15; v.vec = 2; v.pipe_items = cfg.items; v.pipe_pairs = true;
             return v;
         }
     }
@@ -1228,8 +1259,22 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
 
 template <class Env>
 static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st) {
-    const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg);
+    const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg, a.n);
     if constexpr (Env::PIPELINED) {
+        if (v.pipe_pairs) {
+            const dim3 qgrid((unsigned)(a.n / (2 * (int64_t)v.pipe_items * 256))), qblk(256);
+#define GYMNET_PIPE2(I)                                                                                                 \
+    case I:                                                                                                             \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a);                 \
+        else hipLaunchKernelGGL((step_kernel_pipe2<Env, I, false, 15>), qgrid, qblk, 0, st, a);                          \
+        break;
+            switch (v.pipe_items) {
+                GYMNET_PIPE2(2) GYMNET_PIPE2(3) GYMNET_PIPE2(4)
+                default: return hipErrorInvalidValue;
+            }
+#undef GYMNET_PIPE2
+            return hipGetLastError();
+        }
         if (v.lds_tiles > 1) {
             const int64_t tiles = a.n / kLdsTileMax;
             const dim3 lgrid(grid_for(tiles, v.lds_tiles)), lblk(kLdsTileMax + 64);
@@ -1309,18 +1354,19 @@ hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &
     }
 }
 
-int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, char *buf, size_t cap) {
+int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap) {
     cfg = normalized(cfg);
     StepVariant v;
     const char *env;
     switch (env_id) {
-        case 0: v = resolve_variant<CartPole>(autoreset, extras, cfg); env = "CartPole"; break;
-        case 1: v = resolve_variant<Pendulum>(autoreset, extras, cfg); env = "Pendulum"; break;
-        case 2: v = resolve_variant<MountainCar>(autoreset, extras, cfg); env = "MountainCar"; break;
-        case 3: v = resolve_variant<Acrobot>(autoreset, extras, cfg); env = "Acrobot"; break;
+        case 0: v = resolve_variant<CartPole>(autoreset, extras, cfg, n); env = "CartPole"; break;
+        case 1: v = resolve_variant<Pendulum>(autoreset, extras, cfg, n); env = "Pendulum"; break;
+        case 2: v = resolve_variant<MountainCar>(autoreset, extras, cfg, n); env = "MountainCar"; break;
+        case 3: v = resolve_variant<Acrobot>(autoreset, extras, cfg, n); env = "Acrobot"; break;
         default: return -1;
     }
     const char *ar = autoreset ? "true" : "false";
+    if (v.pipe_pairs) return std::snprintf(buf, cap, "step_kernel_pipe2<%s,%d,%s,15>", env, v.pipe_items, ar);
     if (v.lds_tiles > 1) return std::snprintf(buf, cap, "step_kernel_lds<%s,%d,%s,15>", env, v.lds_tiles, ar);
     if (v.pipe_items > 1) return std::snprintf(buf, cap, "step_kernel_pipe<%s,%d,%s,15>", env, v.pipe_items, ar);
     return std::snprintf(buf, cap, "step_kernel<%s,%d,%s,%s,%d,%d>", env, v.vec, ar, extras ? "true" : "false", v.nt, v.resetf);

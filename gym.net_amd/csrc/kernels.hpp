@@ -57,8 +57,8 @@ struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1;
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);
 
 // The template instantiation launch_step would run for this configuration, as text ("step_kernel<CartPole,4,true,false,15,1>");
-// returns the length, or < 0 for an unknown env.
-int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, char *buf, size_t cap);
+// returns the length, or < 0 for an unknown env.  n: the batch size (one form needs whole 2 * items * 256-lane groups).
+int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap);
 
 // ---- GYMNET_FLAG_F64: CartPole in the reference's own binary64 arithmetic (cartpole64.hpp, kernels64.hip) ------------------
 // 73 B per env-step: 32 B state read + 4 B action + 32 B state written (the observation IS the state) + 4 B reward + 1 B done.

@@ -376,3 +376,32 @@ def test_set_state_of_get_state_leaves_the_observation_unchanged(gpu_pkg, name):
         env.SetState(env.GetState())
         after = env.Read().Observation
         assert np.array_equal(before, after)
+
+
+def test_acrobot_lane_pair_multi_lane_kernel_is_bit_identical(gpu_pkg):
+    """step_kernel_pipe2 (launch policy vec = 2 with sequential_lanes = 2..4; round 4 probe): ITEMS lane PAIRS per thread, 8-byte
+    accesses, scalar arithmetic lane after lane, all loads first.  Same per-lane code and Philox counters as the one-shot kernel:
+    bit-identical states / observations / rewards / done flags with and without auto-reset; batches that are not whole
+    2 * ITEMS * 256-lane groups fall back to the packed two-lane one-shot kernel."""
+    import torch
+    n, ring = 2 * 256 * 12 * 3, 6
+    rng = np.random.default_rng(4)
+    s0 = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n), rng.uniform(-12, 12, n), rng.uniform(-28, 28, n)]).astype(np.float32)
+    acts = torch.randint(0, 3, (ring, n), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    res = {}
+    for auto in (True, False):
+        for vec, items in ((1, 1), (2, 2), (2, 3), (2, 4)):
+            with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, launch_policy={"vec": vec, "sequential_lanes": items}) as env:
+                want = f"step_kernel<Acrobot,1,{str(auto).lower()},false,15,0>" if vec == 1 else f"step_kernel_pipe2<Acrobot,{items},{str(auto).lower()},15>"
+                assert env.KernelName() == want, env.KernelName()
+                env.ResetDevice(); env.SetState(s0)
+                env.RolloutDevice(acts, 25, n, ring)
+                env.Sync()
+                r = env.Read()
+                res[(auto, vec, items)] = (env.GetState(), r.Observation, r.Reward, r.Done)
+        for key in ((auto, 2, 2), (auto, 2, 3), (auto, 2, 4)):
+            assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(res[(auto, 1, 1)], res[key])), key
+        assert res[(auto, 1, 1)][3].any()
+    with gpu_pkg.VectorEnv("Acrobot-v1", n + 2, seed=SEED, auto_reset=True, launch_policy={"vec": 2, "sequential_lanes": 4}) as env:
+        assert env.KernelName() == "step_kernel<Acrobot,2,true,false,15,0>"
