@@ -955,6 +955,10 @@ def main():
             out["other_configs_2p20"] = other
         out["roofline"]["isolated_launch_us_median"] = single_us
         out["roofline"]["measured_copy_GBps"] = copy_bw
+        if copy_bw and copy_bw.get("32MiB"):
+            # the fraction of the MEASURED attainable rate beside the fraction of the 8 TB/s spec peak — a plain
+            # device-to-device copy of a working set of the same (Infinity-Cache-resident) size on this very box
+            out["roofline"]["frac_of_measured_copy_32MiB"] = out["roofline"]["achieved"] / copy_bw["32MiB"]
         if big:
             out["hbm_resident_2p27"] = big
         if fused:
