@@ -594,6 +594,10 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 31)
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "num_envs %lld out of range [1, 2^31]", (long long)cfg->num_envs);
     if (cfg->lane_offset < 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "lane_offset < 0");
+    constexpr uint32_t kKnownFlags = GYMNET_FLAG_AUTORESET | GYMNET_FLAG_VALIDATE_ACTIONS | GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS |
+                                     GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER | GYMNET_FLAG_F64 | GYMNET_FLAG_COMPACT_RECORDS_ONLY;
+    if (cfg->flags & ~kKnownFlags)      // a flag from a newer header must not be silently ignored by an older library
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "unknown flag bits 0x%x (this library is ABI %d)", cfg->flags & ~kKnownFlags, GYMNET_ABI_VERSION);
     if (cfg->max_episode_steps < 0 || (cfg->max_episode_steps > 0 && !(cfg->flags & GYMNET_FLAG_EPISODE_STATS)))
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "max_episode_steps needs GYMNET_FLAG_EPISODE_STATS");
     if ((cfg->flags & GYMNET_FLAG_FINAL_OBS) && !(cfg->flags & GYMNET_FLAG_AUTORESET))

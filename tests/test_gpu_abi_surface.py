@@ -314,6 +314,8 @@ def test_abi4_entry_points_reject_bad_arguments_without_side_effects(gpu_pkg):
     assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG and b"DONE_LIST" in lib.gymnet_last_error()
     cfg.flags, cfg.env_id = capi.FLAG_F64, 3
     assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_UNSUPPORTED
+    cfg.flags, cfg.env_id = capi.FLAG_AUTORESET | 0x4000, 0
+    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG and b"unknown flag bits 0x4000" in lib.gymnet_last_error()
     with gpu_pkg.VectorEnv("CartPole-v1", 64, seed=1, dtype=np.float64) as e64:
         v = e64.DeviceView()
         assert v.state_dtype == capi.DTYPE_F64 and v.d_state == v.d_obs and v.d_state and not v.d_obs_alt and v.obs_aliases_state == 1
