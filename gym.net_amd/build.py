@@ -1,6 +1,7 @@
 """Builds gym.net_amd/lib/libgymnet_amd.so: the HIP kernels + the C ABI, for gfx950 only.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared csrc/*.hip -ldl -o lib/libgymnet_amd.so
+(done as one `hipcc -c` per .hip file in parallel plus one link: same flags, same result, about a third less wall time)
 
 -ffp-contract=off is part of the numerical contract (see csrc/envs.hpp): every float32 operation
 rounds on its own, in the order written.  hipcc cross-compiles without a GPU present.
@@ -46,10 +47,24 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LIBS + ["-o", OUT + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    # one hipcc -c per translation unit, side by side (kernels.hip alone is most of the build), then one link
+    import concurrent.futures
+    import tempfile
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="gymnet_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc()] + compile_flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + LIBS + ["-o", OUT + ".tmp"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (link) failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
     os.replace(OUT + ".tmp", OUT)
     if verbose:
         print("built", OUT)
