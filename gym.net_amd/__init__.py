@@ -7,8 +7,8 @@ Step interface.  The directory name contains a dot, so it is loaded by path
 (`__graft_entry__.load_package()` registers it as module `gymnet_amd`).
 """
 from . import _capi
-from ._capi import (ENV_IDS, FLAG_AUTORESET, FLAG_DONE_LIST, FLAG_DOUBLE_BUFFER, FLAG_EPISODE_STATS, FLAG_FINAL_OBS,
-                    FLAG_VALIDATE_ACTIONS, LIB_PATH, device_count, env_describe, load_library)
+from ._capi import (ENV_IDS, FLAG_AUTORESET, FLAG_COMPACT_RECORDS_ONLY, FLAG_DONE_LIST, FLAG_DOUBLE_BUFFER, FLAG_EPISODE_STATS, FLAG_F64,
+                    FLAG_FINAL_OBS, FLAG_VALIDATE_ACTIONS, LIB_PATH, device_count, env_describe, load_library)
 from .errors import (AlreadySteppingError, GymNetError, InvalidActionError, NoDeviceError,
                      NotSteppingError)
 from .sharding import ShardPlan, ShardedVectorEnv
