@@ -801,7 +801,19 @@ def main():
                 e4.ResetDevice()
                 e4.RolloutDevice(a4.data_ptr(), 128, n, r4)
                 us, w4 = timed_rollouts(e4, a4, r4)
+                fsteps4 = 1024
+                e4.RolloutFusedDevice(a4.data_ptr(), 256, n, r4)
+                torch.cuda.synchronize(dev)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(stream)
+                for _ in range(fsteps4 // 256):
+                    e4.RolloutFusedDevice(a4.data_ptr(), 256, n, r4)
+                g1.record(stream)
+                torch.cuda.synchronize(dev)
+                fused64_us = g0.elapsed_time(g1) * 1e3 / fsteps4
                 f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
+                           "fused_rollout": {"us_per_step": fused64_us, "env_steps_per_sec": n / (fused64_us * 1e-6), "steps_per_launch": 256,
+                                             "note": "T-step fused float64 kernel (state in registers, arithmetic-bound); open-loop rollouts only"},
                            "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
                            "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
                            "frac_of_peak_by_events": 73 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,

@@ -922,10 +922,22 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     ENTER(h);
     if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
     if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
-    if (h->f64) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no GYMNET_FLAG_F64 variant; use gymnet_vecenv_rollout_device");
     if (h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no DONE_LIST / EPISODE_STATS / FINAL_OBS / per-lane-seed variant");
     if (h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device");
     if (steps == 0) return GYMNET_OK;
+    if (h->f64) {       // float64 handle: rec->d_obs holds doubles, [steps][4][num_envs]
+        const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned_to(rec->d_reward, 8)) &&
+                                     (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 1u) == 0));
+        int vec = h->lcfg.vec == 2 ? 2 : 1;
+        if (vec == 2 && (!aligned_to(d_actions, 8) || (action_stride % 2) != 0 || (h->n % 2) != 0 || !rec_ok)) vec = 1;
+        StepArgs64 a = make_step_args64(h, d_actions);
+        RolloutArgs64 r{};
+        r.steps = steps; r.action_stride = action_stride; r.ring = ring;
+        if (rec) { r.rec_obs = static_cast<double *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
+        HIP_TRY(h, launch_rollout_fused_f64(h->autoreset, a, r, vec, h->stream));
+        h->tick += (uint64_t)steps; h->tslot ^= 1; h->step_launches += 1; h->lane_steps += (uint64_t)steps * (uint64_t)h->n;
+        return GYMNET_OK;
+    }
     LaunchCfg cfg = h->lcfg;
     const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned16(rec->d_reward)) &&
                                  (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 3u) == 0));
@@ -933,7 +945,7 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     StepArgs a = make_step_args(h, d_actions);
     RolloutArgs r{};
     r.steps = steps; r.action_stride = action_stride; r.ring = ring;
-    if (rec) { r.rec_obs = rec->d_obs; r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
+    if (rec) { r.rec_obs = static_cast<float *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
     HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
     swap_buffers(h);                     // DOUBLE_BUFFER: the launch read one buffer and wrote the other, once
     h->tick += (uint64_t)steps;

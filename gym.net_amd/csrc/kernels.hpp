@@ -90,6 +90,13 @@ struct ResetArgs64 {
     int32_t parity;
 };
 hipError_t launch_reset_f64(const ResetArgs64 &a, hipStream_t st);
+// Fused multi-step rollout of a float64 handle: `steps` vector steps inside ONE launch, state in registers between steps; bitwise the
+// same results as `steps` launch_step_f64 calls.  Lean variant only.  rec_obs: optional [T][4][n] doubles.
+struct RolloutArgs64 {
+    int64_t steps, action_stride, ring;
+    double *rec_obs; float *rec_reward; uint8_t *rec_done;
+};
+hipError_t launch_rollout_fused_f64(bool autoreset, const StepArgs64 &a, const RolloutArgs64 &r, int vec, hipStream_t st);
 // float64 twins of launch_pack_obs / launch_export_small / launch_export_host (obs_dim 4 only: CartPole)
 hipError_t launch_pack_obs_f64(int obs_dim, const double *obs, int64_t stride, double *out_rowmajor, int64_t n, hipStream_t st);
 hipError_t launch_export_small_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,

@@ -202,6 +202,91 @@ __global__ __launch_bounds__(256) void step_kernel_f64_pipe(const StepArgs64 a) 
     }
 }
 
+// Fused rollout in the float64 mode: T vector steps in ONE launch.  A thread keeps its VEC lanes in registers for
+// all T steps, so per env-step only the action is read (4 B) and — when recording — observation / reward / done are written
+// (37 B): the launch is bound by the ~270 binary64 VALU per env-step, not by memory.  The next step's action is loaded before
+// the current step's arithmetic.  Same per-lane code, same Philox counters (tick0 + t): bit-identical to T one-step launches.
+template <int VEC, bool AUTORESET>
+__global__ __launch_bounds__(256) void rollout_kernel_f64(const StepArgs64 a, const RolloutArgs64 ro) {
+    constexpr int S = CartPole64::S;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const uint64_t tick0 = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
+    const int64_t n = a.n;
+    if (i0 >= n) return;
+    const bool full = i0 + VEC <= n;
+    double s[S][VEC];
+#pragma unroll
+    for (int k = 0; k < S; ++k) load_row<double, VEC, true>(a.state + k * a.stride, i0, n, full, s[k]);
+    int32_t sbd[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sbd[j] = -1;
+    if constexpr (!AUTORESET) load_row<int32_t, VEC, true>(a.sbd, i0, n, full, sbd);
+    int32_t act[VEC], act_next[VEC];
+    load_row<int32_t, VEC, true>(a.action, i0, n, full, act);
+    int64_t slice = 0;
+    float reward[VEC];
+    uint8_t done[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { reward[j] = 0.0f; done[j] = 0; act_next[j] = 0; }
+    for (int64_t t = 0; t < ro.steps; ++t) {
+        int64_t nslice = slice + 1;
+        if (nslice == ro.ring) nslice = 0;
+        if (t + 1 < ro.steps) load_row<int32_t, VEC, true>(a.action + nslice * ro.action_stride, i0, n, full, act_next);   // in flight during this step's arithmetic
+        bool small = true;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) small = small && (__builtin_fabs(s[2][j]) <= kSmallAngle64);
+        const bool wave_small = __ballot(!small) == 0;
+        uint32_t after = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            double sj[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) sj[k] = s[k][j];
+            bool dn;
+            if (wave_small) CartPole64::step<true>(sj, act[j], dn);
+            else CartPole64::step<false>(sj, act[j], dn);
+            float rw = 1.0f;
+            if constexpr (!AUTORESET) {
+                if (dn) {
+                    if (sbd[j] == -1) sbd[j] = 0;
+                    else { after += (i0 + j < n) ? 1u : 0u; sbd[j] += 1; rw = 0.0f; }
+                }
+            }
+            if constexpr (AUTORESET) {
+                if (dn) CartPole64::reset(sj, a.seed, a.lane_offset + (uint64_t)(i0 + j), tick0 + (uint64_t)t);
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[k][j] = sj[k];
+            reward[j] = rw;
+            done[j] = dn ? 1 : 0;
+        }
+        if constexpr (!AUTORESET) {
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t c = 1; c <= (uint32_t)VEC; ++c) total += c * (uint32_t)__popcll(__ballot(after == c));
+            if (total && lane_id64() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) {
+                const uint32_t shard = (uint32_t)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kShards - 1));
+                atomicAdd(&a.after_done[shard * kAfterStride], (unsigned long long)total);
+            }
+        }
+        if (ro.rec_reward) store_row<float, VEC, true>(ro.rec_reward + t * n, i0, n, full, reward);
+        if (ro.rec_done) store_row<uint8_t, VEC, true>(ro.rec_done + t * n, i0, n, full, done);
+        if (ro.rec_obs) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) store_row<double, VEC, true>(ro.rec_obs + (t * S + k) * n, i0, n, full, s[k]);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) act[j] = act_next[j];
+        slice = nslice;
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) store_row<double, VEC, false>(a.state + k * a.stride, i0, n, full, s[k]);
+    store_row<float, VEC, false>(a.reward, i0, n, full, reward);
+    store_row<uint8_t, VEC, false>(a.done, i0, n, full, done);
+    if constexpr (!AUTORESET) store_row<int32_t, VEC, false>(a.sbd, i0, n, full, sbd);
+}
+
 // Reset: all lanes, or the lanes selected by a byte mask (which may alias a.done: a lane's flag is read before it is cleared)
 __global__ __launch_bounds__(256) void reset_kernel_f64(const ResetArgs64 a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,6 +375,20 @@ hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int
 #undef GYMNET_L64_EX
 #undef GYMNET_L64_NT
 #undef GYMNET_L64
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_fused_f64(bool autoreset, const StepArgs64 &a, const RolloutArgs64 &r, int vec, hipStream_t st) {
+    if (vec != 2) vec = 1;
+    const int64_t threads = (a.n + vec - 1) / vec;
+    const dim3 grid(grid64(threads > 0 ? threads : 1, 256)), blk(256);
+    if (vec == 2) {
+        if (autoreset) hipLaunchKernelGGL((rollout_kernel_f64<2, true>), grid, blk, 0, st, a, r);
+        else hipLaunchKernelGGL((rollout_kernel_f64<2, false>), grid, blk, 0, st, a, r);
+    } else {
+        if (autoreset) hipLaunchKernelGGL((rollout_kernel_f64<1, true>), grid, blk, 0, st, a, r);
+        else hipLaunchKernelGGL((rollout_kernel_f64<1, false>), grid, blk, 0, st, a, r);
+    }
     return hipGetLastError();
 }
 

@@ -286,7 +286,8 @@ class VectorEnv:
 
     def RolloutFusedDevice(self, d_actions, steps, action_stride, ring, rec_obs=None, rec_reward=None, rec_done=None):
         """`steps` vector steps in ONE kernel launch (state stays in registers); optional device-side rollout
-        buffers rec_obs [T][D][N], rec_reward [T][N], rec_done [T][N] (ReplayMemory.cs:25-67, batched)."""
+        buffers rec_obs [T][D][N] (of the handle's dtype: float64 for a float64 handle), rec_reward [T][N], rec_done [T][N]
+        (ReplayMemory.cs:25-67, batched)."""
         rec = None
         if rec_obs is not None or rec_reward is not None or rec_done is not None:
             rec = capi.RolloutBuffers(_ptr(rec_obs), _ptr(rec_reward), _ptr(rec_done))

@@ -88,7 +88,7 @@ typedef enum gymnet_env_id {
                                               reset draws with 53 random bits, float64 observations at the boundary.  Reproduces the reference's
                                               episode lengths free-running (the float32 engine guarantees 1e-5 per teacher-forced step only).
                                               73 B per env-step instead of 41.  Not combinable with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER /
-                                              d_ext_obs / the fused rollout / groups (GYMNET_ERR_UNSUPPORTED) */
+                                              d_ext_obs / groups (GYMNET_ERR_UNSUPPORTED) */
 #define GYMNET_FLAG_COMPACT_RECORDS_ONLY 0x80u /* ABI 4, with DONE_LIST: the step kernel writes the finished lanes' episode records / terminal
                                               observations ONLY as compact records (gymnet_vecenv_done_records); the dense per-lane views
                                               (gymnet_vecenv_episode_stats / _final_obs, gymnet_device_view.d_finished_*) are then brought up to
@@ -263,7 +263,8 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
 /* Device-side rollout buffers (the example's replay memory, batched: examples/ReinforcementLearning/
  * ReinforcementLearning/MemoryTypes/ReplayMemory.cs:25-67).  Any pointer may be NULL = do not record that stream. */
 typedef struct gymnet_rollout_buffers {
-    float   *d_obs;     /* [steps][obs_dim][num_envs]  observation AFTER step t (after auto-reset, like the step API) */
+    void    *d_obs;     /* [steps][obs_dim][num_envs]  observation AFTER step t (after auto-reset, like the step API); float32 —
+                           float64 for a GYMNET_FLAG_F64 handle */
     float   *d_reward;  /* [steps][num_envs] */
     uint8_t *d_done;    /* [steps][num_envs] */
 } gymnet_rollout_buffers;

@@ -174,8 +174,6 @@ def test_f64_device_path_graph_replay_time_limit_and_lane_seeds(gpu_pkg, oracle)
             assert env.Tick == steps + 1
             r = env.Read()
             res.append((env.GetState(), r.Reward, r.Done))
-            with pytest.raises(NotImplementedError):
-                env.RolloutFusedDevice(acts, 4, n + 1, ring)
     for x in res[1:]:
         assert all(np.array_equal(u, v) for u, v in zip(res[0], x))
     a_host = acts.cpu().numpy()[:, :n]
@@ -320,3 +318,48 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
         assert env.KernelName() == "step_kernel_f64<2,true,true,15>"                  # bookkeeping: one-shot kernel
         with pytest.raises(ValueError):
             env.SetLaunchPolicy(sequential_lanes=5)
+
+
+@pytest.mark.parametrize("auto", [True, False])
+@pytest.mark.parametrize("n", [2 * 4096, 4096 + 3])
+def test_f64_fused_rollout_is_bit_identical_to_stepwise_and_records(gpu_pkg, oracle, auto, n):
+    """gymnet_vecenv_rollout_fused_device on a float64 handle: T vector steps in ONE launch (state in registers), bit-identical to T
+    one-launch steps — state, reward, done, steps_beyond_done, the step-after-done counter, the Philox reset draws (tick0 + t) — with
+    the recorded [T][4][N] float64 observations, [T][N] rewards and done flags equal to what the stepwise handle returned at every
+    step; even and odd lane counts (two-lane and tail paths), an action ring shorter than the rollout, and the CPU twin for the
+    auto-reset case."""
+    import torch
+    T, ring = 45, 8
+    stride = n + (n % 2)
+    acts = torch.randint(0, 2, (ring, stride), dtype=torch.int32, device="cuda")
+    rec_o = torch.zeros((T, 4, n), dtype=torch.float64, device="cuda")
+    rec_r = torch.full((T, n), -1.0, dtype=torch.float32, device="cuda")
+    rec_d = torch.full((T, n), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    a_host = acts.cpu().numpy()[:, :n]
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, lane_offset=77) as f, \
+            gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, lane_offset=77) as e:
+        f.ResetDevice(); e.ResetDevice()
+        f.RolloutFusedDevice(acts, T, stride, ring, rec_obs=rec_o, rec_reward=rec_r, rec_done=rec_d)
+        f.Sync()
+        s = oracle.cartpole_reset_f64(SEED, 77, 0, n)
+        obs, rew, don = rec_o.cpu().numpy(), rec_r.cpu().numpy(), rec_d.cpu().numpy()
+        for t in range(T):
+            o = e.Step(a_host[t % ring])
+            assert np.array_equal(obs[t], o.Observation.T) and np.array_equal(rew[t], o.Reward) and np.array_equal(don[t].astype(bool), o.Done), t
+            if auto:
+                s, r, d = oracle.cartpole_autoreset_step_f64(SEED, 77, 1 + t, s, a_host[t % ring])
+                assert np.array_equal(obs[t], s), t
+        assert np.array_equal(f.GetState(), e.GetState()) and f.Tick == e.Tick == T + 1
+        lf, le = f.Read(), e.Read()
+        assert np.array_equal(lf.Observation, le.Observation) and np.array_equal(lf.Reward, le.Reward) and np.array_equal(lf.Done, le.Done)
+        assert f.Counters()["stepped_after_done"] == e.Counters()["stepped_after_done"] and f.Counters()["tick"] == T + 1
+        if not auto:
+            assert np.array_equal(f.GetStepsBeyondDone(), e.GetStepsBeyondDone()) and don[-1].mean() > 0.5 and (rew[-1][don[-1] > 0] == 0).mean() > 0.9
+        f.RolloutFusedDevice(acts, 3, stride, ring)                      # without recording, and continuing from the fused state
+        for t in range(3):
+            e.Step(a_host[t % ring])
+        assert np.array_equal(f.GetState(), e.GetState())
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True) as x:
+        with pytest.raises(NotImplementedError):
+            x.RolloutFusedDevice(acts, 4, stride, ring)                  # bookkeeping variants are not fused (as in float32)
