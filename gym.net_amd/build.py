@@ -1,7 +1,9 @@
 """Builds gym.net_amd/lib/libgymnet_amd.so: the HIP kernels + the C ABI, for gfx950 only.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared csrc/*.hip -ldl -o lib/libgymnet_amd.so
-(done as one `hipcc -c` per .hip file in parallel plus one link: same flags, same result, about a third less wall time)
+(done as one `hipcc -c` per .hip file in parallel plus one link: same flags, same result.  Every env's step / rollout / reset
+kernels are a translation unit of their own — csrc/env_*.hip instantiating csrc/step_kernels.hpp — so the eight files compile
+side by side: ~15 s wall on 8 cores instead of ~40 s for the former single kernels.hip)
 
 -ffp-contract=off is part of the numerical contract (see csrc/envs.hpp): every float32 operation
 rounds on its own, in the order written.  hipcc cross-compiles without a GPU present.
@@ -13,8 +15,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libgymnet_amd.so")
-SOURCES = ["kernels.hip", "kernels64.hip", "capi.hip", "group.hip"]
-DEPS = SOURCES + ["kernels.hpp", "envs.hpp", "cartpole64.hpp", "philox.hpp", "handle.hpp", os.path.join("..", "..", "include", "gymnet_amd.h")]
+SOURCES = ["env_cartpole.hip", "env_cartpole64.hip", "env_acrobot.hip", "env_pendulum.hip", "env_mountaincar.hip", "kernels.hip", "capi.hip",
+           "group.hip"]
+DEPS = SOURCES + ["kernels.hpp", "step_kernels.hpp", "lanes.hpp", "envs.hpp", "cartpole64.hpp", "philox.hpp", "handle.hpp",
+                  os.path.join("..", "..", "include", "gymnet_amd.h")]
 # -fno-slp-vectorize: on gfx950 a packed FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) occupies the SIMD about
 # as long as the two scalar instructions it replaces (~5 cycles against ~2.4 each in these kernels' instruction mix:
 # tools/acrobot_alu_probe.hip, tools/valu_probe.hip, profiles/*_r02.txt), so the compiler's opportunistic pairing saves
@@ -24,9 +28,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
 # Probe builds only: GYMNET_BUILD_PROBE_ENV=1 compiles the GYMNET_VEC / GYMNET_NT / ... environment overrides of the launch policy
 # back in (the round 1-3 tools/ scripts use them).  The shipped library never reads the process environment for its policy:
-# gymnet_vecenv_set_launch_policy is the interface.
+# gymnet_vecenv_set_launch_policy is the interface.  A probe build goes to ITS OWN file (libgymnet_amd_probe.so; point
+# GYMNET_LIB_PATH at it), so it can never be mistaken for — or be left behind as — the shipped library.
 if os.environ.get("GYMNET_BUILD_PROBE_ENV") == "1":
     FLAGS = FLAGS + ["-DGYMNET_PROBE_ENV"]
+    OUT = os.path.join(HERE, "lib", "libgymnet_amd_probe.so")
 
 
 def hipcc():

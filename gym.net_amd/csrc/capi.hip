@@ -72,8 +72,7 @@ int dalloc(gymnet_vecenv *h, T **p, size_t count) {
 // device-resident consumer (bench.py, a GPU policy) never pays for it — at 2^27 CartPole lanes it is 2.6 GiB.
 int ensure_staging(gymnet_vecenv *h, bool actions, bool pack, bool mask) {
     if (actions && !h->d_actions) ST_TRY(dalloc(h, (int32_t **)&h->d_actions, (size_t)h->padded));
-    if (pack && h->f64 && !h->d_pack64) ST_TRY(dalloc(h, &h->d_pack64, (size_t)h->padded * h->desc->obs_dim));
-    if (pack && !h->f64 && !h->d_pack) ST_TRY(dalloc(h, &h->d_pack, (size_t)h->padded * h->desc->obs_dim));
+    if (pack && !h->d_pack) ST_TRY(dalloc(h, (char **)&h->d_pack, (size_t)h->padded * h->desc->obs_dim * h->esz));
     if (mask && !h->d_mask) ST_TRY(dalloc(h, &h->d_mask, (size_t)h->padded));
     return GYMNET_OK;
 }
@@ -90,13 +89,14 @@ void drop_graphs(gymnet_vecenv *h) {
 }
 
 int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict);
-StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
-    StepArgs a{};
+template <class R>
+StepArgsT<R> make_step_args(gymnet_vecenv *h, const void *d_actions) {
+    StepArgsT<R> a{};
     const bool alias = h->desc->alias;
-    a.state = h->d_state;
-    a.state_out = (h->double_buffer && alias) ? h->d_state_alt : h->d_state;
-    a.obs = (h->double_buffer && !alias) ? h->d_obs_alt : h->d_obs;
-    a.obs_in = h->d_obs;
+    a.state = static_cast<R *>(h->d_state);
+    a.state_out = static_cast<R *>((h->double_buffer && alias) ? h->d_state_alt : h->d_state);
+    a.obs = static_cast<R *>((h->double_buffer && !alias) ? h->d_obs_alt : h->d_obs);
+    a.obs_in = static_cast<const R *>(h->d_obs);
     a.action = d_actions;
     a.reward = h->d_reward;
     a.done = h->d_done;
@@ -105,12 +105,12 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     // the dense "last finished episode per lane" arrays are maintained by the step kernel itself unless the caller opted for
     // compact records only (GYMNET_FLAG_COMPACT_RECORDS_ONLY with DONE_LIST): then the getters apply the records on demand
     const bool dense = !(h->compact_only && h->d_done_list);
-    a.final_obs = dense ? h->d_final_obs : nullptr;
+    a.final_obs = dense ? static_cast<R *>(h->d_final_obs) : nullptr;
     a.done_list = h->d_done_list;
     a.done_count2 = h->d_done_count2;
     a.done_cap = h->done_cap;
     a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = dense ? h->d_fin_ret : nullptr; a.fin_len = dense ? h->d_fin_len : nullptr;
-    a.rec_ret = h->d_rec_ret; a.rec_len = h->d_rec_len; a.rec_obs = h->d_rec_obs;
+    a.rec_ret = h->d_rec_ret; a.rec_len = h->d_rec_len; a.rec_obs = static_cast<R *>(h->d_rec_obs);
     a.lane_seed = h->d_lane_seed;
     a.after_done = h->d_after_done;
     a.n = h->n; a.state_stride = h->sstride; a.obs_stride = h->ostride;
@@ -118,21 +118,6 @@ StepArgs make_step_args(gymnet_vecenv *h, const void *d_actions) {
     a.seed = h->seed;
     a.parity = (int32_t)h->tslot;
     a.cparity = (int32_t)(h->step_launches & 1u);
-    a.max_episode_steps = h->cfg.max_episode_steps;
-    return a;
-}
-
-StepArgs64 make_step_args64(gymnet_vecenv *h, const void *d_actions) {
-    StepArgs64 a{};
-    a.state = h->d_state64;
-    a.action = static_cast<const int32_t *>(d_actions);
-    a.reward = h->d_reward; a.done = h->d_done; a.sbd = h->d_sbd; a.tick2 = h->d_tick2;
-    a.ep_ret = h->d_ep_ret; a.ep_len = h->d_ep_len; a.fin_ret = h->d_fin_ret; a.fin_len = h->d_fin_len;
-    a.lane_seed = h->d_lane_seed;
-    a.after_done = h->d_after_done;
-    a.n = h->n; a.stride = h->sstride;
-    a.lane_offset = (uint64_t)h->cfg.lane_offset; a.seed = h->seed;
-    a.parity = (int32_t)h->tslot;
     a.max_episode_steps = h->cfg.max_episode_steps;
     return a;
 }
@@ -147,35 +132,44 @@ void swap_buffers(gymnet_vecenv *h) {
 
 // Gathers the sharded done list of the most recent step — and the records written beside it — into compact arrays
 // (stream-ordered, non-blocking); with `dense`, also applies the records to the dense per-lane arrays.  NULL outputs are skipped.
-int compact_done(gymnet_vecenv *h, int32_t *d_list, float *d_ret, int32_t *d_len, float *d_obs, int64_t capacity, uint32_t *d_count,
-                 bool dense = false) {
-    CompactArgs c{};
+template <class R>
+int compact_done_typed(gymnet_vecenv *h, int32_t *d_list, float *d_ret, int32_t *d_len, void *d_obs, int64_t capacity, uint32_t *d_count, bool dense) {
+    CompactArgsT<R> c{};
     c.counts = h->d_done_count2 + (size_t)h->last_cparity * kShards * kCountStride;
     c.list = h->d_done_list; c.cap = h->done_cap;
-    c.rec_ret = h->d_rec_ret; c.rec_len = h->d_rec_len; c.rec_obs = h->d_rec_obs; c.obs_dim = h->desc->obs_dim;
-    c.out_list = d_list; c.out_ret = d_ret; c.out_len = d_len; c.out_obs = d_obs; c.out_capacity = capacity; c.out_count = d_count;
-    if (dense) { c.dense_ret = h->d_rec_ret ? h->d_fin_ret : nullptr; c.dense_len = h->d_fin_len; c.dense_obs = h->d_rec_obs ? h->d_final_obs : nullptr; }
+    c.rec_ret = h->d_rec_ret; c.rec_len = h->d_rec_len; c.rec_obs = static_cast<const R *>(h->d_rec_obs); c.obs_dim = h->desc->obs_dim;
+    c.out_list = d_list; c.out_ret = d_ret; c.out_len = d_len; c.out_obs = static_cast<R *>(d_obs); c.out_capacity = capacity; c.out_count = d_count;
+    if (dense) { c.dense_ret = h->d_rec_ret ? h->d_fin_ret : nullptr; c.dense_len = h->d_fin_len; c.dense_obs = h->d_rec_obs ? static_cast<R *>(h->d_final_obs) : nullptr; }
     c.n = h->n;
     HIP_TRY(h, launch_compact_done(c, h->stream));
     return GYMNET_OK;
 }
-
-// device address of state row k of the CURRENT state (its own row of d_state, or the observation row that holds it)
-float *state_row(gymnet_vecenv *h, int k) {
-    const int m = h->desc->alias ? -1 : h->desc->state_row_in_obs[k];
-    return m < 0 ? h->d_state + (size_t)k * h->sstride : h->d_obs + (size_t)m * h->ostride;
+// d_obs: terminal observations of the handle's state scalar (float, or double for a GYMNET_FLAG_F64 handle)
+int compact_done(gymnet_vecenv *h, int32_t *d_list, float *d_ret, int32_t *d_len, void *d_obs, int64_t capacity, uint32_t *d_count,
+                 bool dense = false) {
+    return h->f64 ? compact_done_typed<double>(h, d_list, d_ret, d_len, d_obs, capacity, d_count, dense)
+                  : compact_done_typed<float>(h, d_list, d_ret, d_len, d_obs, capacity, d_count, dense);
 }
 
-// Applies the fields of `p` that are not -1.  strict: a value the handle cannot run is an error; else it is ignored (probe builds).
+// device address of state row k of the CURRENT state (its own row of d_state, or the observation row that holds it)
+void *state_row(gymnet_vecenv *h, int k) {
+    const int m = h->desc->alias ? -1 : h->desc->state_row_in_obs[k];
+    return m < 0 ? row_at(h->d_state, k, h->sstride, h->esz) : row_at(h->d_obs, m, h->ostride, h->esz);
+}
+
+// Applies the fields of `p` that are not -1.  strict: a value the handle cannot run — or that would not take effect for it (a
+// multi-lane form on a batch that is not whole groups, a reset form the env has no use for) — is an error and nothing changes;
+// else it is ignored (probe builds).  gymnet_vecenv_kernel_name stays the authority on what the next launch runs.
 int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
     LaunchCfg c = h->lcfg;
+    int graph_mode = h->graph_mode;
     const bool acrobot = h->cfg.env_id == GYMNET_ENV_ACROBOT;
+    const bool wide2 = acrobot || h->f64;            // the env's wide form is two lanes per thread (else four)
     auto bad = [&](const char *what, int v) -> int {
         return strict ? fail(h, GYMNET_ERR_INVALID_ARG, "launch policy: %s = %d is not available for this handle", what, v) : GYMNET_OK;
     };
     if (p.vec != -1) {
-        const bool ok = h->f64 ? (p.vec == 1 || p.vec == 2)
-                               : (p.vec == 1 || (p.vec == 4 && h->can_vec4 && !acrobot) || (p.vec == 2 && h->can_vec2 && acrobot));
+        const bool ok = p.vec == 1 || (p.vec == 4 && h->can_vec4 && !wide2) || (p.vec == 2 && h->can_vec2 && wide2);
         if (ok) c.vec = p.vec; else ST_TRY(bad("vec", p.vec));
     }
     if (p.block != -1) { if (p.block == 64 || p.block == 128 || p.block == 256) c.block = p.block; else ST_TRY(bad("block", p.block)); }
@@ -184,7 +178,10 @@ int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
         if (p.sequential_lanes >= 1 && p.sequential_lanes <= (h->f64 ? 4 : 5) && (acrobot || h->f64 || p.sequential_lanes == 1)) c.items = p.sequential_lanes;
         else ST_TRY(bad("sequential_lanes", p.sequential_lanes));
     }
-    if (p.reset_form != -1) { if (p.reset_form == 0 || p.reset_form == 1) c.reset_form = p.reset_form; else ST_TRY(bad("reset_form", p.reset_form)); }
+    if (p.reset_form != -1) {
+        const bool has_form1 = h->desc->alias;       // the wave-compacted reset hands back the state only (CartPole, MountainCar)
+        if (p.reset_form == 0 || (p.reset_form == 1 && (has_form1 || !strict))) c.reset_form = p.reset_form; else ST_TRY(bad("reset_form", p.reset_form));
+    }
     if (p.lds_pipe != -1) {
         if (p.lds_pipe == 0 || (p.lds_pipe == 1 && h->lds_ok)) c.lds_pipe = p.lds_pipe; else ST_TRY(bad("lds_pipe", p.lds_pipe));
     }
@@ -192,7 +189,17 @@ int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
         if (p.occupancy_lds_bytes >= 0 && p.occupancy_lds_bytes <= 160 * 1024) c.lds_bytes = p.occupancy_lds_bytes;
         else ST_TRY(bad("occupancy_lds_bytes", p.occupancy_lds_bytes));
     }
-    if (p.graph != -1) { if (p.graph == 0 || p.graph == 1) h->graph_mode = p.graph; else if (p.graph == -2) h->graph_mode = -1; else ST_TRY(bad("graph", p.graph)); }
+    if (p.graph != -1) { if (p.graph == 0 || p.graph == 1) graph_mode = p.graph; else if (p.graph == -2) graph_mode = -1; else ST_TRY(bad("graph", p.graph)); }
+    if (strict && p.sequential_lanes > 1) {
+        // an explicitly requested multi-lane form must be the one the launcher resolves to: lean variant, the lane
+        // width it is defined for, whole 2 * items * 256-lane groups for the pair form
+        int rvec = 1, rseq = 1;
+        resolved_step_shape(h->cfg.env_id, h->f64, h->autoreset, h->extras, c, h->n, &rvec, &rseq);
+        if (rseq != p.sequential_lanes)
+            return fail(h, GYMNET_ERR_INVALID_ARG, "launch policy: sequential_lanes = %d would not take effect for this handle (vec %d, %s variant, "
+                        "%lld lanes: the launcher resolves to %d)", p.sequential_lanes, c.vec, h->extras ? "bookkeeping" : "lean", (long long)h->n, rseq);
+    }
+    h->graph_mode = graph_mode;
     if (std::memcmp(&c, &h->lcfg, sizeof c) != 0) {
         h->lcfg = c;
         drop_graphs(h);          // captured launches froze the old configuration
@@ -205,20 +212,22 @@ void default_policy(gymnet_vecenv *h) {
     const EnvDesc &d = *h->desc;
     const gymnet_config *cfg = &h->cfg;
     if (h->f64) {
-        // float64 CartPole: two lanes per thread (one dwordx4 per state row and direction); stream policy by the bytes a vector
-        // step moves, with the thresholds of the float32 path below
-        const size_t step_bytes = (size_t)h->n * 73;
-        h->can_vec4 = false; h->can_vec2 = true; h->lds_ok = false;
+        // float64 CartPole: two lanes per thread (one dwordx4 per state row and direction) where the rows are 16-byte aligned
+        // (external observation buffers may not be); stream policy by the bytes a vector step moves, with the thresholds of the
+        // float32 path below
+        const size_t step_bytes = (size_t)h->n * bytes_per_step(h);
+        const bool can2 = aligned16(h->d_state) && (h->sstride % 2 == 0) && (!h->d_state_alt || aligned16(h->d_state_alt));
+        h->can_vec4 = false; h->can_vec2 = can2; h->lds_ok = false;
         // measured at 2^20 lanes (73 MiB per step; us per step, gpurun_out r4): every stream non-temporal 14.3, state cacheable 14.8,
         // nothing non-temporal 16.2, one lane per thread 15.6
-        h->lcfg = LaunchCfg{2, 256, 15, 0, 1, 0, 0};
+        h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, 0, 0};
         if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
-        // The multi-item kernel (step_kernel_f64_pipe: a thread owns 2 lane pairs, all loads first, then advance / store pair after
-        // pair) wins exactly where the one-shot kernel is ONE full lock-step generation of waves — 2^20 lanes = 2^19 threads = 8 waves
-        // on every SIMD: 14.4 -> 13.1-13.2 us (0.67 -> 0.73 of 8 TB/s on its 73 B; profiles/f64_forms_r04.txt).  Below (2^19: 8.9 vs
-        // 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the generations overlap by
-        // themselves.  Lean variant and whole 1024-lane groups only (the launcher falls back otherwise).
-        if (h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = 2;
+        // The multi-item kernel (step_kernel_pipe2<CartPole64, 2>: a thread owns 2 lane pairs, all loads first, then advance / store
+        // pair after pair) wins exactly where the one-shot kernel is ONE full lock-step generation of waves — 2^20 lanes = 2^19
+        // threads = 8 waves on every SIMD: 14.4 -> 13.1-13.2 us (0.67 -> 0.73 of 8 TB/s on its 73 B; profiles/f64_forms_r04.txt).  Below
+        // (2^19: 8.9 vs 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the generations
+        // overlap by themselves.  Lean variant and whole 1024-lane groups only (the launcher falls back otherwise).
+        if (can2 && h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = 2;
         return;
     }
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be
@@ -299,16 +308,18 @@ int seed_handle(gymnet_vecenv *h, uint64_t seed) {
 
 // one vector step = one kernel launch; bumps the host mirrors of the device-side counters
 int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
+    int cparity;
     if (h->f64) {
-        StepArgs64 a = make_step_args64(h, d_actions);
-        HIP_TRY(h, launch_step_f64(h->autoreset, h->extras, a, h->lcfg.vec, h->lcfg.nt, h->lcfg.items, h->stream));
-        h->tick += 1; h->tslot ^= 1; h->step_launches += 1; h->lane_steps += (uint64_t)h->n;
-        return GYMNET_OK;
+        const StepArgsT<double> a = make_step_args<double>(h, d_actions);
+        cparity = a.cparity;
+        HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
+    } else {
+        const StepArgsT<float> a = make_step_args<float>(h, d_actions);
+        cparity = a.cparity;
+        HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
     }
-    StepArgs a = make_step_args(h, d_actions);
-    HIP_TRY(h, launch_step(h->cfg.env_id, h->autoreset, h->extras, a, h->lcfg, h->stream));
     swap_buffers(h);
-    h->last_cparity = a.cparity;
+    h->last_cparity = cparity;
     h->tick += 1;
     h->tslot ^= 1;
     h->step_launches += 1;
@@ -316,19 +327,10 @@ int launch_one_step(gymnet_vecenv *h, const void *d_actions) {
     return GYMNET_OK;
 }
 
-int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
-    if (h->f64) {
-        ResetArgs64 r{};
-        r.state = h->d_state64; r.sbd = h->d_sbd; r.done = h->d_done; r.mask = d_mask;
-        r.tick2 = h->d_tick2; r.lane_seed = h->d_lane_seed; r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
-        r.n = h->n; r.stride = h->sstride; r.lane_offset = (uint64_t)h->cfg.lane_offset; r.seed = h->seed;
-        r.parity = (int32_t)h->tslot;
-        HIP_TRY(h, launch_reset_f64(r, h->stream));
-        h->tick += 1; h->tslot ^= 1;
-        return GYMNET_OK;
-    }
-    ResetArgs r{};
-    r.state = h->d_state; r.obs = h->d_obs; r.sbd = h->d_sbd; r.done = h->d_done;
+template <class R>
+static int reset_lanes_typed(gymnet_vecenv *h, const uint8_t *d_mask) {
+    ResetArgsT<R> r{};
+    r.state = static_cast<R *>(h->d_state); r.obs = static_cast<R *>(h->d_obs); r.sbd = h->d_sbd; r.done = h->d_done;
     r.mask = d_mask;
     r.tick2 = h->d_tick2; r.lane_seed = h->d_lane_seed;
     r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
@@ -341,6 +343,10 @@ int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
     return GYMNET_OK;
 }
 
+int launch_reset_lanes(gymnet_vecenv *h, const uint8_t *d_mask) {
+    return h->f64 ? reset_lanes_typed<double>(h, d_mask) : reset_lanes_typed<float>(h, d_mask);
+}
+
 int write_tick(gymnet_vecenv *h) {
     uint64_t both[2] = {h->tick, h->tick};
     HIP_TRY(h, hipMemcpyAsync(h->d_tick2, both, sizeof both, hipMemcpyHostToDevice, h->stream));
@@ -348,18 +354,31 @@ int write_tick(gymnet_vecenv *h) {
     return GYMNET_OK;
 }
 
+// row-major packing / host export of the CURRENT observations, typed by the handle's state scalar
+static hipError_t pack_current_obs(gymnet_vecenv *h, const void *src_obs, int64_t stride, void *dst) {
+    return h->f64 ? launch_pack_obs(h->desc->obs_dim, static_cast<const double *>(src_obs), stride, static_cast<double *>(dst), h->n, h->stream)
+                  : launch_pack_obs(h->desc->obs_dim, static_cast<const float *>(src_obs), stride, static_cast<float *>(dst), h->n, h->stream);
+}
+static hipError_t export_current(gymnet_vecenv *h, bool host_form, void *obs_out, float *reward_out, uint8_t *done_out) {
+    const int O = h->desc->obs_dim;
+    if (h->f64) {
+        const double *o = static_cast<const double *>(h->d_obs);
+        return host_form ? launch_export_host(O, o, h->ostride, h->d_reward, h->d_done, static_cast<double *>(obs_out), reward_out, done_out, h->n, h->stream)
+                         : launch_export_small(O, o, h->ostride, h->d_reward, h->d_done, static_cast<double *>(obs_out), reward_out, done_out, h->n, h->stream);
+    }
+    const float *o = static_cast<const float *>(h->d_obs);
+    return host_form ? launch_export_host(O, o, h->ostride, h->d_reward, h->d_done, static_cast<float *>(obs_out), reward_out, done_out, h->n, h->stream)
+                     : launch_export_small(O, o, h->ostride, h->d_reward, h->d_done, static_cast<float *>(obs_out), reward_out, done_out, h->n, h->stream);
+}
+
 // queues the copies of the current results to host buffers (any may be NULL) without the closing synchronize;
 // only for handles without the host-mapped small-batch path
 int queue_copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
-    if (obs_out && h->f64) {
+    if (obs_out) {
         ST_TRY(ensure_staging(h, false, true, false));
-        HIP_TRY(h, launch_pack_obs_f64(d.obs_dim, h->d_state64, h->sstride, h->d_pack64, h->n, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack64, (size_t)h->n * d.obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    } else if (obs_out) {
-        ST_TRY(ensure_staging(h, false, true, false));
-        HIP_TRY(h, launch_pack_obs(d.obs_dim, h->d_obs, h->ostride, h->d_pack, h->n, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, pack_current_obs(h, h->d_obs, h->ostride, h->d_pack));
+        HIP_TRY(h, hipMemcpyAsync(obs_out, h->d_pack, (size_t)h->n * d.obs_dim * h->esz, hipMemcpyDeviceToHost, h->stream));
     }
     if (reward_out) HIP_TRY(h, hipMemcpyAsync(reward_out, h->d_reward, (size_t)h->n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (done_out) HIP_TRY(h, hipMemcpyAsync(done_out, h->d_done, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
@@ -369,22 +388,17 @@ int queue_copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *
 // copy the current results to host buffers (any may be NULL); blocks
 int copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     const EnvDesc &d = *h->desc;
-    const size_t esz = h->f64 ? sizeof(double) : sizeof(float);      // element size of an observation at the boundary
-    if (h->pin_block && (obs_out || reward_out || done_out) && (!obs_out || obs_out == (void *)h->pin_obs) &&
+    const size_t esz = h->esz;      // element size of an observation at the boundary
+    if (h->pin_block && (obs_out || reward_out || done_out) && (!obs_out || obs_out == h->pin_obs) &&
         (!reward_out || reward_out == h->pin_reward) && (!done_out || done_out == h->pin_done)) {
         // the caller reads the library's pinned buffers: ONE kernel writes the results across PCIe, no staging, no memcpy calls
-        if (h->f64) HIP_TRY(h, launch_export_host_f64(d.obs_dim, h->d_state64, h->sstride, h->d_reward, h->d_done, static_cast<double *>(obs_out), reward_out, done_out, h->n, h->stream));
-        else HIP_TRY(h, launch_export_host(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, static_cast<float *>(obs_out), reward_out, done_out, h->n, h->stream));
+        HIP_TRY(h, export_current(h, /*host_form=*/true, obs_out, reward_out, done_out));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GYMNET_OK;
     }
     if (h->hm_block) {   // latency path for small batches: one export kernel into host-mapped memory, one sync, host memcpy
-        if ((obs_out || reward_out || done_out) && h->f64)
-            HIP_TRY(h, launch_export_small_f64(d.obs_dim, h->d_state64, h->sstride, h->d_reward, h->d_done, reinterpret_cast<double *>(h->hm_obs),
-                                               reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr, h->n, h->stream));
-        else if (obs_out || reward_out || done_out)
-            HIP_TRY(h, launch_export_small(d.obs_dim, h->d_obs, h->ostride, h->d_reward, h->d_done, h->hm_obs,
-                                           reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr, h->n, h->stream));
+        if (obs_out || reward_out || done_out)
+            HIP_TRY(h, export_current(h, /*host_form=*/false, h->hm_obs, reward_out ? h->hm_reward : nullptr, done_out ? h->hm_done : nullptr));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (obs_out) std::memcpy(obs_out, h->hm_obs, (size_t)h->n * d.obs_dim * esz);
         if (reward_out) std::memcpy(reward_out, h->hm_reward, (size_t)h->n * sizeof(float));
@@ -455,7 +469,7 @@ int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_
     // Graph replay only pays while the host launch path (~3.5 us per launch) is the bottleneck: measured on
     // MI355X, replay beats eager launches up to ~2^18 CartPole lanes (2.6 vs 5.7 us/step at 2^16), ties at 2^19
     // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
-    const bool launch_bound = (size_t)h->n * (size_t)h->desc->algorithmic_bytes < ((size_t)24 << 20);
+    const bool launch_bound = (size_t)h->n * bytes_per_step(h) < ((size_t)24 << 20);
     if (graph_mode < 0) graph_mode = h->graph_mode;          // gymnet_vecenv_set_launch_policy(.graph)
 #ifdef GYMNET_PROBE_ENV
     if (graph_mode < 0) { if (const char *force = std::getenv("GYMNET_GRAPH")) graph_mode = std::atoi(force) != 0; }
@@ -608,13 +622,11 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt needs d_ext_obs and GYMNET_FLAG_DOUBLE_BUFFER");
     if (cfg->d_ext_obs_alt && cfg->d_ext_obs_alt == cfg->d_ext_obs)
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs_alt must be a different buffer than d_ext_obs");
-    if (cfg->flags & GYMNET_FLAG_F64) {
-        if (cfg->env_id != GYMNET_ENV_CARTPOLE)
-            return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 exists for CartPole only (the one env whose float64 arithmetic the reference defines)");
-        if (cfg->flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER))
-            return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 cannot be combined with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER");
-        if (cfg->d_ext_obs) return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 keeps its own (float64) state arrays: no d_ext_obs");
-    }
+    if ((cfg->flags & GYMNET_FLAG_F64) && cfg->env_id != GYMNET_ENV_CARTPOLE)
+        return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 exists for CartPole only (the one env whose float64 arithmetic the reference defines)");
+    const size_t esz_cfg = (cfg->flags & GYMNET_FLAG_F64) ? 8 : 4;
+    if ((cfg->d_ext_obs && !aligned_to(cfg->d_ext_obs, (int)esz_cfg)) || (cfg->d_ext_obs_alt && !aligned_to(cfg->d_ext_obs_alt, (int)esz_cfg)))
+        return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs / d_ext_obs_alt must be aligned to the observation element (%zu bytes)", esz_cfg);
     if ((cfg->flags & GYMNET_FLAG_COMPACT_RECORDS_ONLY) && !(cfg->flags & GYMNET_FLAG_DONE_LIST))
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "GYMNET_FLAG_COMPACT_RECORDS_ONLY needs GYMNET_FLAG_DONE_LIST");
 
@@ -633,6 +645,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     h->autoreset = (cfg->flags & GYMNET_FLAG_AUTORESET) != 0;
     h->double_buffer = (cfg->flags & GYMNET_FLAG_DOUBLE_BUFFER) != 0;
     h->f64 = (cfg->flags & GYMNET_FLAG_F64) != 0;
+    h->esz = h->f64 ? 8 : 4;
     h->compact_only = (cfg->flags & GYMNET_FLAG_COMPACT_RECORDS_ONLY) != 0;
     const EnvDesc &d = *h->desc;
     DeviceScope dev_scope;
@@ -658,22 +671,21 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
 
     const int64_t padded = (h->n + 63) / 64 * 64;   // every component array starts 256-byte aligned
     h->padded = padded;
-    if (h->f64) {
-        CREATE_TRY(dalloc(h, &h->d_state64, (size_t)padded * d.state_dim)); h->sstride = padded; h->ostride = padded;
-    } else if (cfg->d_ext_obs) {
+    const size_t esz = h->esz;      // bytes per state / observation element: 4, or 8 for a GYMNET_FLAG_F64 handle
+    if (cfg->d_ext_obs) {
         if (d.alias) { h->d_state = cfg->d_ext_obs; h->sstride = cfg->ext_obs_stride; h->d_obs = h->d_state; h->ostride = h->sstride; }
         else {
             h->d_obs = cfg->d_ext_obs; h->ostride = cfg->ext_obs_stride;
-            CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded;
+            CREATE_TRY(dalloc(h, (char **)&h->d_state, (size_t)padded * d.state_dim * esz)); h->sstride = padded;
         }
     } else {
-        CREATE_TRY(dalloc(h, &h->d_state, (size_t)padded * d.state_dim)); h->sstride = padded;
+        CREATE_TRY(dalloc(h, (char **)&h->d_state, (size_t)padded * d.state_dim * esz)); h->sstride = padded;
         if (d.alias) { h->d_obs = h->d_state; h->ostride = h->sstride; }
-        else { CREATE_TRY(dalloc(h, &h->d_obs, (size_t)padded * d.obs_dim)); h->ostride = padded; }
+        else { CREATE_TRY(dalloc(h, (char **)&h->d_obs, (size_t)padded * d.obs_dim * esz)); h->ostride = padded; }
     }
     if (h->double_buffer) {   // the second observation buffer (for aliasing envs: the second STATE buffer), same stride
-        float *alt = cfg->d_ext_obs_alt;
-        if (!alt) CREATE_TRY(dalloc(h, &alt, (size_t)h->ostride * d.obs_dim));
+        void *alt = cfg->d_ext_obs_alt;
+        if (!alt) CREATE_TRY(dalloc(h, (char **)&alt, (size_t)h->ostride * d.obs_dim * esz));
         if (d.alias) { h->d_state_alt = alt; h->d_obs_alt = alt; } else { h->d_obs_alt = alt; }
     }
     CREATE_TRY(dalloc(h, &h->d_reward, (size_t)padded));
@@ -683,10 +695,10 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     CREATE_TRY(dalloc(h, &h->d_after_done, (size_t)kShards * kAfterStride));
     CREATE_TRY(dalloc(h, &h->d_bad, 1));
     if (h->n <= kSmallHostPath) {
-        const size_t a_bytes = (size_t)padded * 4, o_bytes = (size_t)padded * d.obs_dim * (h->f64 ? 8 : 4), r_bytes = (size_t)padded * 4, d_bytes = (size_t)padded;
+        const size_t a_bytes = (size_t)padded * 4, o_bytes = (size_t)padded * d.obs_dim * esz, r_bytes = (size_t)padded * 4, d_bytes = (size_t)padded;
         if (hipHostMalloc(&h->hm_block, a_bytes + o_bytes + r_bytes + d_bytes, hipHostMallocMapped) == hipSuccess) {
             char *b = static_cast<char *>(h->hm_block);
-            h->hm_actions = b; h->hm_obs = reinterpret_cast<float *>(b + a_bytes);
+            h->hm_actions = b; h->hm_obs = b + a_bytes;
             h->hm_reward = reinterpret_cast<float *>(b + a_bytes + o_bytes); h->hm_done = reinterpret_cast<uint8_t *>(b + a_bytes + o_bytes + r_bytes);
         } else {
             (void)hipGetLastError();
@@ -694,12 +706,13 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         }
     }
     if (d.has_sbd && !h->autoreset) CREATE_TRY(dalloc(h, &h->d_sbd, (size_t)padded));
-    if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, &h->d_final_obs, (size_t)h->n * d.obs_dim));
+    if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, (char **)&h->d_final_obs, (size_t)h->n * d.obs_dim * esz));
     if (cfg->flags & GYMNET_FLAG_DONE_LIST) {
-        // segment capacity: the most lanes the waves of one shard can own, for either lane width (dwordx4 / scalar)
-        const int64_t w4 = (h->n + 255) / 256, w1 = (h->n + 63) / 64;
-        const int64_t cap4 = (w4 + kShards - 1) / kShards * 256, cap1 = (w1 + kShards - 1) / kShards * 64;
+        // segment capacity: the most lanes the waves of one shard can own, for any lane width (4 / 2 / 1 lanes per thread)
+        const int64_t w4 = (h->n + 255) / 256, w2 = (h->n + 127) / 128, w1 = (h->n + 63) / 64;
+        const int64_t cap4 = (w4 + kShards - 1) / kShards * 256, cap2 = (w2 + kShards - 1) / kShards * 128, cap1 = (w1 + kShards - 1) / kShards * 64;
         h->done_cap = cap4 > cap1 ? cap4 : cap1;
+        if (cap2 > h->done_cap) h->done_cap = cap2;
         CREATE_TRY(dalloc(h, &h->d_done_list, (size_t)kShards * (size_t)h->done_cap));
         CREATE_TRY(dalloc(h, &h->d_done_compact, (size_t)padded));
         CREATE_TRY(dalloc(h, &h->d_done_count2, (size_t)2 * kShards * kCountStride));
@@ -712,7 +725,7 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         CREATE_TRY(dalloc(h, &h->d_rec_len, (size_t)kShards * (size_t)h->done_cap));
     }
     if ((cfg->flags & GYMNET_FLAG_DONE_LIST) && (cfg->flags & GYMNET_FLAG_FINAL_OBS))
-        CREATE_TRY(dalloc(h, &h->d_rec_obs, (size_t)kShards * (size_t)h->done_cap * d.obs_dim));
+        CREATE_TRY(dalloc(h, (char **)&h->d_rec_obs, (size_t)kShards * (size_t)h->done_cap * d.obs_dim * esz));
     if (cfg->flags & GYMNET_FLAG_EPISODE_STATS) {
         CREATE_TRY(dalloc(h, &h->d_ep_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_ep_len, (size_t)padded));
         CREATE_TRY(dalloc(h, &h->d_fin_ret, (size_t)padded)); CREATE_TRY(dalloc(h, &h->d_fin_len, (size_t)padded));
@@ -723,14 +736,13 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     }
     recompute_extras(h);
     // defined start: zero state, reward, done; sbd = -1
-    if (h->f64) CREATE_HIP(hipMemsetAsync(h->d_state64, 0, (size_t)padded * d.state_dim * 8, h->stream));
-    else CREATE_HIP(hipMemsetAsync(h->d_state, 0, (size_t)h->sstride * (d.state_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
-    if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
-    if (h->d_obs_alt) CREATE_HIP(hipMemsetAsync(h->d_obs_alt, 0, (size_t)h->ostride * (d.obs_dim - 1) * 4 + (size_t)h->n * 4, h->stream));
+    CREATE_HIP(hipMemsetAsync(h->d_state, 0, ((size_t)h->sstride * (d.state_dim - 1) + (size_t)h->n) * esz, h->stream));
+    if (!d.alias) CREATE_HIP(hipMemsetAsync(h->d_obs, 0, ((size_t)h->ostride * (d.obs_dim - 1) + (size_t)h->n) * esz, h->stream));
+    if (h->d_obs_alt) CREATE_HIP(hipMemsetAsync(h->d_obs_alt, 0, ((size_t)h->ostride * (d.obs_dim - 1) + (size_t)h->n) * esz, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_reward, 0, (size_t)padded * 4, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_done, 0, (size_t)padded, h->stream));
     CREATE_HIP(hipMemsetAsync(h->d_after_done, 0, (size_t)kShards * kAfterStride * sizeof(unsigned long long), h->stream));
-    if (h->d_final_obs) CREATE_HIP(hipMemsetAsync(h->d_final_obs, 0, (size_t)h->n * d.obs_dim * 4, h->stream));
+    if (h->d_final_obs) CREATE_HIP(hipMemsetAsync(h->d_final_obs, 0, (size_t)h->n * d.obs_dim * esz, h->stream));
     if (h->d_sbd) CREATE_HIP(launch_fill_i32(h->d_sbd, -1, h->n, h->stream));
     CREATE_TRY(write_tick(h));
 
@@ -821,13 +833,13 @@ int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, void **obs, flo
     if (!h->pin_block) {
         const EnvDesc &d = *h->desc;
         auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };          // every buffer on its own page
-        const size_t a_b = up((size_t)h->n * 4), o_b = up((size_t)h->n * d.obs_dim * (h->f64 ? 8 : 4)), r_b = up((size_t)h->n * 4), d_b = up((size_t)h->n);
+        const size_t a_b = up((size_t)h->n * 4), o_b = up((size_t)h->n * d.obs_dim * h->esz), r_b = up((size_t)h->n * 4), d_b = up((size_t)h->n);
         void *blk = nullptr;
         hipError_t e = hipHostMalloc(&blk, a_b + o_b + r_b + d_b, hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, GYMNET_ERR_OOM, "hipHostMalloc(%zu bytes, mapped) failed: %s", a_b + o_b + r_b + d_b, hipGetErrorString(e)); }
         std::memset(blk, 0, a_b + o_b + r_b + d_b);
         char *b = static_cast<char *>(blk);
-        h->pin_block = blk; h->pin_actions = b; h->pin_obs = reinterpret_cast<float *>(b + a_b);
+        h->pin_block = blk; h->pin_actions = b; h->pin_obs = b + a_b;
         h->pin_reward = reinterpret_cast<float *>(b + a_b + o_b); h->pin_done = reinterpret_cast<uint8_t *>(b + a_b + o_b + r_b);
     }
     if (actions) *actions = h->pin_actions;
@@ -925,28 +937,25 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
     if (h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no DONE_LIST / EPISODE_STATS / FINAL_OBS / per-lane-seed variant");
     if (h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device");
     if (steps == 0) return GYMNET_OK;
+    LaunchCfg cfg = h->lcfg;
+    // wide accesses on the recorded streams: 16-byte rows of observations (4 floats / 2 doubles per thread), vec rewards, vec done bytes
+    const int w = cfg.vec > 1 ? cfg.vec : 1;
+    const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned_to(rec->d_reward, 4 * w)) &&
+                                 (!rec->d_done || aligned_to(rec->d_done, w)));
+    if (cfg.vec > 1 && (!aligned_to(d_actions, 4 * cfg.vec) || (action_stride % cfg.vec) != 0 || (h->n % cfg.vec) != 0 || !rec_ok)) cfg.vec = 1;
     if (h->f64) {       // float64 handle: rec->d_obs holds doubles, [steps][4][num_envs]
-        const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned_to(rec->d_reward, 8)) &&
-                                     (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 1u) == 0));
-        int vec = h->lcfg.vec == 2 ? 2 : 1;
-        if (vec == 2 && (!aligned_to(d_actions, 8) || (action_stride % 2) != 0 || (h->n % 2) != 0 || !rec_ok)) vec = 1;
-        StepArgs64 a = make_step_args64(h, d_actions);
-        RolloutArgs64 r{};
+        const StepArgsT<double> a = make_step_args<double>(h, d_actions);
+        RolloutArgsT<double> r{};
         r.steps = steps; r.action_stride = action_stride; r.ring = ring;
         if (rec) { r.rec_obs = static_cast<double *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
-        HIP_TRY(h, launch_rollout_fused_f64(h->autoreset, a, r, vec, h->stream));
-        h->tick += (uint64_t)steps; h->tslot ^= 1; h->step_launches += 1; h->lane_steps += (uint64_t)steps * (uint64_t)h->n;
-        return GYMNET_OK;
+        HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
+    } else {
+        const StepArgsT<float> a = make_step_args<float>(h, d_actions);
+        RolloutArgsT<float> r{};
+        r.steps = steps; r.action_stride = action_stride; r.ring = ring;
+        if (rec) { r.rec_obs = static_cast<float *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
+        HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
     }
-    LaunchCfg cfg = h->lcfg;
-    const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned16(rec->d_reward)) &&
-                                 (!rec->d_done || (reinterpret_cast<uintptr_t>(rec->d_done) & 3u) == 0));
-    if (cfg.vec > 1 && (!aligned_to(d_actions, 4 * cfg.vec) || (action_stride % cfg.vec) != 0 || (h->n % cfg.vec) != 0 || !rec_ok)) cfg.vec = 1;
-    StepArgs a = make_step_args(h, d_actions);
-    RolloutArgs r{};
-    r.steps = steps; r.action_stride = action_stride; r.ring = ring;
-    if (rec) { r.rec_obs = static_cast<float *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
-    HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
     swap_buffers(h);                     // DOUBLE_BUFFER: the launch read one buffer and wrote the other, once
     h->tick += (uint64_t)steps;
     h->tslot ^= 1;                       // one launch: it read one half of d_tick2 and wrote the other
@@ -961,11 +970,7 @@ int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, void *d_obs_rowmajor) {
     ENTER(h);
     if (!d_obs_rowmajor) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor is null");
     if (!aligned16(d_obs_rowmajor)) return fail(h, GYMNET_ERR_INVALID_ARG, "d_obs_rowmajor must be 16-byte aligned");
-    if (h->f64) {
-        HIP_TRY(h, launch_pack_obs_f64(h->desc->obs_dim, h->d_state64, h->sstride, static_cast<double *>(d_obs_rowmajor), h->n, h->stream));
-        return GYMNET_OK;
-    }
-    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_obs, h->ostride, static_cast<float *>(d_obs_rowmajor), h->n, h->stream));
+    HIP_TRY(h, pack_current_obs(h, h->d_obs, h->ostride, d_obs_rowmajor));
     return GYMNET_OK;
     });
 }
@@ -985,7 +990,7 @@ int gymnet_vecenv_device_view(gymnet_vecenv *h, gymnet_device_view *out) {
     out->struct_size = sizeof *out;
     out->state_dim = h->desc->state_dim; out->obs_dim = h->desc->obs_dim; out->obs_aliases_state = h->desc->alias;
     out->num_envs = h->n; out->state_stride = h->sstride; out->obs_stride = h->ostride;
-    out->d_state = h->f64 ? (void *)h->d_state64 : (void *)h->d_state; out->d_obs = h->f64 ? (void *)h->d_state64 : (void *)h->d_obs;
+    out->d_state = h->d_state; out->d_obs = h->d_obs;
     out->state_dtype = h->f64 ? GYMNET_DTYPE_F64 : GYMNET_DTYPE_F32;
     out->d_reward = h->d_reward; out->d_done = h->d_done;
     out->d_steps_beyond_done = h->d_sbd; out->d_final_obs = h->d_final_obs; out->d_done_list = h->d_done_compact;
@@ -1004,10 +1009,10 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
     if (vec) *vec = h->lcfg.vec;
     if (block) *block = h->lcfg.block;
     if (nt) *nt = h->lcfg.nt;
-    if (sequential_lanes) {
-        const int it = h->lcfg.items;
-        if (h->f64) *sequential_lanes = (it > 1 && it <= 4 && !h->extras && h->lcfg.vec == 2 && h->n % (2 * (int64_t)it * 256) == 0) ? it : 1;   // lane PAIRS per thread
-        else *sequential_lanes = (h->cfg.env_id == GYMNET_ENV_ACROBOT && it > 1 && h->lcfg.vec == 1 && !h->extras) ? it : 1;
+    if (sequential_lanes) {      // what the launcher resolves to (lanes, or lane pairs, a thread works through one after another)
+        int rvec = 1, rseq = 1;
+        resolved_step_shape(h->cfg.env_id, h->f64, h->autoreset, h->extras, h->lcfg, h->n, &rvec, &rseq);
+        *sequential_lanes = rseq;
     }
     return GYMNET_OK;
     });
@@ -1016,8 +1021,7 @@ int gymnet_vecenv_launch_policy(gymnet_vecenv *h, int32_t *vec, int32_t *block, 
 int gymnet_vecenv_kernel_name(gymnet_vecenv *h, char *buf, int32_t capacity) {
     return guarded([&]() -> int {
     if (!h || !buf || capacity < 1) return fail(h, GYMNET_ERR_INVALID_ARG, "null handle / buffer");
-    if (h->f64) { describe_step_kernel_f64(h->autoreset, h->extras, h->lcfg.vec, h->lcfg.nt, h->lcfg.items, h->n, buf, (size_t)capacity); return GYMNET_OK; }
-    if (describe_step_kernel(h->cfg.env_id, h->autoreset, h->extras, h->lcfg, h->n, buf, (size_t)capacity) < 0)
+    if (describe_step_kernel(h->cfg.env_id, h->f64, h->autoreset, h->extras, h->lcfg, h->n, buf, (size_t)capacity) < 0)
         return fail(h, GYMNET_ERR_INVALID_ARG, "unknown env");
     return GYMNET_OK;
     });
@@ -1027,15 +1031,9 @@ int gymnet_vecenv_get_state(gymnet_vecenv *h, void *state_soa_v) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa_v) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
-    if (h->f64) {
-        HIP_TRY(h, hipMemcpy2DAsync(state_soa_v, (size_t)h->n * 8, h->d_state64, (size_t)h->sstride * 8, (size_t)h->n * 8, (size_t)h->desc->state_dim,
-                                    hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return GYMNET_OK;
-    }
-    float *state_soa = static_cast<float *>(state_soa_v);
+    const size_t row = (size_t)h->n * h->esz;
     for (int k = 0; k < h->desc->state_dim; ++k)      // row by row: a row the observation repeats lives in the observation array
-        HIP_TRY(h, hipMemcpyAsync(state_soa + (size_t)k * h->n, state_row(h, k), (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(static_cast<char *>(state_soa_v) + (size_t)k * row, state_row(h, k), row, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
     });
@@ -1045,17 +1043,11 @@ int gymnet_vecenv_set_state(gymnet_vecenv *h, const void *state_soa_v) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!state_soa_v) return fail(h, GYMNET_ERR_INVALID_ARG, "state_soa is null");
-    if (h->f64) {
-        HIP_TRY(h, hipMemcpy2DAsync(h->d_state64, (size_t)h->sstride * 8, state_soa_v, (size_t)h->n * 8, (size_t)h->n * 8, (size_t)h->desc->state_dim,
-                                    hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return GYMNET_OK;
-    }
-    const float *state_soa = static_cast<const float *>(state_soa_v);
+    const size_t row = (size_t)h->n * h->esz;
     for (int k = 0; k < h->desc->state_dim; ++k)
-        HIP_TRY(h, hipMemcpyAsync(state_row(h, k), state_soa + (size_t)k * h->n, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
-    if (!h->desc->alias)
-        HIP_TRY(h, launch_observe(h->cfg.env_id, h->d_state, h->sstride, h->d_obs, h->ostride, h->n, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(state_row(h, k), static_cast<const char *>(state_soa_v) + (size_t)k * row, row, hipMemcpyHostToDevice, h->stream));
+    if (!h->desc->alias)      // (float32 envs only: the float64 handle's observation IS its state)
+        HIP_TRY(h, launch_observe(h->cfg.env_id, static_cast<const float *>(h->d_state), h->sstride, static_cast<float *>(h->d_obs), h->ostride, h->n, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
     });
@@ -1156,7 +1148,7 @@ int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint
     });
 }
 
-int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, float *d_final_obs,
+int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, void *d_final_obs,
                                       int64_t capacity, uint32_t *d_count) {
     return guarded([&]() -> int {
     ENTER(h);
@@ -1169,7 +1161,7 @@ int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float 
     });
 }
 
-int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, float *final_obs_out,
+int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, void *final_obs_out,
                                int64_t capacity, int64_t *count) {
     return guarded([&]() -> int {
     ENTER(h);
@@ -1180,7 +1172,7 @@ int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *retu
     if (h->last_cparity < 0) { *count = 0; return GYMNET_OK; }
     const int O = h->desc->obs_dim;
     if ((return_out || length_out) && !h->d_rec_ret_c) { ST_TRY(dalloc(h, &h->d_rec_ret_c, (size_t)h->padded)); ST_TRY(dalloc(h, &h->d_rec_len_c, (size_t)h->padded)); }
-    if (final_obs_out && !h->d_rec_obs_c) ST_TRY(dalloc(h, &h->d_rec_obs_c, (size_t)h->padded * O));
+    if (final_obs_out && !h->d_rec_obs_c) ST_TRY(dalloc(h, (char **)&h->d_rec_obs_c, (size_t)h->padded * O * h->esz));
     ST_TRY(compact_done(h, h->d_done_compact, (return_out || length_out) ? h->d_rec_ret_c : nullptr, (return_out || length_out) ? h->d_rec_len_c : nullptr,
                         final_obs_out ? h->d_rec_obs_c : nullptr, h->padded, h->d_done_total));
     uint32_t c32 = 0;
@@ -1192,7 +1184,7 @@ int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *retu
         if (lanes_out) HIP_TRY(h, hipMemcpyAsync(lanes_out, h->d_done_compact, m * 4, hipMemcpyDeviceToHost, h->stream));
         if (return_out) HIP_TRY(h, hipMemcpyAsync(return_out, h->d_rec_ret_c, m * 4, hipMemcpyDeviceToHost, h->stream));
         if (length_out) HIP_TRY(h, hipMemcpyAsync(length_out, h->d_rec_len_c, m * 4, hipMemcpyDeviceToHost, h->stream));
-        if (final_obs_out) HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_rec_obs_c, m * O * 4, hipMemcpyDeviceToHost, h->stream));
+        if (final_obs_out) HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_rec_obs_c, m * O * h->esz, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return GYMNET_OK;
@@ -1212,15 +1204,15 @@ int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_
     });
 }
 
-int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out) {
+int gymnet_vecenv_final_obs(gymnet_vecenv *h, void *final_obs_out) {
     return guarded([&]() -> int {
     ENTER(h);
     if (!h->d_final_obs) return fail(h, GYMNET_ERR_UNSUPPORTED, "needs GYMNET_FLAG_FINAL_OBS");
     if (!final_obs_out) return fail(h, GYMNET_ERR_INVALID_ARG, "final_obs_out is null");
     if (h->compact_only && h->d_rec_obs && h->last_cparity >= 0) ST_TRY(compact_done(h, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true));
     ST_TRY(ensure_staging(h, false, true, false));
-    HIP_TRY(h, launch_pack_obs(h->desc->obs_dim, h->d_final_obs, h->n, h->d_pack, h->n, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, pack_current_obs(h, h->d_final_obs, h->n, h->d_pack));       // dense terminal observations [O][n] -> row-major
+    HIP_TRY(h, hipMemcpyAsync(final_obs_out, h->d_pack, (size_t)h->n * h->desc->obs_dim * h->esz, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return GYMNET_OK;
     });
@@ -1379,7 +1371,7 @@ ArrayRef array_ref(gymnet_vecenv *h, int which) {
         case GYMNET_ARRAY_EPISODE_LENGTH: return {h->d_ep_len, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
         case GYMNET_ARRAY_FINISHED_RETURN: return {h->d_fin_ret, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
         case GYMNET_ARRAY_FINISHED_LENGTH: return {h->d_fin_len, n * 4, 1, 0, "GYMNET_FLAG_EPISODE_STATS"};
-        case GYMNET_ARRAY_FINAL_OBS: return {h->d_final_obs, n * 4, h->desc->obs_dim, n * 4, "GYMNET_FLAG_FINAL_OBS"};
+        case GYMNET_ARRAY_FINAL_OBS: return {h->d_final_obs, n * h->esz, h->desc->obs_dim, n * h->esz, "GYMNET_FLAG_FINAL_OBS"};
         case GYMNET_ARRAY_LANE_SEEDS: return {h->d_lane_seed, n * 8, 1, 0, "per-lane seeds (gymnet_vecenv_seed_lanes)"};
         default: return {nullptr, 0, 0, 0, "a gymnet_array_id"};
     }

@@ -89,7 +89,22 @@ __host__ __device__ __forceinline__ double u01_53(uint32_t a, uint32_t b) {
 constexpr uint64_t kStreamReset64 = 0xC2B2AE3D27D4EB4Full;
 
 struct CartPole64 {
-    static constexpr int S = 4;
+    // the Env interface of step_kernels.hpp (see CartPole in envs.hpp), with the state scalar the reference uses
+    using Real = double;
+    using Action = int32_t;                  // Discrete(2)                      (:47)
+    static constexpr int S = 4;              // x, x_dot, theta, theta_dot       (:141-144)
+    static constexpr int O = 4;              // observation == state             (:166,185)
+    static constexpr bool OBS_ALIASES_STATE = true;
+    static constexpr bool HAS_SBD = true;    // steps_beyond_done state machine  (:41,168-183)
+    static constexpr bool BOX_ACTION = false;
+    static constexpr bool PACKED2 = false;
+    static constexpr bool PIPE_LANES = false;
+    static constexpr bool PIPE_PAIRS = true; // step_kernel_pipe2: ITEMS lane pairs per thread (13.1 vs 14.4 us at 2^20 lanes, round 4)
+    static constexpr bool RESET_TAKES_KEY = true;                   // reset() makes its own two Philox calls (53-bit uniforms)
+    static constexpr const char *NAME = "CartPole64";
+    static constexpr bool HAS_SMALL_ANGLE_PATH = true;
+    static constexpr int ANGLE_ROW = 2;
+    static constexpr double SMALL_ANGLE_BOUND = kSmallAngle64;
     // :24-36 — the float32 VALUES of the C# consts (total_mass, polemass_length const-folded in float), widened at use
     static constexpr float gravity = 9.8f;
     static constexpr float masspole = 0.1f;
@@ -103,7 +118,7 @@ struct CartPole64 {
 
     // :141-167, statement for statement; C#'s usual arithmetic conversions written out (float op double -> double)
     template <bool SMALL_ANGLE = false>
-    __device__ __forceinline__ static void step(double (&st)[S], int32_t a, bool &done) {
+    __device__ __forceinline__ static void step(double (&st)[S], int32_t a, float &reward, bool &done) {
         double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];                                  // :141-144
         const float force = a == 1 ? force_mag : -force_mag;                                                // :146
         double sintheta, costheta;
@@ -119,6 +134,7 @@ struct CartPole64 {
         st[0] = x; st[1] = x_dot; st[2] = theta; st[3] = theta_dot;                                         // :166
         done = x < -(double)x_threshold || x > (double)x_threshold
                || theta < -(double)theta_threshold || theta > (double)theta_threshold;                      // :167
+        reward = 1.0f;   // the steps_beyond_done rule (:168-183) is applied by the kernel, which owns sbd
     }
 
     // :63-67 — state = uniform(-0.05, 0.05, 4) in float64: low + (high - low) * u, u with 53 random bits
@@ -128,6 +144,12 @@ struct CartPole64 {
 #pragma unroll
         for (int k = 0; k < 4; ++k) st[k] = -0.05 + (0.05 - -0.05) * u01_53(a.w[k], b.w[k]);
     }
+
+    __device__ __forceinline__ static void observe(const double (&s)[S], double (&o)[O]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = s[k];
+    }
+    __device__ __forceinline__ static void observe_fresh(const double (&s)[S], double (&o)[O]) { observe(s, o); }
 };
 
 }  // namespace gymnet

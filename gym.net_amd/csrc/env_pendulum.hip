@@ -1,0 +1,7 @@
+// env_pendulum.hip — the step / fused-rollout / reset kernels of step_kernels.hpp instantiated for Pendulum:
+// Pendulum-v1 (absent from the reference; upstream gym).  One translation unit per env so the build compiles them side by side.
+#include "step_kernels.hpp"
+
+#include "envs.hpp"
+
+GYMNET_DEFINE_ENV(pendulum, gymnet::Pendulum)

@@ -176,8 +176,11 @@ struct CartPole {
     static constexpr bool HAS_SBD = true;    // steps_beyond_done state machine  (:41,168-183)
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = false;   // no two-lane packed-FP32 form (the kernel is memory-bound)
-    static constexpr bool PIPELINED = false; // no software-pipelined multi-lane kernel (ditto)
+    static constexpr bool PIPE_LANES = false, PIPE_PAIRS = false;   // no multi-lane kernel forms (ditto)
     using Action = int32_t;                  // Discrete(2)                      (:47)
+    using Real = float;                      // state scalar of this engine (CartPole64 in cartpole64.hpp: the reference's float64)
+    static constexpr bool RESET_TAKES_KEY = false;                  // reset() takes the four words of one Philox call
+    static constexpr const char *NAME = "CartPole";
 
     // :24-36 — the float32 values of the C# consts (total_mass, polemass_length const-folded in float)
     static constexpr float gravity = 9.8f;
@@ -195,6 +198,7 @@ struct CartPole {
     // The state component whose magnitude decides whether the step may use sincos_tiny (SMALL_ANGLE), and the bound
     static constexpr bool HAS_SMALL_ANGLE_PATH = true;
     static constexpr int ANGLE_ROW = 2;
+    static constexpr float SMALL_ANGLE_BOUND = kSmallAngle;
 
     // :146-167.  Any action != 1 pushes left (validity is only Debug.Assert'ed, :139).
     // SMALL_ANGLE: the caller guarantees |theta| <= kSmallAngle; the results are bit-identical either way (sincos_tiny).
@@ -259,9 +263,12 @@ struct Pendulum {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = true;
     static constexpr bool PACKED2 = false;
-    static constexpr bool PIPELINED = false;
+    static constexpr bool PIPE_LANES = false, PIPE_PAIRS = false;
     static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = float;                    // Box(-2, 2, (1,))
+    using Real = float;
+    static constexpr bool RESET_TAKES_KEY = false;
+    static constexpr const char *NAME = "Pendulum";
     static constexpr float PI = 3.14159265358979323846f;
 
     // fmodf(a, m) for the ONE modulus the env uses (m = 2 pi), in ~11 instructions instead of OCML's iterative reduction, and
@@ -329,9 +336,12 @@ struct MountainCar {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = false;
-    static constexpr bool PIPELINED = false;
+    static constexpr bool PIPE_LANES = false, PIPE_PAIRS = false;
     static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = int32_t;                  // Discrete(3)
+    using Real = float;
+    static constexpr bool RESET_TAKES_KEY = false;
+    static constexpr const char *NAME = "MountainCar";
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         float p = s[0], v = s[1];
@@ -370,9 +380,13 @@ struct Acrobot {
     static constexpr bool HAS_SBD = false;
     static constexpr bool BOX_ACTION = false;
     static constexpr bool PACKED2 = true;    // step_observe_x2: two envs per thread on v_pk_*_f32
-    static constexpr bool PIPELINED = true;  // step_kernel_pipe: ITEMS lanes per thread, loads / arithmetic / stores overlapped
+    static constexpr bool PIPE_LANES = true;  // step_kernel_pipe / _lds: ITEMS lanes per thread, loads / arithmetic / stores overlapped
+    static constexpr bool PIPE_PAIRS = true;  // step_kernel_pipe2: the same over lane pairs
     static constexpr bool HAS_SMALL_ANGLE_PATH = false;
     using Action = int32_t;                  // Discrete(3): torque = a - 1
+    using Real = float;
+    static constexpr bool RESET_TAKES_KEY = false;
+    static constexpr const char *NAME = "Acrobot";
     static constexpr float PI = 3.14159265358979323846f;
 
     // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals.

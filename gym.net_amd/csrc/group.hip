@@ -66,11 +66,12 @@ int load_rccl(RcclApi &r) {
 struct gymnet_group {
     gymnet_group_config cfg{};
     int G = 0, obs_dim = 0, nbuf = 1;
-    int64_t n_local = 0, slice = 0;            // slice = obs_dim * n_local floats
+    int64_t n_local = 0, slice = 0;            // slice = obs_dim * n_local observation ELEMENTS of one member
+    size_t esz = 4;                            // bytes per observation element: 4, or 8 for GYMNET_FLAG_F64 members
     bool overlap = false;
     std::vector<int> devices;
     std::vector<gymnet_vecenv *> members;
-    std::vector<float *> replica[2];           // [buffer][member] -> [G][D][n_local] on the member's device
+    std::vector<char *> replica[2];            // [buffer][member] -> [G][D][n_local] elements on the member's device
     std::vector<hipStream_t> gstream;          // per member: the stream its push / ncclAllGather runs on
     std::vector<hipEvent_t> ev_step, ev_push[2];
     hipStream_t join_stream = nullptr;         // on devices[0]
@@ -125,6 +126,8 @@ struct MembersBusy {
     } while (0)
 
 int buffer_of(gymnet_group *g) { return g->members[0]->cur; }
+// member m's slice inside a replica (bytes)
+inline size_t slice_bytes(const gymnet_group *g) { return (size_t)g->slice * g->esz; }
 
 // before member m's next step overwrites buffer b, its own push of b (which is reading the member's slice) must be done
 int guard_overwrite(gymnet_group *g, int b) {
@@ -164,11 +167,11 @@ int allgather(gymnet_group *g) {
     }
     if (g->cfg.gather == GYMNET_GATHER_DIRECT) {
         for (int m = 0; m < G; ++m) {
-            PushArgs a{};
-            a.src = g->replica[b][m] + (int64_t)m * g->slice;
-            a.count = g->slice;
+            PushArgs a{};            // the push moves 4-byte words: a float64 slice is two per element
+            a.src = reinterpret_cast<const float *>(g->replica[b][m] + (size_t)m * slice_bytes(g));
+            a.count = (int64_t)(slice_bytes(g) / 4);
             for (int p = 0; p < G; ++p)
-                if (p != m) a.dst[a.npeers++] = g->replica[b][p] + (int64_t)m * g->slice;
+                if (p != m) a.dst[a.npeers++] = reinterpret_cast<float *>(g->replica[b][p] + (size_t)m * slice_bytes(g));
             HIP_TRY(nullptr, hipSetDevice(g->devices[m]));
             HIP_TRY(nullptr, launch_push_obs(a, g->gstream[m]));
         }
@@ -176,8 +179,8 @@ int allgather(gymnet_group *g) {
         RCCL_TRY(g, g->rccl.GroupStart());
         for (int m = 0; m < G; ++m) {
             HIP_TRY(nullptr, hipSetDevice(g->devices[m]));
-            RCCL_TRY(g, g->rccl.AllGather(g->replica[b][m] + (int64_t)m * g->slice, g->replica[b][m], (size_t)g->slice, ncclFloat,
-                                          g->comms[m], g->gstream[m]));
+            RCCL_TRY(g, g->rccl.AllGather(g->replica[b][m] + (size_t)m * slice_bytes(g), g->replica[b][m], (size_t)g->slice,
+                                          g->esz == 8 ? ncclDouble : ncclFloat, g->comms[m], g->gstream[m]));
         }
         RCCL_TRY(g, g->rccl.GroupEnd());
         (void)hipGetLastError();      // see gymnet_group_create: RCCL may leave a stale HIP error behind
@@ -340,8 +343,8 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "global_num_envs %lld must be a positive multiple of num_members %d",
                     (long long)cfg->global_num_envs, G);
     if (cfg->gather < GYMNET_GATHER_NONE || cfg->gather > GYMNET_GATHER_RCCL) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "bad gather mode");
-    if (cfg->flags & GYMNET_FLAG_F64)
-        return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 handles keep their own float64 state arrays: they cannot be group members");
+    if ((cfg->flags & GYMNET_FLAG_F64) && cfg->env_id != GYMNET_ENV_CARTPOLE)
+        return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_F64 exists for CartPole only");
     int ndev = 0;
     ST_TRY(gymnet_device_count(&ndev));
 
@@ -354,6 +357,7 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
     g->obs_dim = kEnvs[cfg->env_id].obs_dim;
     g->n_local = cfg->global_num_envs / G;
     g->slice = (int64_t)g->obs_dim * g->n_local;
+    g->esz = (cfg->flags & GYMNET_FLAG_F64) ? 8 : 4;
     g->overlap = (cfg->flags & GYMNET_FLAG_DOUBLE_BUFFER) != 0;
     g->nbuf = g->overlap ? 2 : 1;
     g->devices.resize(G);
@@ -395,9 +399,9 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
         G_HIP(hipSetDevice(g->devices[m]));
         for (int b = 0; b < g->nbuf; ++b) {
             void *q = nullptr;
-            G_HIP(hipMalloc(&q, (size_t)G * (size_t)g->slice * sizeof(float)));
-            g->replica[b][m] = static_cast<float *>(q);
-            G_HIP(hipMemset(q, 0, (size_t)G * (size_t)g->slice * sizeof(float)));
+            G_HIP(hipMalloc(&q, (size_t)G * slice_bytes(g)));
+            g->replica[b][m] = static_cast<char *>(q);
+            G_HIP(hipMemset(q, 0, (size_t)G * slice_bytes(g)));
         }
         for (int b = 0; b < 2; ++b) G_HIP(hipEventCreateWithFlags(&g->ev_push[b][m], hipEventDisableTiming));
         G_HIP(hipEventCreateWithFlags(&g->ev_step[m], hipEventDisableTiming));
@@ -411,10 +415,10 @@ int gymnet_group_create(const gymnet_group_config *cfg, gymnet_group **out) {
         mc.flags = cfg->flags;
         mc.seed = cfg->seed;
         mc.stream = nullptr;
-        mc.d_ext_obs = g->replica[0][m] + (int64_t)m * g->slice;
+        mc.d_ext_obs = g->replica[0][m] + (size_t)m * slice_bytes(g);
         mc.ext_obs_stride = g->n_local;
         mc.max_episode_steps = cfg->max_episode_steps;
-        mc.d_ext_obs_alt = g->overlap ? g->replica[1][m] + (int64_t)m * g->slice : nullptr;
+        mc.d_ext_obs_alt = g->overlap ? g->replica[1][m] + (size_t)m * slice_bytes(g) : nullptr;
         int s = gymnet_vecenv_create(&mc, &g->members[m]);
         if (s != GYMNET_OK) { destroy_group(g); return s; }
     }
@@ -543,7 +547,7 @@ int gymnet_group_wait_gather(gymnet_group *g) {
     });
 }
 
-int gymnet_group_global_obs(gymnet_group *g, int32_t member, float **d_obs_all) {
+int gymnet_group_global_obs(gymnet_group *g, int32_t member, void **d_obs_all) {
     return guarded([&]() -> int {
     if (!g || !d_obs_all) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "null argument");
     if (member < 0 || member >= g->G) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "member %d not in [0, %d)", member, g->G);
@@ -552,7 +556,7 @@ int gymnet_group_global_obs(gymnet_group *g, int32_t member, float **d_obs_all) 
     });
 }
 
-int gymnet_group_read_replica(gymnet_group *g, int32_t member, float *replica_out) {
+int gymnet_group_read_replica(gymnet_group *g, int32_t member, void *replica_out) {
     return guarded([&]() -> int {
     GROUP_ENTER(g);
     if (!replica_out) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "replica_out is null");
@@ -561,7 +565,7 @@ int gymnet_group_read_replica(gymnet_group *g, int32_t member, float *replica_ou
     const int b = g->last_gathered < 0 ? buffer_of(g) : g->last_gathered;
     HIP_TRY(nullptr, hipSetDevice(g->devices[member]));
     hipStream_t st = g->members[member]->stream;
-    HIP_TRY(nullptr, hipMemcpyAsync(replica_out, g->replica[b][member], (size_t)g->G * (size_t)g->slice * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(nullptr, hipMemcpyAsync(replica_out, g->replica[b][member], (size_t)g->G * slice_bytes(g), hipMemcpyDeviceToHost, st));
     HIP_TRY(nullptr, hipStreamSynchronize(st));
     return GYMNET_OK;
     });
@@ -583,12 +587,12 @@ int gymnet_group_sync(gymnet_group *g) {
 
 // Host-boundary forms: the whole batch in NDArray layout.  Members are queued first and synchronized last, so the G GPUs
 // (and their PCIe links) work concurrently.
-static int group_copy_out(gymnet_group *g, float *obs_out, float *reward_out, uint8_t *done_out) {
+static int group_copy_out(gymnet_group *g, void *obs_out, float *reward_out, uint8_t *done_out) {
     const int64_t n = g->n_local;
     for (int m = 0; m < g->G; ++m) {
         HIP_TRY(nullptr, hipSetDevice(g->devices[m]));
         gymnet_vecenv *h = g->members[m];
-        float *o = obs_out ? obs_out + (size_t)m * n * g->obs_dim : nullptr;
+        void *o = obs_out ? static_cast<char *>(obs_out) + (size_t)m * n * g->obs_dim * g->esz : nullptr;
         float *r = reward_out ? reward_out + (size_t)m * n : nullptr;
         uint8_t *d = done_out ? done_out + (size_t)m * n : nullptr;
         if (h->hm_block) ST_TRY(copy_out(h, o, r, d));
@@ -601,7 +605,7 @@ static int group_copy_out(gymnet_group *g, float *obs_out, float *reward_out, ui
     return GYMNET_OK;
 }
 
-int gymnet_group_reset(gymnet_group *g, float *obs_out) {
+int gymnet_group_reset(gymnet_group *g, void *obs_out) {
     return guarded([&]() -> int {
     GROUP_ENTER(g);
     ST_TRY(guard_overwrite(g, buffer_of(g)));
@@ -613,7 +617,7 @@ int gymnet_group_reset(gymnet_group *g, float *obs_out) {
     });
 }
 
-int gymnet_group_step(gymnet_group *g, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out) {
+int gymnet_group_step(gymnet_group *g, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
     GROUP_ENTER(g);
     if (!actions) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "actions is null");

@@ -48,15 +48,16 @@ struct gymnet_vecenv {
     bool own_stream = false;
     int64_t n = 0, padded = 0, sstride = 0, ostride = 0;
     bool autoreset = false, extras = false;
+    // The STATE SCALAR of the handle: float, or double with GYMNET_FLAG_F64 (CartPole only: the reference's own arithmetic,
+    // CartPoleEnv.cs:141-166,185).  Every buffer that holds state or observation values — d_state / d_obs and their double-buffer
+    // twins, the row-major staging, terminal observations and their compact records, the host-mapped observation staging — holds
+    // elements of that type; they are kept as void* here and typed where they are used (esz = element size in bytes).
+    bool f64 = false;
+    size_t esz = 4;
     // d_state / d_obs always point at the CURRENT (most recently written) buffers; with GYMNET_FLAG_DOUBLE_BUFFER
     // d_state_alt / d_obs_alt are what the next step writes, and the pairs swap after every step launch.
-    float *d_state = nullptr, *d_obs = nullptr;
-    float *d_state_alt = nullptr, *d_obs_alt = nullptr;
-    // GYMNET_FLAG_F64 (CartPole only): the state — which IS the observation — lives in d_state64 [4][sstride] as binary64 and
-    // d_state / d_obs stay NULL; every host-boundary buffer that carries observations or state then holds doubles.
-    bool f64 = false;
-    double *d_state64 = nullptr;
-    double *d_pack64 = nullptr;    // row-major staging of the float64 observations (allocated on first use)
+    void *d_state = nullptr, *d_obs = nullptr;
+    void *d_state_alt = nullptr, *d_obs_alt = nullptr;
     bool double_buffer = false;
     int cur = 0;                   // index of the buffer d_obs points at (0 = the one reset first wrote)
     float *d_reward = nullptr;
@@ -64,28 +65,31 @@ struct gymnet_vecenv {
     int32_t *d_sbd = nullptr;
     uint64_t *d_tick2 = nullptr;
     void *d_actions = nullptr;     // staging for host-path / broadcast actions   (allocated on first use)
-    float *d_pack = nullptr;       // row-major obs staging                       (allocated on first use)
-    float *d_final_obs = nullptr;
+    void *d_pack = nullptr;        // row-major obs staging                       (allocated on first use)
+    void *d_final_obs = nullptr;
     int32_t *d_done_list = nullptr, *d_done_compact = nullptr;    // sharded segments / compact list (on demand)
     uint32_t *d_done_count2 = nullptr, *d_done_total = nullptr;
     int64_t done_cap = 0;
     float *d_ep_ret = nullptr, *d_fin_ret = nullptr;
     int32_t *d_ep_len = nullptr, *d_fin_len = nullptr;
     // compact per-step records beside the sharded done list (DONE_LIST + EPISODE_STATS / FINAL_OBS), and their gathered copies
-    float *d_rec_ret = nullptr, *d_rec_obs = nullptr, *d_rec_ret_c = nullptr, *d_rec_obs_c = nullptr;
+    float *d_rec_ret = nullptr, *d_rec_ret_c = nullptr;
+    void *d_rec_obs = nullptr, *d_rec_obs_c = nullptr;
     int32_t *d_rec_len = nullptr, *d_rec_len_c = nullptr;
     uint64_t *d_lane_seed = nullptr;       // active per-lane keys (NULL = one key for all lanes)
     uint64_t *d_lane_seed_buf = nullptr;   // the one allocation Seed(int[]) reuses
     unsigned long long *d_after_done = nullptr;
     // small batches (n <= kSmallHostPath): host-mapped staging, so a host-boundary step is 2 kernel launches + 1 sync
     void *hm_actions = nullptr;    // pinned + mapped: the step kernel reads the actions straight from it
-    float *hm_obs = nullptr, *hm_reward = nullptr;
+    void *hm_obs = nullptr;
+    float *hm_reward = nullptr;
     uint8_t *hm_done = nullptr;
     void *hm_block = nullptr;
     // gymnet_vecenv_host_buffers: library-owned page-locked, device-mapped host buffers for the host-boundary path (any batch
     // size); the step's export kernel writes results straight into them, actions are DMA'd out of them
     void *pin_block = nullptr, *pin_actions = nullptr;
-    float *pin_obs = nullptr, *pin_reward = nullptr;
+    void *pin_obs = nullptr;
+    float *pin_reward = nullptr;
     uint8_t *pin_done = nullptr;
     uint32_t *d_bad = nullptr;
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
@@ -166,6 +170,12 @@ int guarded(F &&f) noexcept {
         return GYMNET_ERR_HIP;
     }
 }
+
+// address of row k of a [rows][stride] structure-of-arrays buffer of esz-byte elements
+inline void *row_at(void *base, int64_t k, int64_t stride, size_t esz) { return static_cast<char *>(base) + (size_t)k * (size_t)stride * esz; }
+// bytes one env-step of this handle moves by the algorithmic count: 41 for float32 CartPole, 73 in float64
+// (32 B state read + 4 B action + 32 B state written + 4 B reward + 1 B done)
+inline size_t bytes_per_step(const gymnet_vecenv *h) { return h->f64 ? (size_t)73 : (size_t)h->desc->algorithmic_bytes; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned_to(const void *p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }

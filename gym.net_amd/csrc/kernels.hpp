@@ -6,12 +6,16 @@
 namespace gymnet {
 
 // Everything one vector-step launch needs.  Passed by value (kernarg segment).
-struct StepArgs {
-    float *state;            // [S][state_stride]  structure-of-arrays, one env per lane (read)
-    float *state_out;        // where the new state is written: == state, or the OTHER half of a double-buffered pair
+// R is the STATE SCALAR of the handle: float (the batched engine's structure-of-arrays hot path) or double (GYMNET_FLAG_F64: the
+// reference's own arithmetic, CartPoleEnv.cs:141-166,185 — float64 state that IS the float64 observation).  Everything that holds a
+// state or observation value is typed R; reward (Step.cs:9: a C# float), done, the actions and all counters are the same for both.
+template <class R>
+struct StepArgsT {
+    R *state;                // [S][state_stride]  structure-of-arrays, one env per lane (read)
+    R *state_out;            // where the new state is written: == state, or the OTHER half of a double-buffered pair
                              // (GYMNET_FLAG_DOUBLE_BUFFER: step t+1 writes B while a gather of A is still in flight)
-    float *obs;              // [O][obs_stride]    (unused when the env's observation aliases its state)
-    const float *obs_in;     // the CURRENT observation buffer (== obs unless double-buffered): state rows the observation repeats
+    R *obs;                  // [O][obs_stride]    (unused when the env's observation aliases its state)
+    const R *obs_in;         // the CURRENT observation buffer (== obs unless double-buffered): state rows the observation repeats
                              // (Env::OBS_ROW_OF_STATE) are read from here — they have no row of their own in `state`
     const void *action;      // int32[n] (Discrete) or float32[n] (Box)
     float *reward;           // [n]
@@ -19,7 +23,7 @@ struct StepArgs {
     int32_t *sbd;            // [n] CartPole steps_beyond_done (CartPoleEnv.cs:41); NULL with auto-reset
     uint64_t *tick2;         // device tick, double-buffered: launch with tick t reads tick2[t&1], writes tick2[(t+1)&1]=t+1
     // extras (all NULL / 0 in the lean hot-path variant)
-    float *final_obs;        // [O][n] dense terminal observations; NULL = none kept / compact records only
+    R *final_obs;            // [O][n] dense terminal observations; NULL = none kept / compact records only
     // Done-lane compaction is SHARDED: 4096 waves hammering one counter word serialise at ~88 atomics/us (46 us per
     // step at 2^20 lanes, measured); wave w appends to shard w % kShards, each shard has its own counter (64-byte
     // stride) and its own segment of the list.  compact_done gathers the segments into one list on demand.
@@ -30,7 +34,7 @@ struct StepArgs {
     float *fin_ret; int32_t *fin_len;   // dense last-finished-episode arrays; NULL = compact records only (with done_list)
     // compact records, segmented like done_list (position p of shard s = the lane at done_list[s * done_cap + p]):
     float *rec_ret; int32_t *rec_len;   // [kShards][done_cap]     finished episode's return / length   (EPISODE_STATS + DONE_LIST)
-    float *rec_obs;                     // [kShards][O][done_cap]  terminal observation                  (FINAL_OBS + DONE_LIST)
+    R *rec_obs;                         // [kShards][O][done_cap]  terminal observation                  (FINAL_OBS + DONE_LIST)
     const uint64_t *lane_seed;       // [n] per-lane Philox keys (VecEnv.Seed(int[])) or NULL
     unsigned long long *after_done;  // [kShards * kAfterStride] sharded counter: steps taken on already-done lanes (CartPoleEnv.cs:176-179)
     int64_t n, state_stride, obs_stride;
@@ -39,6 +43,8 @@ struct StepArgs {
     int32_t cparity;         // (number of step launches so far) & 1: which done_count2 slot this launch fills
     int32_t max_episode_steps;
 };
+typedef StepArgsT<float> StepArgs;
+typedef StepArgsT<double> StepArgs64;
 
 // vec: envs per thread (4 = dwordx4 streams, 1 = scalar); block: threads per workgroup;
 // nt: non-temporal mask (0 none, 12 action + reward/done streams, 15 every stream)
@@ -53,71 +59,31 @@ constexpr int kAfterStride = 8;     // uint64 words between after_done shards (6
 // lds_pipe: 1 = the multi-lane kernel in its producer / consumer form (step_kernel_lds: `items` tiles per workgroup)
 struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; int lds_pipe = 0; };
 
-// env_id: gymnet_env_id.  autoreset / extras select the compiled variant.  Returns hipError_t.
-hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgs &a, LaunchCfg cfg, hipStream_t st);
-
-// The template instantiation launch_step would run for this configuration, as text ("step_kernel<CartPole,4,true,false,15,1>");
-// returns the length, or < 0 for an unknown env.  n: the batch size (one form needs whole 2 * items * 256-lane groups).
-int describe_step_kernel(int env_id, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap);
-
-// ---- GYMNET_FLAG_F64: CartPole in the reference's own binary64 arithmetic (cartpole64.hpp, kernels64.hip) ------------------
-// 73 B per env-step: 32 B state read + 4 B action + 32 B state written (the observation IS the state) + 4 B reward + 1 B done.
-struct StepArgs64 {
-    double *state;           // [4][stride]  x, x_dot, theta, theta_dot (CartPoleEnv.cs:141-144), read and written in place
-    const int32_t *action;   // [n]
-    float *reward;           // [n]   (Step.Reward is a C# float, Step.cs:9)
-    uint8_t *done;           // [n]
-    int32_t *sbd;            // [n] steps_beyond_done (CartPoleEnv.cs:41); NULL with auto-reset
-    uint64_t *tick2;         // as StepArgs
-    float *ep_ret; int32_t *ep_len; float *fin_ret; int32_t *fin_len;   // EPISODE_STATS (NULL without)
-    const uint64_t *lane_seed;
-    unsigned long long *after_done;
-    int64_t n, stride;
-    uint64_t lane_offset, seed;
-    int32_t parity, max_episode_steps;
-};
-// vec: 2 (16-byte accesses on the state rows) or 1; nt as LaunchCfg::nt; items: lane pairs per thread of the multi-item kernel
-// (2..4: lean variant, vec 2, n a multiple of 2 * items * 256 — else the one-shot kernel runs)
-hipError_t launch_step_f64(bool autoreset, bool extras, const StepArgs64 &a, int vec, int nt, int items, hipStream_t st);
-int describe_step_kernel_f64(bool autoreset, bool extras, int vec, int nt, int items, int64_t n, char *buf, size_t cap);
-struct ResetArgs64 {
-    double *state; int32_t *sbd; uint8_t *done;
-    const uint8_t *mask;      // NULL = all lanes
-    uint64_t *tick2; const uint64_t *lane_seed;
-    float *ep_ret; int32_t *ep_len;
-    int64_t n, stride;
-    uint64_t lane_offset, seed;
-    int32_t parity;
-};
-hipError_t launch_reset_f64(const ResetArgs64 &a, hipStream_t st);
-// Fused multi-step rollout of a float64 handle: `steps` vector steps inside ONE launch, state in registers between steps; bitwise the
-// same results as `steps` launch_step_f64 calls.  Lean variant only.  rec_obs: optional [T][4][n] doubles.
-struct RolloutArgs64 {
-    int64_t steps, action_stride, ring;
-    double *rec_obs; float *rec_reward; uint8_t *rec_done;
-};
-hipError_t launch_rollout_fused_f64(bool autoreset, const StepArgs64 &a, const RolloutArgs64 &r, int vec, hipStream_t st);
-// float64 twins of launch_pack_obs / launch_export_small / launch_export_host (obs_dim 4 only: CartPole)
-hipError_t launch_pack_obs_f64(int obs_dim, const double *obs, int64_t stride, double *out_rowmajor, int64_t n, hipStream_t st);
-hipError_t launch_export_small_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
-                                   double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
-hipError_t launch_export_host_f64(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
-                                  double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
+// ---- env-dependent launchers: one translation unit per env (env_*.hip, GYMNET_DEFINE_ENV in step_kernels.hpp) ---------------
+#define GYMNET_DECLARE_ENV(tag, R)                                                                                              \
+    hipError_t launch_step_##tag(bool autoreset, bool extras, const StepArgsT<R> &a, LaunchCfg cfg, hipStream_t st);            \
+    int describe_step_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap);                      \
+    void resolved_shape_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential);                \
+    hipError_t launch_rollout_##tag(bool autoreset, const StepArgsT<R> &a, const RolloutArgsT<R> &r, LaunchCfg cfg, hipStream_t st); \
+    hipError_t launch_reset_##tag(const ResetArgsT<R> &a, hipStream_t st);                                                      \
+    hipError_t launch_observe_##tag(const R *state, int64_t sstride, R *obs, int64_t ostride, int64_t n, hipStream_t st);
 
 // Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
-struct RolloutArgs {
+template <class R>
+struct RolloutArgsT {
     int64_t steps;           // T
     int64_t action_stride;   // elements between consecutive action slices
     int64_t ring;            // step t reads slice t % ring
-    float *rec_obs;          // optional [T][O][n]   (NULL = do not record)
+    R *rec_obs;              // optional [T][O][n]   (NULL = do not record)
     float *rec_reward;       // optional [T][n]
     uint8_t *rec_done;       // optional [T][n]
 };
-// Same results as `steps` launch_step calls (bitwise).  Only the lean variant (no EXTRAS) is fused.
-hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgs &a, const RolloutArgs &r, LaunchCfg cfg, hipStream_t st);
+typedef RolloutArgsT<float> RolloutArgs;
+typedef RolloutArgsT<double> RolloutArgs64;
 
-struct ResetArgs {
-    float *state; float *obs; int32_t *sbd; uint8_t *done;   // done flags cleared for reset lanes
+template <class R>
+struct ResetArgsT {
+    R *state; R *obs; int32_t *sbd; uint8_t *done;   // done flags cleared for reset lanes
     const uint8_t *mask;      // NULL = all lanes
     uint64_t *tick2; const uint64_t *lane_seed;
     float *ep_ret; int32_t *ep_len;
@@ -125,18 +91,49 @@ struct ResetArgs {
     uint64_t lane_offset, seed;
     int32_t parity;
 };
-hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t st);
+typedef ResetArgsT<float> ResetArgs;
+typedef ResetArgsT<double> ResetArgs64;
 
-// observations: SoA [O][stride] -> row-major [n][O]
+GYMNET_DECLARE_ENV(cartpole, float)
+GYMNET_DECLARE_ENV(pendulum, float)
+GYMNET_DECLARE_ENV(mountaincar, float)
+GYMNET_DECLARE_ENV(acrobot, float)
+GYMNET_DECLARE_ENV(cartpole64, double)      // GYMNET_FLAG_F64: CartPole in the reference's own binary64 arithmetic (cartpole64.hpp)
+
+// env_id: gymnet_env_id; the state scalar of the arguments selects the float32 engine or (env 0 only) the float64 one.
+// autoreset / extras select the compiled variant.  Returns hipError_t.
+hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, LaunchCfg cfg, hipStream_t st);
+hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgsT<double> &a, LaunchCfg cfg, hipStream_t st);
+
+// The template instantiation launch_step would run for this configuration, as text ("step_kernel<CartPole,4,true,false,15,1>");
+// returns the length, or < 0 for an unknown env.  n: the batch size (one form needs whole 2 * items * 256-lane groups).
+int describe_step_kernel(int env_id, bool f64, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap);
+// what that instantiation is shaped like: lanes per thread on its wide accesses, and lanes (or lane pairs) a thread works through
+// one after another in the multi-lane forms (1 = one-shot kernel)
+void resolved_step_shape(int env_id, bool f64, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential);
+
+// Same results as `steps` launch_step calls (bitwise).
+hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<float> &a, const RolloutArgsT<float> &r, LaunchCfg cfg, hipStream_t st);
+hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<double> &a, const RolloutArgsT<double> &r, LaunchCfg cfg, hipStream_t st);
+
+hipError_t launch_reset(int env_id, const ResetArgsT<float> &a, hipStream_t st);
+hipError_t launch_reset(int env_id, const ResetArgsT<double> &a, hipStream_t st);
+
+// observations: SoA [O][stride] -> row-major [n][O]; float32, or float64 for a GYMNET_FLAG_F64 handle (here and below)
 hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float *out_rowmajor, int64_t n, hipStream_t st);
+hipError_t launch_pack_obs(int obs_dim, const double *obs, int64_t stride, double *out_rowmajor, int64_t n, hipStream_t st);
 // small batches at the host boundary: obs (row-major), reward and done written straight into ONE host-mapped buffer
 // [n*O floats | n floats | n bytes] by a single kernel — no device-to-host memcpy calls on the latency path
 hipError_t launch_export_small(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
                                float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
+hipError_t launch_export_small(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                               double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
 // any batch size: obs (row-major), reward, done written straight into page-locked device-mapped HOST memory (the stores are the
 // PCIe transfer); any out pointer may be NULL
 hipError_t launch_export_host(int obs_dim, const float *obs, int64_t stride, const float *reward, const uint8_t *done,
                               float *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
+hipError_t launch_export_host(int obs_dim, const double *obs, int64_t stride, const float *reward, const uint8_t *done,
+                              double *out_obs, float *out_reward, uint8_t *out_done, int64_t n, hipStream_t st);
 // recompute obs from state (after set_state) for envs whose observation is derived
 hipError_t launch_observe(int env_id, const float *state, int64_t state_stride, float *obs, int64_t obs_stride,
                           int64_t n, hipStream_t st);
@@ -144,15 +141,18 @@ hipError_t launch_fill_i32(int32_t *p, int32_t v, int64_t n, hipStream_t st);
 // Gathers the sharded done list of one step (counter half `counts`) and the records written beside it into compact arrays
 // out_*[0 .. *out_count) (entries beyond out_capacity are dropped; the count is the true one), and / or applies the records to
 // the dense per-lane arrays.  Every out / dense / rec pointer may be NULL.
-struct CompactArgs {
+template <class R>
+struct CompactArgsT {
     const uint32_t *counts; const int32_t *list; int64_t cap;
-    const float *rec_ret; const int32_t *rec_len; const float *rec_obs; int32_t obs_dim;
-    int32_t *out_list; float *out_ret; int32_t *out_len; float *out_obs;   // out_obs: row-major [count][obs_dim]
+    const float *rec_ret; const int32_t *rec_len; const R *rec_obs; int32_t obs_dim;
+    int32_t *out_list; float *out_ret; int32_t *out_len; R *out_obs;       // out_obs: row-major [count][obs_dim]
     int64_t out_capacity;
     uint32_t *out_count;
-    float *dense_ret; int32_t *dense_len; float *dense_obs; int64_t n;     // dense_obs: [obs_dim][n]
+    float *dense_ret; int32_t *dense_len; R *dense_obs; int64_t n;         // dense_obs: [obs_dim][n]
 };
-hipError_t launch_compact_done(const CompactArgs &a, hipStream_t st);
+typedef CompactArgsT<float> CompactArgs;
+hipError_t launch_compact_done(const CompactArgsT<float> &a, hipStream_t st);
+hipError_t launch_compact_done(const CompactArgsT<double> &a, hipStream_t st);
 // counts actions outside [0, nvals) into *bad
 hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, uint32_t *bad, hipStream_t st);
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
@@ -160,7 +160,7 @@ hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_
 // Discrete.Sample(mask) (Discrete.cs:18-26): mask uint8 [n][nvals] (mask_stride = nvals) or one row for every lane (mask_stride = 0)
 hipError_t launch_sample_discrete_masked(int32_t *out, int64_t n, int32_t nvals, int32_t start, const uint8_t *mask,
                                          int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick, hipStream_t st);
-// Direct all-gather, push form: copies `count` floats from src to the same offset inside each of `npeers` peer buffers
+// Direct all-gather, push form: copies `count` 4-byte words (floats; a float64 slice counts two per element) from src to the same offset inside each of `npeers` peer buffers
 // (peer-mapped device memory reached over xGMI, or buffers on the same device for logical shards).
 constexpr int kMaxPeers = 15;
 struct PushArgs { const float *src; float *dst[kMaxPeers]; int64_t count; int32_t npeers; };

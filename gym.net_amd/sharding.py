@@ -55,10 +55,10 @@ class ShardPlan:
         return r, global_lane - self.offset(r)
 
 
-def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream, ext_obs_alt=None):
+def _hip_local_env(env, num_envs, lane_offset, seed, auto_reset, ext_obs, ext_obs_stride, device, stream, ext_obs_alt=None, dtype="float32"):
     return VectorEnv(env, num_envs, device=device, seed=seed, auto_reset=auto_reset, lane_offset=lane_offset,
                      ext_obs=ext_obs, ext_obs_stride=ext_obs_stride, stream=stream,
-                     double_buffer=ext_obs_alt is not None, ext_obs_alt=ext_obs_alt)
+                     double_buffer=ext_obs_alt is not None, ext_obs_alt=ext_obs_alt, dtype=dtype)
 
 
 class ShardedVectorEnv:
@@ -73,6 +73,9 @@ class ShardedVectorEnv:
     t+1 writes the other one while the all-gather of step t's buffer is still in flight on a side stream, so a
     consumer that wants every rank to see all observations pays max(step, gather) per step instead of step + gather.
 
+    dtype="float64" (CartPole) shards the reference-arithmetic mode (GYMNET_FLAG_F64, CartPoleEnv.cs:141-166,185): the gather
+    buffers hold doubles — 32 MiB per rank at N = 2^23, G = 8 instead of 16 — and everything else is unchanged.
+
     local_env_factory exists so the host-side sharding logic can be exercised without a GPU (the
     CPU tests inject an oracle-backed stand-in); the default — and the only thing the product ever
     uses — is the HIP VectorEnv.
@@ -80,10 +83,16 @@ class ShardedVectorEnv:
 
     def __init__(self, env, global_num_envs, rank=None, world_size=None, device=None, seed=0, auto_reset=True,
                  gather_obs=True, process_group=None, local_env_factory=None, tensor_device=None, force_gather=False,
-                 overlap=False, gather="rccl", barrier=None):
+                 overlap=False, gather="rccl", barrier=None, dtype="float32"):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
+        import numpy as np
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self._tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        self._esz = self.dtype.itemsize
         self.group = process_group
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -121,12 +130,14 @@ class ShardedVectorEnv:
         if self.gather == "direct":
             self.obs_bufs = self._make_peer_buffers(shape, device)
         else:
-            self.obs_bufs = torch.zeros(shape, dtype=torch.float32, device=self.tensor_device)
+            self.obs_bufs = torch.zeros(shape, dtype=self._tdtype, device=self.tensor_device)
         self.obs_all = self.obs_bufs[0]
         stream = None
         if self._cuda:
             stream = torch.cuda.current_stream(self.tensor_device).cuda_stream
         kw = {"ext_obs_alt": self.obs_bufs[1][self.rank].data_ptr()} if self.overlap else {}
+        if self.dtype == np.float64:
+            kw["dtype"] = "float64"            # (only passed when asked for: stand-in factories of older tests take no dtype)
         self.local = factory(env, n_local, self.lane_offset, seed, auto_reset, self.obs_bufs[0][self.rank].data_ptr(),
                              n_local, device, stream, **kw)
         self._work = None
@@ -145,7 +156,7 @@ class ShardedVectorEnv:
         from . import _capi
         torch, dist = self._torch, self._dist
         lib = _capi.load_library()
-        nbytes = int(np.prod(shape)) * 4
+        nbytes = int(np.prod(shape)) * self._esz
         base, handle = C.c_void_p(), _capi.IpcHandle()
         self._peer_dev, self._lib, self._peers = int(device), lib, {}
 
@@ -192,7 +203,7 @@ class ShardedVectorEnv:
             raise RuntimeError(f"opening peer buffers failed on rank(s) {sorted(bad)}: {next(iter(bad.values()))}")
 
         class _Raw:                                   # zero-copy torch view of the library's allocation
-            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (self._own_base, False), "version": 2}
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8" if self._esz == 8 else "<f4", "data": (self._own_base, False), "version": 2}
         t = torch.as_tensor(_Raw(), device=self.tensor_device)
         return t
 
@@ -200,11 +211,11 @@ class ShardedVectorEnv:
         import ctypes as C
         from . import _capi
         G, D, n = self.world_size, self.obs_dim, self.local_num_envs
-        off = ((b * G + self.rank) * D * n) * 4                      # byte offset of slice [b][rank] in every replica
+        off = ((b * G + self.rank) * D * n) * self._esz              # byte offset of slice [b][rank] in every replica
         peers = [self._peers[r] for r in sorted(self._peers)]
         dst = (C.c_void_p * max(1, len(peers)))(*[C.c_void_p(p + off) for p in peers])
         _capi.check(self._lib.gymnet_push_obs_device(self._peer_dev, C.c_void_p(stream_ptr), C.c_void_p(self._own_base + off), dst,
-                                                     len(peers), D * n))
+                                                     len(peers), D * n * (self._esz // 4)))      # count in 4-byte words
 
     # ---- stepping -----------------------------------------------------------------------------------
     def _current_buffer(self):

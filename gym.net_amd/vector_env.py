@@ -113,7 +113,7 @@ class VectorEnv:
             self.SetLaunchPolicy(**launch_policy)
 
     @classmethod
-    def _borrow(cls, handle, env_id, num_envs, auto_reset):
+    def _borrow(cls, handle, env_id, num_envs, auto_reset, dtype=np.float32):
         """A VectorEnv view over a handle somebody else owns (a member of a GroupVectorEnv): Close() does not destroy it."""
         self = cls.__new__(cls)
         self._lib = capi.load_library()
@@ -122,7 +122,7 @@ class VectorEnv:
         self._owns_handle = False
         self._bookkeeping = True            # a group member: flags unknown here (DoneRecords() asks for everything it may have)
         self._final_obs = False
-        self._dtype = np.dtype(np.float32)
+        self._dtype = np.dtype(dtype)
         self._describe(env_id, num_envs, auto_reset)
         return self
 
@@ -408,14 +408,14 @@ class VectorEnv:
     def DoneRecords(self, episode=None, final_obs=None):
         """Compact records of the lanes that finished in the most recent step (gymnet_vecenv_done_records): dict with
         "lanes" int32 [c] and — by default whenever the handle keeps them — "return" float32 [c], "length" int32 [c],
-        "final_obs" float32 [c, D], all in the same (unspecified) order."""
+        "final_obs" [c, D] of the handle's dtype, all in the same (unspecified) order."""
         n = self.NumberOfEnvironments
         episode = self._bookkeeping if episode is None else episode
         final_obs = self._final_obs if final_obs is None else final_obs
         lanes = np.empty(n, np.int32)
         ret = np.empty(n, np.float32) if episode else None
         ln = np.empty(n, np.int32) if episode else None
-        fo = np.empty((n, self.ObsDim), np.float32) if final_obs else None
+        fo = np.empty((n, self.ObsDim), self._dtype) if final_obs else None
         cnt = C.c_int64()
         capi.check(self._lib.gymnet_vecenv_done_records(self._h, _host(lanes), None if ret is None else _host(ret), None if ln is None else _host(ln),
                                                         None if fo is None else _host(fo), n, C.byref(cnt)))
@@ -438,7 +438,7 @@ class VectorEnv:
         return ret, ln
 
     def FinalObs(self):
-        o = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        o = np.empty((self.NumberOfEnvironments, self.ObsDim), self._dtype)
         capi.check(self._lib.gymnet_vecenv_final_obs(self._h, _host(o)))
         return o
 
@@ -454,12 +454,16 @@ class VectorEnv:
         Raises NotImplementedError when the handle's configuration does not keep that array."""
         which, dt = self._ARRAYS[name]
         shape = (self.ObsDim, self.NumberOfEnvironments) if name == "final_obs" else (self.NumberOfEnvironments,)
+        if name == "final_obs":
+            dt = self._dtype                       # terminal observations carry the handle's state scalar
         a = np.empty(shape, dt)
         capi.check(self._lib.gymnet_vecenv_get_array(self._h, which, _host(a), a.nbytes))
         return a
 
     def SetArray(self, name, value):
         which, dt = self._ARRAYS[name]
+        if name == "final_obs":
+            dt = self._dtype
         a = np.ascontiguousarray(np.asarray(value, dtype=dt))
         capi.check(self._lib.gymnet_vecenv_set_array(self._h, which, _host(a), a.nbytes))
 
@@ -515,7 +519,7 @@ class VectorEnv:
         if value is None:
             raise ValueError("object")                         # ArgumentNullException, VecEnv.cs:88
         if name == "state":
-            return self.SetState(np.asarray(value, np.float32).T)
+            return self.SetState(np.asarray(value, self._dtype).T)    # the handle's own dtype: float64 state round-trips bit for bit
         if name == "steps_beyond_done":
             return self.SetStepsBeyondDone(value)
         raise AttributeError(name)
@@ -531,11 +535,17 @@ class GroupVectorEnv:
     peer-mapped memory, or RCCL).  Same VecEnv surface for the host-boundary path (Reset / Step over the whole batch)."""
 
     def __init__(self, env="CartPole-v1", global_num_envs=1, num_members=1, devices=None, seed=0, auto_reset=False,
-                 gather="direct", overlap=False, validate_actions=False, max_episode_steps=0, episode_stats=False):
+                 gather="direct", overlap=False, validate_actions=False, max_episode_steps=0, episode_stats=False, dtype=np.float32):
+        """dtype=np.float64 (CartPole): every member runs GYMNET_FLAG_F64 — the reference's own arithmetic — and the replicas,
+        the gather and the host batches carry doubles."""
         env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
         self._lib = capi.load_library()
+        self._dtype = np.dtype(dtype)
+        if self._dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
         flags = ((capi.FLAG_AUTORESET if auto_reset else 0) | (capi.FLAG_VALIDATE_ACTIONS if validate_actions else 0)
-                 | (capi.FLAG_DOUBLE_BUFFER if overlap else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0))
+                 | (capi.FLAG_DOUBLE_BUFFER if overlap else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0)
+                 | (capi.FLAG_F64 if self._dtype == np.float64 else 0))
         mode = {"none": capi.GATHER_NONE, "direct": capi.GATHER_DIRECT, "rccl": capi.GATHER_RCCL}[gather] if isinstance(gather, str) else int(gather)
         devs = None
         if devices is not None:
@@ -557,7 +567,7 @@ class GroupVectorEnv:
         for m in range(self.NumMembers):
             h = C.c_void_p()
             capi.check(self._lib.gymnet_group_member(self._g, m, C.byref(h)))
-            self.Members.append(VectorEnv._borrow(h, env_id, self.LanesPerMember, auto_reset))
+            self.Members.append(VectorEnv._borrow(h, env_id, self.LanesPerMember, auto_reset, self._dtype))
         self.ActionSpace, self.ObservationSpace = self.Members[0].ActionSpace, self.Members[0].ObservationSpace
         self.Metadata, self.RewardRange = self.Members[0].Metadata, self.Members[0].RewardRange
         self._adtype = self.Members[0]._adtype
@@ -589,7 +599,7 @@ class GroupVectorEnv:
 
     # host-boundary path over the whole batch
     def Reset(self):
-        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), np.float32)
+        obs = np.empty((self.NumberOfEnvironments, self.ObsDim), self._dtype)
         capi.check(self._lib.gymnet_group_reset(self._g, _host(obs)))
         return obs
 
@@ -602,7 +612,7 @@ class GroupVectorEnv:
         a = np.ascontiguousarray(np.asarray(action).reshape(-1).astype(self._adtype, copy=False))
         if a.shape[0] != n:
             raise ValueError("Number of actions passed should be equals to number of environments")
-        obs, rew, done = np.empty((n, self.ObsDim), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
+        obs, rew, done = np.empty((n, self.ObsDim), self._dtype), np.empty(n, np.float32), np.empty(n, np.uint8)
         capi.check(self._lib.gymnet_group_step(self._g, _host(a), _host(obs), _host(rew), _host(done)))
         return BatchStep(obs, rew, done.astype(bool), None, truncated=(done & 2) != 0)
 
@@ -634,7 +644,7 @@ class GroupVectorEnv:
 
     def ReadReplica(self, member):
         """Member's replica of all observations on the host, [G, D, N/G] (waits for the last gather)."""
-        out = np.empty((self.NumMembers, self.ObsDim, self.LanesPerMember), np.float32)
+        out = np.empty((self.NumMembers, self.ObsDim, self.LanesPerMember), self._dtype)
         capi.check(self._lib.gymnet_group_read_replica(self._g, int(member), _host(out)))
         return out
 

@@ -49,12 +49,17 @@
 extern "C" {
 #endif
 
-#define GYMNET_ABI_VERSION 4   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
+#define GYMNET_ABI_VERSION 5   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
                                   3: gymnet_env_info.{traffic_bytes_per_step,state_row_in_obs}, per-element Box sampling, compact
                                      terminal observations, pinned host staging;
                                   4: GYMNET_FLAG_F64 (float64 CartPole: observation / state buffers typed by the handle,
                                      gymnet_device_view.state_dtype), GYMNET_FLAG_COMPACT_RECORDS_ONLY, gymnet_launch_policy +
-                                     set / get, gymnet_vecenv_get_array / _set_array / _get_seed (checkpoint of every array) */
+                                     set / get, gymnet_vecenv_get_array / _set_array / _get_seed (checkpoint of every array);
+                                  5: GYMNET_FLAG_F64 is a first-class mode — it combines with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER /
+                                     COMPACT_RECORDS_ONLY / d_ext_obs(_alt) and with groups; every parameter that carries observation
+                                     values (gymnet_config.d_ext_obs*, terminal observations, group replicas and host batches) is
+                                     typed void* = the handle's state scalar (binary layout of the calls unchanged).  A launch-policy
+                                     value that would not take effect is rejected */
 
 typedef enum gymnet_status {
     GYMNET_OK = 0,
@@ -87,8 +92,8 @@ typedef enum gymnet_env_id {
                                               operation sequence of CartPoleEnv.cs:141-167 in binary64 (float32-valued constants widened at use),
                                               reset draws with 53 random bits, float64 observations at the boundary.  Reproduces the reference's
                                               episode lengths free-running (the float32 engine guarantees 1e-5 per teacher-forced step only).
-                                              73 B per env-step instead of 41.  Not combinable with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER /
-                                              d_ext_obs / groups (GYMNET_ERR_UNSUPPORTED) */
+                                              73 B per env-step instead of 41.  Since ABI 5 it combines with every other flag, with d_ext_obs(_alt)
+                                              (buffers of doubles) and with groups: the same kernels, instantiated for double (step_kernels.hpp) */
 #define GYMNET_FLAG_COMPACT_RECORDS_ONLY 0x80u /* ABI 4, with DONE_LIST: the step kernel writes the finished lanes' episode records / terminal
                                               observations ONLY as compact records (gymnet_vecenv_done_records); the dense per-lane views
                                               (gymnet_vecenv_episode_stats / _final_obs, gymnet_device_view.d_finished_*) are then brought up to
@@ -112,7 +117,8 @@ typedef struct gymnet_config {
     uint32_t flags;             /* GYMNET_FLAG_* */
     uint64_t seed;              /* Env.Seed(int) (CartPoleEnv.cs:196-198): Philox key */
     void    *stream;            /* hipStream_t to order all work on; NULL = the library creates its own */
-    float   *d_ext_obs;         /* optional device buffer [obs_dim][ext_obs_stride] to keep observations in (e.g. this
+    void    *d_ext_obs;         /* optional device buffer [obs_dim][ext_obs_stride] (float32; float64 with GYMNET_FLAG_F64) to keep
+                                   observations in (e.g. this
                                    rank's slice of an all-gather buffer).  It is LIVE STATE STORAGE, not an output copy: for
                                    envs whose observation IS the state (CartPole, MountainCar) every row, and for the others
                                    the rows listed in gymnet_env_info.state_row_in_obs (Pendulum obs[2]; Acrobot obs[4], obs[5]),
@@ -122,7 +128,7 @@ typedef struct gymnet_config {
     int32_t  max_episode_steps; /* EXTENSION (the reference has no time limit): >0 truncates episodes;
                                    requires GYMNET_FLAG_EPISODE_STATS; done byte gets bit 1 (value 2) for truncation */
     int32_t  reserved;
-    float   *d_ext_obs_alt;     /* with GYMNET_FLAG_DOUBLE_BUFFER and d_ext_obs: the caller's SECOND observation buffer (same
+    void    *d_ext_obs_alt;     /* with GYMNET_FLAG_DOUBLE_BUFFER and d_ext_obs: the caller's SECOND observation buffer (same
                                    stride), e.g. this rank's slice of a second all-gather buffer.  NULL = library allocates */
 } gymnet_config;
 
@@ -159,14 +165,14 @@ typedef struct gymnet_device_view {
     float   *d_reward;         /* [num_envs] */
     uint8_t *d_done;           /* [num_envs] */
     int32_t *d_steps_beyond_done; /* CartPole without AUTORESET: CartPoleEnv.cs:41 per lane; else NULL */
-    float   *d_final_obs;      /* [obs_dim][num_envs], FINAL_OBS only */
+    void    *d_final_obs;      /* [obs_dim][num_envs] of state_dtype, FINAL_OBS only */
     int32_t *d_done_list;      /* [num_envs] compact list, valid after gymnet_vecenv_done_lanes(_device); DONE_LIST only */
     float   *d_episode_return; int32_t *d_episode_length;     /* running, EPISODE_STATS only */
     float   *d_finished_return; int32_t *d_finished_length;   /* last finished episode per lane */
     void    *stream;           /* hipStream_t all of the handle's work is ordered on */
     int32_t  obs_buffer;       /* GYMNET_FLAG_DOUBLE_BUFFER: index (0 / 1) of the buffer d_obs points at = the latest observation */
     int32_t  state_dtype;      /* ABI 4: gymnet_dtype of d_state / d_obs — GYMNET_DTYPE_F32, or GYMNET_DTYPE_F64 for a GYMNET_FLAG_F64 handle */
-    float   *d_obs_alt;        /* GYMNET_FLAG_DOUBLE_BUFFER: the other buffer = what the NEXT step will write; else NULL */
+    void    *d_obs_alt;        /* GYMNET_FLAG_DOUBLE_BUFFER: the other buffer = what the NEXT step will write; else NULL */
 } gymnet_device_view;
 
 typedef enum gymnet_dtype { GYMNET_DTYPE_F32 = 0, GYMNET_DTYPE_F64 = 1 } gymnet_dtype;
@@ -180,8 +186,11 @@ typedef struct gymnet_launch_policy {
     int32_t  vec;                  /* lanes per thread on wide accesses: 1, 4 (dwordx4 rows; not Acrobot), 2 (Acrobot packed-FP32 form; F64 handles) */
     int32_t  block;                /* threads per workgroup: 64 / 128 / 256 */
     int32_t  nt;                   /* non-temporal stream mask: 0 none, 12 action + reward / done, 15 every stream */
-    int32_t  sequential_lanes;     /* Acrobot's multi-lane kernel: lanes per thread, 1 (one-shot kernel) .. 5 */
-    int32_t  reset_form;           /* fused auto-reset: 0 per-thread drain loop, 1 wave-compacted (dwordx4 kernels of aliasing envs) */
+    int32_t  sequential_lanes;     /* multi-lane kernels (lean variant): Acrobot with vec 1 — lanes per thread, 1 (one-shot kernel) .. 5;
+                                      Acrobot / F64 handles with vec 2 — lane PAIRS per thread, 1 .. 4, num_envs a multiple of
+                                      2 * sequential_lanes * 256.  A value > 1 the launcher would not resolve to -> GYMNET_ERR_INVALID_ARG */
+    int32_t  reset_form;           /* fused auto-reset: 0 per-thread drain loop, 1 wave-compacted (wide kernels of the envs whose
+                                      observation is the state: CartPole in both state scalars, MountainCar) */
     int32_t  lds_pipe;             /* Acrobot: 1 = producer / consumer form of the multi-lane kernel (needs num_envs % 512 == 0) */
     int32_t  occupancy_lds_bytes;  /* unused dynamic LDS per workgroup, for the one purpose of capping occupancy in probes */
     int32_t  graph;                /* gymnet_vecenv_rollout_device: 0 eager launches, 1 hipGraph replay, -2 back to "by batch size" */
@@ -311,7 +320,7 @@ int gymnet_vecenv_counters(gymnet_vecenv *h, gymnet_counters *out);
  * checkpoint of any configuration (get_state / set_state double as checkpoint / resume): running episode return /
  * length (which drive the max_episode_steps truncation), the reward / done flags of the last step (which reset_where(NULL)
  * consumes), steps_beyond_done, the dense finished-episode views, the per-lane Philox keys of VecEnv.Seed(int[]).
- * `bytes` must equal the array's size (num_envs x element size; FINAL_OBS: obs_dim x num_envs x 4, structure-of-arrays).
+ * `bytes` must equal the array's size (num_envs x element size; FINAL_OBS: obs_dim x num_envs x 4 — x 8 for a float64 handle —, structure-of-arrays).
  * An array the handle's configuration does not have -> GYMNET_ERR_UNSUPPORTED.  Both calls block.
  * set(LANE_SEEDS) installs the keys WITHOUT rewinding the tick (gymnet_vecenv_seed_lanes rewinds it); set(DONE) also forgets the
  * compacted done list of the step before (it described other flags). */
@@ -323,7 +332,7 @@ typedef enum gymnet_array_id {
     GYMNET_ARRAY_EPISODE_LENGTH = 4,     /* int32   [num_envs] */
     GYMNET_ARRAY_FINISHED_RETURN = 5,    /* float32 [num_envs]  EPISODE_STATS: last finished episode per lane */
     GYMNET_ARRAY_FINISHED_LENGTH = 6,    /* int32   [num_envs] */
-    GYMNET_ARRAY_FINAL_OBS = 7,          /* float32 [obs_dim][num_envs]  FINAL_OBS */
+    GYMNET_ARRAY_FINAL_OBS = 7,          /* float32 (float64: F64 handle) [obs_dim][num_envs]  FINAL_OBS */
     GYMNET_ARRAY_LANE_SEEDS = 8          /* uint64  [num_envs]  after gymnet_vecenv_seed_lanes with distinct seeds */
 } gymnet_array_id;
 int gymnet_vecenv_get_array(gymnet_vecenv *h, int32_t which, void *out, int64_t bytes);
@@ -341,16 +350,16 @@ int gymnet_vecenv_done_lanes(gymnet_vecenv *h, int32_t *lanes_out, int64_t capac
 int gymnet_vecenv_done_lanes_device(gymnet_vecenv *h, int32_t *d_lanes_out, uint32_t *d_count_out);
 /* ABI 3.  The RECORDS of the lanes that finished in the most recent step, compacted (unordered; all arrays in the same order):
  * lane ids, with EPISODE_STATS the finished episode's return and length, with FINAL_OBS its terminal observation as rows
- * [count][obs_dim] — what a trainer consumes per step (BasePlaySession.cs:58-69: accumulate reward, count steps per episode)
+ * [count][obs_dim] (float32; float64 for a GYMNET_FLAG_F64 handle — here and in gymnet_vecenv_final_obs) — what a trainer consumes per step (BasePlaySession.cs:58-69: accumulate reward, count steps per episode)
  * without shipping num_envs flags to the host.  Inside the step kernel every finished lane's record is written AT ITS POSITION
  * in the (sharded) done list, so a wave's ~11 finished lanes write a few contiguous cache lines instead of one scattered line
  * per lane and array.  Any out pointer may be NULL; at most `capacity` records are copied, *count is the true number.
  * Needs GYMNET_FLAG_DONE_LIST. */
-int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, float *final_obs_out,
+int gymnet_vecenv_done_records(gymnet_vecenv *h, int32_t *lanes_out, float *return_out, int32_t *length_out, void *final_obs_out,
                                int64_t capacity, int64_t *count);
 /* Device-side form (stream-ordered, does not block): caller-owned device arrays of `capacity` records each (d_final_obs:
  * [capacity][obs_dim] row-major); *d_count receives the true number.  Any array may be NULL. */
-int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, float *d_final_obs,
+int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float *d_return, int32_t *d_length, void *d_final_obs,
                                       int64_t capacity, uint32_t *d_count);
 /* DENSE views, one row per lane.  Last finished episode's return and length per lane (0 length = none finished yet); needs
  * EPISODE_STATS.  Terminal observations, host [num_envs, obs_dim], rows of lanes that never finished are 0; needs FINAL_OBS.
@@ -359,7 +368,7 @@ int gymnet_vecenv_done_records_device(gymnet_vecenv *h, int32_t *d_lanes, float 
  * compact records alone; each call of these getters then first applies the records of the MOST RECENT step to the dense arrays,
  * and records of steps the caller did not read are not in the dense view (use gymnet_vecenv_done_records every step). */
 int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_t *finished_length);
-int gymnet_vecenv_final_obs(gymnet_vecenv *h, float *final_obs_out);
+int gymnet_vecenv_final_obs(gymnet_vecenv *h, void *final_obs_out);
 
 /* ---- batched space sampling (the step BEFORE the path: ActionSpace.Sample(), TrainingPlaySession.cs:46-49) -- */
 /* All sampling below draws from the ACTION stream: Philox key = seed ^ 0x9E3779B97F4A7C15, so ActionSpace.Sample() called
@@ -442,14 +451,15 @@ int gymnet_group_rollout_device(gymnet_group *g, const void *const *d_actions, i
  * after gymnet_group_wait_gather (or, without DOUBLE_BUFFER, after this call) sees all G slices. */
 int gymnet_group_allgather_obs(gymnet_group *g);
 int gymnet_group_wait_gather(gymnet_group *g);
-/* Member m's replica that was gathered last: device float [G][obs_dim][N/G] on m's GPU. */
-int gymnet_group_global_obs(gymnet_group *g, int32_t member, float **d_obs_all);
-/* The same replica copied to the host, float [G][obs_dim][N/G]; waits for the last gather and blocks. */
-int gymnet_group_read_replica(gymnet_group *g, int32_t member, float *replica_out);
+/* Member m's replica that was gathered last: device [G][obs_dim][N/G] on m's GPU — float32, or float64 when the group was created
+ * with GYMNET_FLAG_F64 (here and in the three calls below). */
+int gymnet_group_global_obs(gymnet_group *g, int32_t member, void **d_obs_all);
+/* The same replica copied to the host, [G][obs_dim][N/G]; waits for the last gather and blocks. */
+int gymnet_group_read_replica(gymnet_group *g, int32_t member, void *replica_out);
 int gymnet_group_sync(gymnet_group *g);
 /* Host-boundary forms over the whole batch (NDArray-shaped: obs [N, obs_dim], reward [N], done [N]; any may be NULL). */
-int gymnet_group_reset(gymnet_group *g, float *obs_out);
-int gymnet_group_step(gymnet_group *g, const void *actions, float *obs_out, float *reward_out, uint8_t *done_out);
+int gymnet_group_reset(gymnet_group *g, void *obs_out);
+int gymnet_group_step(gymnet_group *g, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out);
 
 /* ---- peer buffers: the direct all-gather for ONE PROCESS PER GPU hosts ---------------------------------------------
  * gymnet_group_* needs all GPUs in one process.  A host that runs one process per GPU (torch.distributed, MPI, a .NET
@@ -465,7 +475,7 @@ int gymnet_peer_buffer_create(int device, int64_t bytes, void **d_ptr, gymnet_ip
 int gymnet_peer_buffer_open(int device, const gymnet_ipc_handle *handle, void **d_ptr);              /* map a peer's buffer */
 int gymnet_peer_buffer_close(int device, void *d_ptr);                                               /* unmap an opened buffer */
 int gymnet_peer_buffer_destroy(int device, void *d_ptr);                                             /* free a created buffer */
-/* Stores `count` floats from d_src into the same-shaped slice d_dst[p] of every peer (p < npeers <= 15), all peers
+/* Stores `count` 4-byte words (floats; a float64 slice counts two per element) from d_src into the same-shaped slice d_dst[p] of every peer (p < npeers <= 15), all peers
  * concurrently (one grid row per peer = one xGMI link each), on `stream` (a hipStream_t of `device`; NULL = default). */
 int gymnet_push_obs_device(int device, void *stream, const float *d_src, float *const *d_dst, int32_t npeers, int64_t count);
 

@@ -16,7 +16,7 @@ def test_f64_step_equals_the_vectors_evaluated_from_the_reference_text(gpu_pkg, 
     g = golden("cartpole_reference_text")                                  # 3200 float64 input -> output vectors
     n = g["state"].shape[1]
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=False, dtype=np.float64) as env:
-        assert env.KernelName().startswith("step_kernel_f64<") and env.Dtype == np.float64
+        assert env.KernelName().startswith("step_kernel<CartPole64,") and env.Dtype == np.float64
         first = env.Reset()
         assert first.dtype == np.float64 and first.shape == (n, 4)
         env.SetState(g["state"])
@@ -146,9 +146,6 @@ def test_f64_host_buffers_step_async_and_errors(gpu_pkg):
         assert np.array_equal(a.Read().Observation, obs)
         with pytest.raises(ValueError):
             a.StepInto(acts, obs.astype(np.float32), rew, done)             # float32 buffer on a float64 handle
-    for kw in (dict(done_list=True), dict(final_obs=True), dict(double_buffer=True)):
-        with pytest.raises(NotImplementedError):
-            gpu_pkg.VectorEnv("CartPole-v1", 64, auto_reset=True, dtype=np.float64, **kw)
     with pytest.raises(NotImplementedError):
         gpu_pkg.VectorEnv("Pendulum-v1", 64, dtype=np.float64)              # only CartPole's float64 arithmetic is defined by the reference
 
@@ -180,7 +177,7 @@ def test_f64_device_path_graph_replay_time_limit_and_lane_seeds(gpu_pkg, oracle)
     seeds = np.arange(n, dtype=np.uint64) * 7 + 3
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True, max_episode_steps=limit) as env:
         env.Seed(seeds.astype(np.int64))
-        assert env.KernelName().split(",")[2] == "true"                      # step_kernel_f64<VEC, AUTORESET, EXTRAS, NT>
+        assert env.KernelName().split(",")[3] == "true"                      # step_kernel<CartPole64, VEC, AUTORESET, EXTRAS, NT, RESETF>
         first = env.Reset()
         s = oracle.cartpole_reset_f64(0, 0, 0, n, lane_seed=seeds)
         assert np.array_equal(first.T, s)
@@ -208,7 +205,7 @@ def test_f64_at_2p20_lanes_matches_the_twin_and_the_float32_engine_statistically
     import torch
     n, steps, ring = 1 << 20, 24, 8
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64) as env:
-        assert env.KernelName() == "step_kernel_f64_pipe<2,true,15>"        # the default at this size (one lock-step generation otherwise)
+        assert env.KernelName() == "step_kernel_pipe2<CartPole64,2,true,15>"   # the default at this size (one lock-step generation otherwise)
         acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for t in range(ring):
@@ -287,10 +284,10 @@ def test_f64_steps_beyond_done_reward_stream_and_counter(gpu_pkg, golden):
 
 
 def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
-    """step_kernel_f64_pipe<ITEMS> (launch policy sequential_lanes = 2..4: a thread owns ITEMS lane pairs, all loads first, then
+    """step_kernel_pipe2<CartPole64, ITEMS> (launch policy sequential_lanes = 2..4: a thread owns ITEMS lane pairs, all loads first, then
     advance / store pair after pair) runs the same per-lane code with the same Philox counters as the one-shot kernel: states,
-    rewards, done flags and reset draws must agree bit for bit, with and without auto-reset; batches that are not whole multiples
-    of 2 * ITEMS * 256 lanes, and the bookkeeping variant, fall back to the one-shot kernel."""
+    rewards, done flags and reset draws must agree bit for bit, with and without auto-reset; for batches that are not whole multiples
+    of 2 * ITEMS * 256 lanes, and for the bookkeeping variant, an explicit request is rejected (it would not take effect)."""
     import torch
     n, ring, steps = 2 * 256 * 12 * 5, 6, 37
     acts = torch.randint(0, 2, (ring, n), dtype=torch.int32, device="cuda")
@@ -299,7 +296,7 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
     for auto in (True, False):
         for items in (1, 2, 3, 4):
             with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, launch_policy={"sequential_lanes": items}) as env:
-                want = f"step_kernel_f64<2,{str(auto).lower()},false,15>" if items == 1 else f"step_kernel_f64_pipe<{items},{str(auto).lower()},15>"
+                want = f"step_kernel<CartPole64,2,{str(auto).lower()},false,15,0>" if items == 1 else f"step_kernel_pipe2<CartPole64,{items},{str(auto).lower()},15>"
                 assert env.KernelName() == want, env.KernelName()
                 env.ResetDevice()
                 env.RolloutDevice(acts, steps, n, ring)
@@ -312,12 +309,18 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
             got = out[(auto, items)]
             assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(ref[:3], got[:3])), (auto, items)
             assert (ref[3] is None or np.array_equal(ref[3], got[3])) and ref[4] == got[4]
-    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64, launch_policy={"sequential_lanes": 4}) as env:
-        assert env.KernelName() == "step_kernel_f64<2,true,false,15>"                 # not whole 2 * 4 * 256-lane groups: one-shot kernel
-    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True, launch_policy={"sequential_lanes": 2}) as env:
-        assert env.KernelName() == "step_kernel_f64<2,true,true,15>"                  # bookkeeping: one-shot kernel
+    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64) as env:
+        with pytest.raises(ValueError, match="would not take effect"):
+            env.SetLaunchPolicy(sequential_lanes=4)                                    # not whole 2 * 4 * 256-lane groups
+        assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,0>" and env.GetLaunchPolicy()["sequential_lanes"] == 1
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True) as env:
+        with pytest.raises(ValueError, match="would not take effect"):
+            env.SetLaunchPolicy(sequential_lanes=2)                                    # bookkeeping variant: one-shot kernel only
+        assert env.KernelName() == "step_kernel<CartPole64,2,true,true,15,0>"
         with pytest.raises(ValueError):
             env.SetLaunchPolicy(sequential_lanes=5)
+        env.SetLaunchPolicy(block=64)                                                  # honoured (the float64 launcher used to ignore it)
+        assert env.GetLaunchPolicy()["block"] == 64
 
 
 @pytest.mark.parametrize("auto", [True, False])

@@ -272,8 +272,12 @@ def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
     for vec, items in ((1, 1), (2, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
         res = []
         for auto, stats in ((True, False), (False, False), (True, True)):
+            # (the bookkeeping variant has the one-shot kernel only: an explicit multi-lane request for it is refused)
             with gpu_pkg.VectorEnv("Acrobot-v1", n, seed=SEED, auto_reset=auto, episode_stats=stats, done_list=stats,
-                                   launch_policy={"vec": vec, "sequential_lanes": items, "lds_pipe": 0}) as env:
+                                   launch_policy={"vec": vec, "sequential_lanes": 1 if stats else items, "lds_pipe": 0}) as env:
+                if stats and items > 1:
+                    with pytest.raises(ValueError, match="would not take effect"):
+                        env.SetLaunchPolicy(sequential_lanes=items)
                 pol = env.LaunchPolicy()
                 assert pol["envs_per_thread"] == vec and pol["sequential_lanes_per_thread"] == (1 if stats else items)
                 acts = torch.empty((ring, n + (n % 2)), dtype=torch.int32, device="cuda")
@@ -381,8 +385,8 @@ def test_set_state_of_get_state_leaves_the_observation_unchanged(gpu_pkg, name):
 def test_acrobot_lane_pair_multi_lane_kernel_is_bit_identical(gpu_pkg):
     """step_kernel_pipe2 (launch policy vec = 2 with sequential_lanes = 2..4; round 4 probe): ITEMS lane PAIRS per thread, 8-byte
     accesses, scalar arithmetic lane after lane, all loads first.  Same per-lane code and Philox counters as the one-shot kernel:
-    bit-identical states / observations / rewards / done flags with and without auto-reset; batches that are not whole
-    2 * ITEMS * 256-lane groups fall back to the packed two-lane one-shot kernel."""
+    bit-identical states / observations / rewards / done flags with and without auto-reset; for batches that are not whole
+    2 * ITEMS * 256-lane groups the request is refused and the packed two-lane one-shot kernel stays."""
     import torch
     n, ring = 2 * 256 * 12 * 3, 6
     rng = np.random.default_rng(4)
@@ -403,5 +407,7 @@ def test_acrobot_lane_pair_multi_lane_kernel_is_bit_identical(gpu_pkg):
         for key in ((auto, 2, 2), (auto, 2, 3), (auto, 2, 4)):
             assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(res[(auto, 1, 1)], res[key])), key
         assert res[(auto, 1, 1)][3].any()
-    with gpu_pkg.VectorEnv("Acrobot-v1", n + 2, seed=SEED, auto_reset=True, launch_policy={"vec": 2, "sequential_lanes": 4}) as env:
+    with gpu_pkg.VectorEnv("Acrobot-v1", n + 2, seed=SEED, auto_reset=True, launch_policy={"vec": 2}) as env:
+        with pytest.raises(ValueError, match="would not take effect"):
+            env.SetLaunchPolicy(sequential_lanes=4)                              # not whole 2 * 4 * 256-lane groups
         assert env.KernelName() == "step_kernel<Acrobot,2,true,false,15,0>"

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, overlap=False):
+def _worker(rank, world, port, out_dir, overlap=False, dtype="float32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -34,8 +34,9 @@ def _worker(rank, world, port, out_dir, overlap=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     env = pkg.ShardedVectorEnv("CartPole-v1", N, rank=rank, world_size=world, seed=SEED, auto_reset=True,
-                               gather_obs=True, local_env_factory=OracleLocalEnv, tensor_device="cpu", overlap=overlap)
+                               gather_obs=True, local_env_factory=OracleLocalEnv, tensor_device="cpu", overlap=overlap, dtype=dtype)
     assert env.overlap == overlap and env.obs_bufs.shape[0] == (2 if overlap else 1)
+    assert env.obs_bufs.dtype == (torch.float64 if dtype == "float64" else torch.float32)
     assert env.local_num_envs == N // world and env.lane_offset == rank * N // world
     rng = np.random.default_rng(99)                       # every rank derives the same GLOBAL action array
     acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
@@ -68,23 +69,31 @@ def _worker(rank, world, port, out_dir, overlap=False):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (8, False), (8, True)])
-def test_sharded_rollout_equals_single_shard(tmp_path, oracle, world, overlap):
+@pytest.mark.parametrize("world,overlap,dtype", [(2, False, "float32"), (2, True, "float32"), (8, False, "float32"), (8, True, "float32"),
+                                                 (2, True, "float64"), (8, False, "float64"), (8, True, "float64")])
+def test_sharded_rollout_equals_single_shard(tmp_path, oracle, world, overlap, dtype):
     """World sizes 2 and 8 (BASELINE config 5's shape: 8 ranks, rank-major [8][4][N/8] gather buffer), with and without the
-    double-buffered overlap: ShardPlan's lane blocks, the per-rank Philox lane offsets, the overlap bookkeeping and the
-    all-gather — every rank must end up holding the single-shard batch, bit for bit, after every step."""
+    double-buffered overlap, in float32 and in the reference-arithmetic float64 mode (gather buffers of doubles): ShardPlan's lane
+    blocks, the per-rank Philox lane offsets, the overlap bookkeeping and the all-gather — every rank must end up holding the
+    single-shard batch, bit for bit, after every step."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap, dtype), nprocs=world, join=True)
     got = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
-    assert got[0].shape == (STEPS, world, 4, N // world)
+    assert got[0].shape == (STEPS, world, 4, N // world) and got[0].dtype == np.dtype(dtype)
     for r in range(1, world):
         assert np.array_equal(got[0], got[r]), r          # every rank holds the same gathered observations
-    # single shard, same seed, same global actions, same float32 kernel-semantics oracle
+    # single shard, same seed, same global actions, same kernel-semantics oracle
     rng = np.random.default_rng(99)
     acts = rng.integers(0, 2, (STEPS, N)).astype(np.int32)
-    s = oracle.cartpole_reset(SEED, 0, 0, N)
+    f64 = dtype == "float64"
+    s = oracle.cartpole_reset_f64(SEED, 0, 0, N) if f64 else oracle.cartpole_reset(SEED, 0, 0, N)
     for t in range(STEPS):
+        if f64:
+            s, _, _ = oracle.cartpole_autoreset_step_f64(SEED, 0, t + 1, s, acts[t])
+            gathered = got[0][t]
+            assert np.array_equal(np.concatenate(list(gathered), axis=1), s), t
+            continue
         s2, _, d, _ = oracle.cartpole_step(s, acts[t], dtype=np.float32)
         fresh = oracle.cartpole_reset(SEED, 0, t + 1, N)
         fin = d.astype(bool)
@@ -141,6 +150,7 @@ def _failing_setup_worker(rank, world, port, out_dir, fail_stage):
     import torch
     env._torch, env._dist, env.group = torch, dist, None
     env.rank, env.world_size, env.tensor_device = rank, world, torch.device("cpu")
+    env._esz = 4
     msg = ""
     try:
         env._make_peer_buffers((1, world, 4, 16), 0)
