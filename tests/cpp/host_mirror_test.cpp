@@ -237,7 +237,13 @@ static void gpu_tests() {
             if (a.Done) { e64.Reset(); e32.Reset(); }
         }
         CHECK(close && done_same && steps == 200, "float32 engine within 1e-5 of the float64 one per teacher-forced step, same done / reward");
-        CHECK(throws<std::logic_error>([] { gymnet::CartPoleEnv64 bad(0, 1, GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_AUTORESET); }), "F64 + DONE_LIST -> NotSupportedException");
+        {   // ABI 5: the float64 mode combines with every other flag (one kernel skeleton for both state scalars)
+            gymnet::CartPoleEnv64 full(0, 1, GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_AUTORESET | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_DOUBLE_BUFFER);
+            full.Reset();
+            bool finished = false;
+            for (int i = 0; i < 200 && !finished; ++i) finished = full.Step(1).Done;
+            CHECK(finished, "F64 + DONE_LIST + FINAL_OBS + EPISODE_STATS + DOUBLE_BUFFER: steps, and the always-right episode ends");
+        }
         CHECK(throws<std::logic_error>([] { gymnet::VectorEnv bad(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_F64); }), "the float32 host class refuses a float64 handle (its buffers are float)");
     }
     {   // ABI 4: launch policy through the ABI, arrays by id

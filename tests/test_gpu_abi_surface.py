@@ -305,11 +305,15 @@ def test_abi4_entry_points_reject_bad_arguments_without_side_effects(gpu_pkg):
         env.SetArray("lane_seeds", np.arange(n, dtype=np.uint64) + 5)
         assert env.GetSeed() == (SEED, True) and env.Tick == tick and env.KernelName().split(",")[3] == "true"
         assert np.array_equal(env.GetArray("lane_seeds"), np.arange(n, dtype=np.uint64) + 5)
-    # float64 handles: the flag's documented exclusions, and float buffers are the caller's responsibility (typed void*)
+    # float64 handles (ABI 5): the flag combines with every other one; CartPole only; buffers are the caller's responsibility (typed void*)
     cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=0, num_envs=64, lane_offset=0, device=0,
-                      flags=capi.FLAG_F64 | capi.FLAG_AUTORESET | capi.FLAG_DONE_LIST, seed=1)
+                      flags=capi.FLAG_F64 | capi.FLAG_AUTORESET | capi.FLAG_DONE_LIST | capi.FLAG_FINAL_OBS | capi.FLAG_DOUBLE_BUFFER, seed=1)
     h = C.c_void_p()
-    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_UNSUPPORTED and not h.value
+    assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.OK and h.value
+    assert lib.gymnet_vecenv_get_array(h, capi.ARRAY_FINAL_OBS, (C.c_double * (4 * 64))(), 4 * 64 * 4) == capi.ERR_INVALID_ARG   # doubles: 4 x 64 x 8 bytes
+    assert lib.gymnet_vecenv_get_array(h, capi.ARRAY_FINAL_OBS, (C.c_double * (4 * 64))(), 4 * 64 * 8) == capi.OK
+    assert lib.gymnet_vecenv_destroy(h) == capi.OK
+    h = C.c_void_p()
     cfg.flags = capi.FLAG_COMPACT_RECORDS_ONLY | capi.FLAG_AUTORESET
     assert lib.gymnet_vecenv_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG and b"DONE_LIST" in lib.gymnet_last_error()
     cfg.flags, cfg.env_id = capi.FLAG_F64, 3
@@ -322,6 +326,14 @@ def test_abi4_entry_points_reject_bad_arguments_without_side_effects(gpu_pkg):
         with gpu_pkg.VectorEnv("CartPole-v1", 64, seed=1) as e32:
             assert e32.DeviceView().state_dtype == capi.DTYPE_F32
     gcfg = capi.GroupConfig(struct_size=C.sizeof(capi.GroupConfig), env_id=0, global_num_envs=128, num_members=2,
-                            flags=capi.FLAG_AUTORESET | capi.FLAG_F64, seed=1, devices=None, gather=capi.GATHER_NONE, max_episode_steps=0)
+                            flags=capi.FLAG_AUTORESET | capi.FLAG_F64, seed=1, devices=(C.c_int32 * 2)(0, 0), gather=capi.GATHER_NONE, max_episode_steps=0)
     g = C.c_void_p()
-    assert lib.gymnet_group_create(C.byref(gcfg), C.byref(g)) == capi.ERR_UNSUPPORTED and not g.value    # float64 handles cannot be group members
+    assert lib.gymnet_group_create(C.byref(gcfg), C.byref(g)) == capi.OK and g.value                     # ABI 5: float64 members
+    m = C.c_void_p()
+    assert lib.gymnet_group_member(g, 1, C.byref(m)) == capi.OK
+    v = capi.DeviceView()
+    assert lib.gymnet_vecenv_device_view(m, C.byref(v)) == capi.OK and v.state_dtype == capi.DTYPE_F64 and v.num_envs == 64
+    assert lib.gymnet_group_destroy(g) == capi.OK
+    gcfg.env_id = 1
+    g = C.c_void_p()
+    assert lib.gymnet_group_create(C.byref(gcfg), C.byref(g)) == capi.ERR_UNSUPPORTED and not g.value    # float64 arithmetic is CartPole's only
