@@ -88,6 +88,37 @@ __host__ __device__ __forceinline__ double u01_53(uint32_t a, uint32_t b) {
 // second Philox call of a float64 reset draw: same counter (lane, tick), key ^ this constant (a stream of its own)
 constexpr uint64_t kStreamReset64 = 0xC2B2AE3D27D4EB4Full;
 
+// x / total_mass for the binary64 x of the float64 mode, as TWO IEEE operations instead of the ~30-instruction correctly rounded
+// division sequence: q = fma(x, ZH, x * ZL) with ZH = RN(1/C), ZL = RN(1/C - ZH) (Brisebarre, Muller, Raina: "Accelerating correctly
+// rounded floating-point division when the divisor is known in advance"; the float32 engine's DivByTotalMass, envs.hpp).
+// Three of the step's four divisions are by this constant (:149-151): ~55 of its ~270 VALU instructions per env-step.
+//
+// Why q equals IEEE x / C for EVERY binary64 x with 2^-900 <= |x| <= 2^1000 (and for +0 and NaN) — PROVED, not sampled
+// (tools/prove_div_total_mass_f64.py does the arithmetic below in exact rationals; tests/test_oracle.py runs it and 1e8 samples):
+//   C = total_mass is a binary32 value widened to binary64: C = Cn / 2^23 with the ODD integer Cn = 9227469.  For x = X * 2^e
+//   (X a 53-bit integer) the exact quotient is X * 2^(e+23) / Cn.  A rounding breakpoint of binary64 in the quotient's binade is
+//   m * 2^k with m an odd integer (a midpoint between neighbouring doubles), so the distance between the quotient and ANY
+//   breakpoint is |X * 2^j - m * Cn| / Cn * 2^k with j = 24 or 25: the numerator is an ODD integer (X * 2^j is even, m * Cn is
+//   odd * odd), so it is at least 1 in magnitude and the quotient stays >= 1/(2 Cn) = 2^-24.1 ulp away from every breakpoint
+//   (attained: the tool constructs such x).  The fma pair computes RN(x * ZH + RN(x * ZL)) = RN(x / C + err) with
+//   |err| <= |x| * |1/C - ZH - ZL| + ulp(x * ZL) / 2 < 2^-53 ulp of the quotient.
+//   An error 2^29 times smaller than the distance to the nearest breakpoint cannot change the rounding: q == x / C.
+//   (A divisor with 53 significant bits would not allow this argument: the 24-bit constant is what makes it a theorem.)
+// Below 2^-900 the product x * ZL approaches the subnormal range and the bound degrades; the step never divides such a value
+// (the three dividends are 10 + ..., masspole * cos^2 and polemass_length * thetaacc * cos: >= 2^-200 in magnitude or exactly 0).
+// Outside the theorem because ZL < 0: x = -0 yields +0 (the division: -0) and x = +-inf yields NaN (the division: +-inf).  Neither
+// can change a step's result: two of the quotients are subtracted from a non-zero term (4/3 - ..., temp - ...: a zero of either
+// sign leaves it unchanged), the third dividend is +-10 + ... (never zero), and an infinite dividend needs a state that is
+// already non-finite.  The CPU twin mirrors the fma pair, so GPU == twin holds for every input regardless.
+struct DivByTotalMass64 {
+    static constexpr double C = (double)(0.1f + 1.0f);                  // 0x1.19999ap+0 exactly
+    static constexpr double ZH = 1.0 / C;                               // RN(1/C)  = 0x1.d1745c6e043b8p-1
+    // RN(1/C - ZH), written out: the compile-time evaluation of (1/C - ZH) in long double is not portable between host and
+    // device passes.  tools/prove_div_total_mass_f64.py derives both constants in exact arithmetic and checks these literals.
+    static constexpr double ZL = -0x1.4633f3e678be9p-55;
+    __host__ __device__ __forceinline__ static double apply(double x) { return __builtin_fma(x, ZH, x * ZL); }
+};
+
 struct CartPole64 {
     // the Env interface of step_kernels.hpp (see CartPole in envs.hpp), with the state scalar the reference uses
     using Real = double;
@@ -116,6 +147,8 @@ struct CartPole64 {
     static constexpr float theta_threshold = 0.20943951606750488f;   // (float)(12 * 2 * Math.PI / 360)
     static constexpr float x_threshold = 2.4f;
 
+    __device__ __forceinline__ static double div_tm(double x) { return DivByTotalMass64::apply(x); }
+
     // :141-167, statement for statement; C#'s usual arithmetic conversions written out (float op double -> double)
     template <bool SMALL_ANGLE = false>
     __device__ __forceinline__ static void step(double (&st)[S], int32_t a, float &reward, bool &done) {
@@ -123,10 +156,11 @@ struct CartPole64 {
         const float force = a == 1 ? force_mag : -force_mag;                                                // :146
         double sintheta, costheta;
         sincos_f64<SMALL_ANGLE>(theta, sintheta, costheta);                                                 // :147-148
-        const double temp = ((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta) / (double)total_mass;   // :149
+        // `/ total_mass` (:149-151) is IEEE division by a constant, evaluated as DivByTotalMass64 (proved bit-identical, above)
+        const double temp = div_tm((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta);                    // :149
         const double thetaacc = ((double)gravity * sintheta - costheta * temp)
-                                / ((double)length * (4.0 / 3.0 - (double)masspole * costheta * costheta / (double)total_mass)); // :150
-        const double xacc = temp - (double)polemass_length * thetaacc * costheta / (double)total_mass;       // :151
+                                / ((double)length * (4.0 / 3.0 - div_tm((double)masspole * costheta * costheta)));              // :150
+        const double xacc = temp - div_tm((double)polemass_length * thetaacc * costheta);                     // :151
         x = x + (double)tau * x_dot;                                                                        // :154
         x_dot = x_dot + (double)tau * xacc;                                                                 // :155
         theta = theta + (double)tau * theta_dot;                                                            // :156

@@ -62,6 +62,10 @@ def lib():
     L.ref_discrete_sample_masked_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _u8p, C.c_int64, _i32p, C.c_int64]
     L.ref_compose_discrete_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64]
     L.ref_box_uniform_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _f32p, C.c_int64]
+    L.ref_div_total_mass_f64_kernel.argtypes = [C.c_double]
+    L.ref_div_total_mass_f64_kernel.restype = C.c_double
+    L.ref_check_div_total_mass_f64.argtypes = [C.c_uint64, C.c_int64]
+    L.ref_check_div_total_mass_f64.restype = C.c_int64
     L.ref_sincos_f64_kernel_batch.argtypes = [_f64p, _f64p, _f64p, C.c_int64]
     L.ref_cartpole_step_batch_f64_kernel.argtypes = [_f64p, _i32p, _i32p, _f32p, _u8p, C.c_int64]
     L.ref_cartpole_reset_batch_f64.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, _f64p, C.c_int64]
@@ -171,6 +175,12 @@ def sincos_kernel(x, small=False):
 def check_div_total_mass(biased_exponents):
     e = np.ascontiguousarray(np.asarray(biased_exponents, dtype=np.int32))
     return int(lib().ref_check_div_total_mass(e, e.shape[0]))
+
+
+def check_div_total_mass_f64(seed, count):
+    """Number of sampled binary64 dividends for which the float64 kernel's fma-pair constant division differs from IEEE x / total_mass
+    (must be 0; the proof is tools/prove_div_total_mass_f64.py)."""
+    return int(lib().ref_check_div_total_mass_f64(seed, count))
 
 
 def check_fmod_2pi(stride, multiples):

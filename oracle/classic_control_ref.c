@@ -266,18 +266,55 @@ void ref_sincos_f64_kernel_batch(const double *x, double *s, double *c, int64_t 
     for (int64_t i = 0; i < n; ++i) ref_sincos_f64_kernel(x[i], &s[i], &c[i]);
 }
 
+/* x / total_mass the way the float64 kernel evaluates it (cartpole64.hpp DivByTotalMass64): fma(x, ZH, x * ZL) with ZH = RN(1/C),
+ * ZL = RN(1/C - ZH).  tools/prove_div_total_mass_f64.py PROVES that this equals IEEE x / C for every binary64 x (C has only 24
+ * significant bits: no quotient comes within 2^-24 ulp of a rounding breakpoint, the fma pair is within 2^-53 ulp of the quotient)
+ * and checks the ZL literal below; ref_check_div_total_mass_f64 samples it against the hardware's division. */
+double ref_div_total_mass_f64_kernel(double x) {
+    const double C = (double)CP_TOTAL_MASS;
+    const double ZH = 1.0 / C;
+    const double ZL = -0x1.4633f3e678be9p-55;
+    return fma(x, ZH, x * ZL);
+}
+
+/* `count` pseudo-random binary64 dividends (xorshift64*, both signs, exponents spread over 2^-300 .. 2^300 with most of the mass
+ * in the range the step produces, plus a few special values): the number for which the fma pair differs from IEEE x / total_mass.
+ * Outside the theorem, by construction (ZL < 0): x = -0 gives +0 where the division gives -0, and x = +-inf gives NaN where the
+ * division gives +-inf.  Neither is observable in a step: every quotient is added to / subtracted from a non-zero term (temp is
+ * (+-10 + ...) / C itself), and an infinite dividend means the state was already non-finite. */
+int64_t ref_check_div_total_mass_f64(uint64_t seed, int64_t count) {
+    int64_t bad = 0;
+    uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+    const double C = (double)CP_TOTAL_MASS;
+    const double special[] = { 0.0, 1.0, -1.0, 0x1.19999ap+0, -0x1.19999ap+0, 0x1.fffffffffffffp+1000, -0x1p-900, 0x1p-900 };
+    for (unsigned i = 0; i < sizeof special / sizeof special[0]; ++i) {
+        const double a = ref_div_total_mass_f64_kernel(special[i]), b = special[i] / C;
+        if (memcmp(&a, &b, sizeof a) != 0) ++bad;
+    }
+    for (int64_t i = 0; i < count; ++i) {
+        s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+        const uint64_t r = s * 0x2545F4914F6CDD1Dull;
+        const uint64_t mant = r & 0xFFFFFFFFFFFFFull;
+        const int spread = (int)((r >> 52) & 0x3FF);                     /* 10 bits */
+        const int e = (spread & 3) ? (spread >> 2) % 41 - 20 : (spread >> 2) * 600 / 256 - 300;   /* 3/4: 2^-20 .. 2^20; 1/4: 2^-300 .. 2^300 */
+        union { uint64_t u; double d; } v;
+        v.u = ((r >> 63) << 63) | ((uint64_t)(1023 + e) << 52) | mant;
+        const double a = ref_div_total_mass_f64_kernel(v.d), b = v.d / C;
+        if (a != b) ++bad;
+    }
+    return bad;
+}
+
 int ref_cartpole_step_f64_kernel(double *state, int action, int *sbd, float *reward) {
     double x = state[0], x_dot = state[1], theta = state[2], theta_dot = state[3];
     float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;                           /* :146 */
     double costheta, sintheta;
     ref_sincos_f64_kernel(theta, &sintheta, &costheta);                                 /* :147-148, the kernel's own */
-    double temp = ((double)force + (double)CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta)
-                  / (double)CP_TOTAL_MASS;                                              /* :149 */
+    /* `/ total_mass` (:149-151) as the kernel evaluates it — proved equal to the plain division ref_cartpole_step_f64 keeps */
+    double temp = ref_div_total_mass_f64_kernel((double)force + (double)CP_POLEMASS_LENGTH * theta_dot * theta_dot * sintheta);   /* :149 */
     double thetaacc = ((double)CP_GRAVITY * sintheta - costheta * temp)
-                      / ((double)CP_LENGTH * (4.0 / 3.0 - (double)CP_MASSPOLE * costheta * costheta
-                                                            / (double)CP_TOTAL_MASS));  /* :150 */
-    double xacc = temp - (double)CP_POLEMASS_LENGTH * thetaacc * costheta
-                             / (double)CP_TOTAL_MASS;                                   /* :151 */
+                      / ((double)CP_LENGTH * (4.0 / 3.0 - ref_div_total_mass_f64_kernel((double)CP_MASSPOLE * costheta * costheta)));  /* :150 */
+    double xacc = temp - ref_div_total_mass_f64_kernel((double)CP_POLEMASS_LENGTH * thetaacc * costheta);   /* :151 */
     x = x + (double)CP_TAU * x_dot;                                                     /* :154 */
     x_dot = x_dot + (double)CP_TAU * xacc;                                              /* :155 */
     theta = theta + (double)CP_TAU * theta_dot;                                         /* :156 */

@@ -713,3 +713,42 @@ def test_f64_kernel_sincos_dense_sweep_against_libm(oracle):
     big = (np.abs(ws) > 1e-6) & (np.abs(wc) > 1e-6)             # away from the zeros, where an ulp is tiny and the reduction error shows
     assert ulp_diff(s[big], ws[big]).max() <= 3 and ulp_diff(c[big], wc[big]).max() <= 3
     assert np.abs(s - ws).max() < 3e-16 and np.abs(c - wc).max() < 3e-16
+
+
+def test_f64_constant_division_is_proved_and_sampled(oracle):
+    """The float64 kernel's `/ total_mass` (CartPoleEnv.cs:149-151) is fma(x, ZH, x * ZL) (cartpole64.hpp DivByTotalMass64, mirrored
+    in the oracle's twin).  (1) tools/prove_div_total_mass_f64.py PROVES in exact rational arithmetic that it equals IEEE division
+    for every binary64 dividend — the divisor is a 24-bit constant, so no quotient comes within 1/(2 * 9227469) ulp of a rounding
+    breakpoint while the fma pair is within 2^-53 ulp of the quotient — checks the ZL literals of the product and of the twin, and
+    verifies the constructed hardest dividends; (2) 1e8 pseudo-random dividends against the hardware's division: 0 mismatches;
+    (3) the twin built on it still reproduces the bit patterns committed in round 4 from the twin that divided
+    (test_f64_twin_reproduces_its_committed_bit_patterns) and equals the plain-division restatement on random states."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prove_div_total_mass_f64.py"), "--samples", "1500"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PROVED"), r.stdout[-1500:] + r.stderr[-1500:]
+    assert "0 mismatches" in r.stdout and "== RN(1/C - ZH)" in r.stdout
+    assert oracle.check_div_total_mass_f64(0x5EED, 100_000_000) == 0
+    L = oracle.lib()
+    C = oracle.cartpole_constants()["total_mass"]
+    for x in (10.0, -10.0, 0.1000000015, 3.3e-9, -7.25e11, 1e-200, 0.0):
+        assert L.ref_div_total_mass_f64_kernel(x) == x / C
+    # outside the theorem, documented (ZL < 0): the sign of a zero quotient and infinite dividends
+    assert L.ref_div_total_mass_f64_kernel(-0.0) == 0.0 and np.isnan(L.ref_div_total_mass_f64_kernel(np.inf))
+    # twin (fma pair) == the same operation sequence with the plain division, on states incl. large angles and velocities
+    rng = np.random.default_rng(5)
+    n = 200_000
+    s = np.stack([rng.uniform(-3, 3, n), rng.uniform(-30, 30, n), rng.uniform(-8, 8, n), rng.uniform(-40, 40, n)])
+    a = rng.integers(0, 2, n).astype(np.int32)
+    got = oracle.cartpole_step(s, a, dtype=np.float64, kernel_sincos=True)[0]
+    sn, cs = oracle.sincos_f64_kernel(s[2])
+    f = np.where(a == 1, 10.0, -10.0)
+    pml, mp, g, ln, tau = (oracle.cartpole_constants()[k] for k in ("polemass_length", "masspole", "gravity", "length", "tau"))
+    temp = (f + pml * s[3] * s[3] * sn) / C
+    thacc = (g * sn - cs * temp) / (ln * (4.0 / 3.0 - mp * cs * cs / C))
+    xacc = temp - pml * thacc * cs / C
+    want = np.stack([s[0] + tau * s[1], s[1] + tau * xacc, s[2] + tau * s[3], s[3] + tau * thacc])
+    assert np.array_equal(got, want)
