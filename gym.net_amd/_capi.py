@@ -98,6 +98,18 @@ class RolloutBuffers(C.Structure):
     _fields_ = [("d_obs", C.c_void_p), ("d_reward", C.c_void_p), ("d_done", C.c_void_p)]
 
 
+ACTIONS_RING, ACTIONS_SAMPLE, ACTIONS_EPSILON_GREEDY = 0, 1, 2
+
+
+class RolloutSpec(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("action_source", C.c_int32), ("d_actions", C.c_void_p), ("steps", C.c_int64),
+                ("action_stride", C.c_int64), ("ring", C.c_int64), ("action_seed", C.c_uint64), ("action_tick0", C.c_uint64),
+                ("epsilon", C.c_float), ("reserved", C.c_int32), ("d_rec_obs", C.c_void_p), ("d_rec_reward", C.c_void_p),
+                ("d_rec_done", C.c_void_p), ("d_rec_actions", C.c_void_p),
+                ("d_ep_step", C.c_void_p), ("d_ep_lane", C.c_void_p), ("d_ep_return", C.c_void_p), ("d_ep_length", C.c_void_p),
+                ("ep_capacity", C.c_int64), ("d_ep_count", C.c_void_p)]
+
+
 class Counters(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("tick", C.c_uint64),
                 ("lane_steps", C.c_uint64), ("stepped_after_done", C.c_uint64),
@@ -130,6 +142,7 @@ PROTOTYPES = {
     "gymnet_vecenv_step_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_rollout_device": (C.c_int, [_H, _P, C.c_int64, C.c_int64, C.c_int64]),
     "gymnet_vecenv_rollout_fused_device": (C.c_int, [_H, _P, C.c_int64, C.c_int64, C.c_int64, C.POINTER(RolloutBuffers)]),
+    "gymnet_vecenv_rollout_fused_ex_device": (C.c_int, [_H, C.POINTER(RolloutSpec)]),
     "gymnet_vecenv_pack_obs_device": (C.c_int, [_H, _P]),
     "gymnet_vecenv_sync": (C.c_int, [_H]),
     "gymnet_vecenv_device_view": (C.c_int, [_H, C.POINTER(DeviceView)]),

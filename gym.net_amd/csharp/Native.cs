@@ -74,6 +74,16 @@ namespace Gym.Envs.Amd {
     [StructLayout(LayoutKind.Sequential)]
     public struct GymnetRolloutBuffers { public IntPtr d_obs; public IntPtr d_reward; public IntPtr d_done; }
 
+    /// gymnet_vecenv_rollout_fused_ex_device (ABI 5): action source (0 ring, 1 ActionSpace.Sample() drawn in the kernel, 2 epsilon-greedy
+    /// over the ring as the policy's actions), dense recording, and the compact records of the episodes that end during the rollout.
+    [StructLayout(LayoutKind.Sequential)]
+    public struct GymnetRolloutSpec {
+        public uint struct_size; public int action_source; public IntPtr d_actions; public long steps; public long action_stride; public long ring;
+        public ulong action_seed; public ulong action_tick0; public float epsilon; public int reserved;
+        public IntPtr d_rec_obs; public IntPtr d_rec_reward; public IntPtr d_rec_done; public IntPtr d_rec_actions;
+        public IntPtr d_ep_step; public IntPtr d_ep_lane; public IntPtr d_ep_return; public IntPtr d_ep_length; public long ep_capacity; public IntPtr d_ep_count;
+    }
+
     [StructLayout(LayoutKind.Sequential)]
     public unsafe struct GymnetIpcHandle { public fixed byte bytes[64]; }
 
@@ -115,6 +125,7 @@ namespace Gym.Envs.Amd {
         [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_device(IntPtr h, IntPtr d_actions, long steps, long action_stride, long ring);
         [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_fused_device(IntPtr h, IntPtr d_actions, long steps, long action_stride, long ring, ref GymnetRolloutBuffers rec);
         [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_fused_device(IntPtr h, IntPtr d_actions, long steps, long action_stride, long ring, IntPtr rec_null);   // rec = NULL: record nothing
+        [DllImport(Lib)] public static extern int gymnet_vecenv_rollout_fused_ex_device(IntPtr h, ref GymnetRolloutSpec spec);
         [DllImport(Lib)] public static extern int gymnet_vecenv_pack_obs_device(IntPtr h, IntPtr d_obs_rowmajor);
         [DllImport(Lib)] public static extern int gymnet_vecenv_sync(IntPtr h);
         [DllImport(Lib)] public static extern int gymnet_vecenv_device_view(IntPtr h, out GymnetDeviceView view);

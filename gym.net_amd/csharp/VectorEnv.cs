@@ -158,6 +158,15 @@ namespace Gym.Envs.Amd {
             Native.Check(Native.gymnet_vecenv_set_launch_policy(_h, ref policy));
         }
 
+        /// ABI 5: `steps` vector steps in ONE kernel launch with what the consumer needs (BasePlaySession.cs:58-69, ReplayMemory.cs:53-67,
+        /// TrainingPlaySession.cs:46-52): actions from a device ring, drawn in the kernel (action_source 1: ActionSpace.Sample()) or
+        /// epsilon-greedy over the ring (2); dense recording; compact (step, lane, return, length) records of the episodes that end.
+        /// All pointers in `spec` are DEVICE pointers; stream-ordered, does not block.
+        public void RolloutFused(GymnetRolloutSpec spec) {
+            spec.struct_size = (uint) sizeof(GymnetRolloutSpec);
+            Native.Check(Native.gymnet_vecenv_rollout_fused_ex_device(_h, ref spec));
+        }
+
         /// ABI 4: any per-lane array the handle keeps, by id — with GetState / the tick / the seed a complete checkpoint of every
         /// configuration (episode return / length, done flags, per-lane Philox keys, ...).  T must be the array's element type.
         public T[] GetArray<T>(GymnetArrayId which, int count) where T : unmanaged {

@@ -169,7 +169,8 @@ int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
         return strict ? fail(h, GYMNET_ERR_INVALID_ARG, "launch policy: %s = %d is not available for this handle", what, v) : GYMNET_OK;
     };
     if (p.vec != -1) {
-        const bool ok = p.vec == 1 || (p.vec == 4 && h->can_vec4 && !wide2) || (p.vec == 2 && h->can_vec2 && wide2);
+        // 4: dwordx4 float rows — or, on a float64 handle, four doubles per thread (two dwordx4 per row); 2: Acrobot's packed form / two doubles
+        const bool ok = p.vec == 1 || (p.vec == 4 && h->can_vec4 && !acrobot) || (p.vec == 2 && h->can_vec2 && wide2);
         if (ok) c.vec = p.vec; else ST_TRY(bad("vec", p.vec));
     }
     if (p.block != -1) { if (p.block == 64 || p.block == 128 || p.block == 256) c.block = p.block; else ST_TRY(bad("block", p.block)); }
@@ -217,7 +218,7 @@ void default_policy(gymnet_vecenv *h) {
         // float32 path below
         const size_t step_bytes = (size_t)h->n * bytes_per_step(h);
         const bool can2 = aligned16(h->d_state) && (h->sstride % 2 == 0) && (!h->d_state_alt || aligned16(h->d_state_alt));
-        h->can_vec4 = false; h->can_vec2 = can2; h->lds_ok = false;
+        h->can_vec4 = can2; h->can_vec2 = can2; h->lds_ok = false;     // (vec = 4: four doubles per thread, the same 16-byte pieces)
         // measured at 2^20 lanes (73 MiB per step; us per step, gpurun_out r4): every stream non-temporal 14.3, state cacheable 14.8,
         // nothing non-temporal 16.2, one lane per thread 15.6
         h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, 0, 0};
@@ -589,6 +590,7 @@ int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     for (void *p : h->owned) (void)hipFree(p);
+    if (h->d_ep_seg) (void)hipFree(h->d_ep_seg);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->pin_block) (void)hipHostFree(h->pin_block);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -930,37 +932,118 @@ int gymnet_vecenv_rollout_device(gymnet_vecenv *h, const void *d_actions, int64_
 
 int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
                                        int64_t ring, const gymnet_rollout_buffers *rec) {
+    gymnet_rollout_spec spec{};
+    spec.struct_size = sizeof spec;
+    spec.action_source = GYMNET_ACTIONS_RING;
+    spec.d_actions = d_actions; spec.steps = steps; spec.action_stride = action_stride; spec.ring = ring;
+    if (rec) { spec.d_rec_obs = rec->d_obs; spec.d_rec_reward = rec->d_reward; spec.d_rec_done = rec->d_done; }
+    return gymnet_vecenv_rollout_fused_ex_device(h, &spec);
+}
+
+}  // extern "C"
+
+namespace {
+
+// segment buffers of the fused rollout's episode records: kShards segments of `cap` records each (t, lane, return, length) +
+// the shard counters.  Random lanes do not fill the shards evenly, so a segment gets twice its share of the caller's capacity.
+int ensure_episode_segments(gymnet_vecenv *h, int64_t capacity) {
+    const int64_t cap = 2 * ((capacity + kShards - 1) / kShards) + 64;
+    if (h->d_ep_seg && cap <= h->ep_seg_cap) return GYMNET_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));          // a previous rollout's gather may still read the old segments
+    if (h->d_ep_seg) (void)hipFree(h->d_ep_seg);
+    h->d_ep_seg = nullptr; h->ep_seg_cap = 0;
+    void *q = nullptr;
+    const size_t bytes = (size_t)kShards * (size_t)cap * 16 + (size_t)kShards * kCountStride * 4 + 8;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, GYMNET_ERR_OOM, "hipMalloc(%zu bytes) for the rollout's episode records failed: %s", bytes, hipGetErrorString(e));
+    h->d_ep_seg = q; h->ep_seg_cap = cap;
+    return GYMNET_OK;
+}
+
+template <class R>
+int rollout_fused_typed(gymnet_vecenv *h, const gymnet_rollout_spec &sp, LaunchCfg cfg, bool episodes) {
+    const StepArgsT<R> a = make_step_args<R>(h, sp.d_actions);
+    RolloutArgsT<R> r{};
+    r.steps = sp.steps; r.action_stride = sp.action_stride; r.ring = sp.ring;
+    r.rec_obs = static_cast<R *>(sp.d_rec_obs); r.rec_reward = sp.d_rec_reward; r.rec_done = sp.d_rec_done;
+    r.rec_action = sp.d_rec_actions;
+    r.action_source = sp.action_source; r.epsilon = sp.epsilon; r.action_seed = sp.action_seed; r.action_tick0 = sp.action_tick0;
+    if (episodes) {
+        char *seg = static_cast<char *>(h->d_ep_seg);
+        const size_t one = (size_t)kShards * (size_t)h->ep_seg_cap * 4;
+        r.ep_t = reinterpret_cast<int32_t *>(seg); r.ep_lane = reinterpret_cast<int32_t *>(seg + one);
+        r.ep_ret = h->d_ep_ret ? reinterpret_cast<float *>(seg + 2 * one) : nullptr;
+        r.ep_len = h->d_ep_ret ? reinterpret_cast<int32_t *>(seg + 3 * one) : nullptr;
+        r.ep_count = reinterpret_cast<uint32_t *>(seg + 4 * one);
+        r.ep_cap = h->ep_seg_cap;
+        HIP_TRY(h, hipMemsetAsync(r.ep_count, 0, (size_t)kShards * kCountStride * 4, h->stream));
+    }
+    HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, h->extras, a, r, cfg, h->stream));
+    if (episodes) {
+        EpisodeGatherArgs g{};
+        g.counts = r.ep_count; g.cap = r.ep_cap;
+        g.ep_t = r.ep_t; g.ep_lane = r.ep_lane; g.ep_ret = r.ep_ret; g.ep_len = r.ep_len;
+        g.out_t = sp.d_ep_step; g.out_lane = sp.d_ep_lane; g.out_ret = sp.d_ep_return; g.out_len = sp.d_ep_length;
+        g.out_capacity = sp.ep_capacity; g.out_count = sp.d_ep_count;
+        HIP_TRY(h, launch_gather_episodes(g, h->stream));
+    }
+    h->last_cparity = a.cparity;          // the done list (if any) describes the rollout's last step
+    return GYMNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout_spec *spec) {
     return guarded([&]() -> int {
     ENTER(h);
-    if (!d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
-    if (steps < 0 || ring < 1 || action_stride < 0) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
-    if (h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "the fused rollout has no DONE_LIST / EPISODE_STATS / FINAL_OBS / per-lane-seed variant");
-    if (h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device");
-    if (steps == 0) return GYMNET_OK;
-    LaunchCfg cfg = h->lcfg;
-    // wide accesses on the recorded streams: 16-byte rows of observations (4 floats / 2 doubles per thread), vec rewards, vec done bytes
-    const int w = cfg.vec > 1 ? cfg.vec : 1;
-    const bool rec_ok = !rec || ((!rec->d_obs || aligned16(rec->d_obs)) && (!rec->d_reward || aligned_to(rec->d_reward, 4 * w)) &&
-                                 (!rec->d_done || aligned_to(rec->d_done, w)));
-    if (cfg.vec > 1 && (!aligned_to(d_actions, 4 * cfg.vec) || (action_stride % cfg.vec) != 0 || (h->n % cfg.vec) != 0 || !rec_ok)) cfg.vec = 1;
-    if (h->f64) {       // float64 handle: rec->d_obs holds doubles, [steps][4][num_envs]
-        const StepArgsT<double> a = make_step_args<double>(h, d_actions);
-        RolloutArgsT<double> r{};
-        r.steps = steps; r.action_stride = action_stride; r.ring = ring;
-        if (rec) { r.rec_obs = static_cast<double *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
-        HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
-    } else {
-        const StepArgsT<float> a = make_step_args<float>(h, d_actions);
-        RolloutArgsT<float> r{};
-        r.steps = steps; r.action_stride = action_stride; r.ring = ring;
-        if (rec) { r.rec_obs = static_cast<float *>(rec->d_obs); r.rec_reward = rec->d_reward; r.rec_done = rec->d_done; }
-        HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, a, r, cfg, h->stream));
+    if (!spec) return fail(h, GYMNET_ERR_INVALID_ARG, "spec is null");
+    if (spec->struct_size != sizeof(gymnet_rollout_spec))
+        return fail(h, GYMNET_ERR_INVALID_ARG, "spec.struct_size %u != %zu (ABI mismatch)", spec->struct_size, sizeof(gymnet_rollout_spec));
+    const gymnet_rollout_spec &sp = *spec;
+    const EnvDesc &d = *h->desc;
+    if (sp.action_source < GYMNET_ACTIONS_RING || sp.action_source > GYMNET_ACTIONS_EPSILON_GREEDY) return fail(h, GYMNET_ERR_INVALID_ARG, "bad action_source %d", sp.action_source);
+    const bool ring_read = sp.action_source != GYMNET_ACTIONS_SAMPLE;
+    if (ring_read && !sp.d_actions) return fail(h, GYMNET_ERR_INVALID_ARG, "d_actions is null");
+    if (sp.steps < 0 || (ring_read && (sp.ring < 1 || sp.action_stride < 0))) return fail(h, GYMNET_ERR_INVALID_ARG, "bad steps/ring/action_stride");
+    if (sp.steps > INT32_MAX) return fail(h, GYMNET_ERR_INVALID_ARG, "steps must fit an int32 (episode records carry the step index)");
+    if (sp.action_source == GYMNET_ACTIONS_EPSILON_GREEDY) {
+        if (d.box_action) return fail(h, GYMNET_ERR_UNSUPPORTED, "epsilon-greedy composition is defined for Discrete action spaces");
+        if (!(sp.epsilon >= 0.0f && sp.epsilon <= 1.0f)) return fail(h, GYMNET_ERR_INVALID_ARG, "epsilon must be in [0, 1]");
     }
+    if ((h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) && ring_read)
+        return fail(h, GYMNET_ERR_UNSUPPORTED, "VALIDATE_ACTIONS is per step; use gymnet_vecenv_rollout_device (sampled actions are valid by construction)");
+    const bool episodes = sp.d_ep_lane || sp.d_ep_step || sp.d_ep_return || sp.d_ep_length || sp.d_ep_count;
+    if (episodes) {
+        if (!h->extras) return fail(h, GYMNET_ERR_UNSUPPORTED, "episode records need a bookkeeping handle (GYMNET_FLAG_EPISODE_STATS / DONE_LIST / FINAL_OBS)");
+        if ((sp.d_ep_return || sp.d_ep_length) && !h->d_ep_ret) return fail(h, GYMNET_ERR_UNSUPPORTED, "episode return / length records need GYMNET_FLAG_EPISODE_STATS");
+        if (sp.ep_capacity < 0 || !sp.d_ep_count) return fail(h, GYMNET_ERR_INVALID_ARG, "episode records need ep_capacity >= 0 and d_ep_count");
+    }
+    if (sp.d_rec_actions && !h->extras && sp.action_source == GYMNET_ACTIONS_RING)
+        return fail(h, GYMNET_ERR_UNSUPPORTED, "d_rec_actions: the actions of a plain ring rollout ARE the ring (recorded for sampled / epsilon-greedy actions and on bookkeeping handles)");
+    if (sp.steps == 0) {
+        if (episodes) HIP_TRY(h, hipMemsetAsync(sp.d_ep_count, 0, 2 * sizeof(uint32_t), h->stream));
+        return GYMNET_OK;
+    }
+    LaunchCfg cfg = h->lcfg;
+    // wide accesses on the streams a rollout touches: 16-byte rows of observations (4 floats / 2 doubles per thread), vec rewards /
+    // actions, vec done bytes; anything less aligned runs one lane per thread (same bits)
+    if (cfg.vec > 1) {
+        const int w = h->f64 ? 2 : cfg.vec;               // the fused rollout's wide form: 2 doubles / 4 floats (2: Acrobot) per thread
+        bool ok = (h->n % w) == 0;
+        if (ring_read) ok = ok && aligned_to(sp.d_actions, 4 * w) && (sp.action_stride % w) == 0;
+        ok = ok && (!sp.d_rec_obs || aligned16(sp.d_rec_obs)) && (!sp.d_rec_reward || aligned_to(sp.d_rec_reward, 4 * w)) &&
+             (!sp.d_rec_done || aligned_to(sp.d_rec_done, w)) && (!sp.d_rec_actions || aligned_to(sp.d_rec_actions, 4 * w));
+        if (!ok) cfg.vec = 1;
+    }
+    if (episodes) ST_TRY(ensure_episode_segments(h, sp.ep_capacity));
+    ST_TRY(h->f64 ? rollout_fused_typed<double>(h, sp, cfg, episodes) : rollout_fused_typed<float>(h, sp, cfg, episodes));
     swap_buffers(h);                     // DOUBLE_BUFFER: the launch read one buffer and wrote the other, once
-    h->tick += (uint64_t)steps;
+    h->tick += (uint64_t)sp.steps;
     h->tslot ^= 1;                       // one launch: it read one half of d_tick2 and wrote the other
     h->step_launches += 1;
-    h->lane_steps += (uint64_t)steps * (uint64_t)h->n;
+    h->lane_steps += (uint64_t)sp.steps * (uint64_t)h->n;
     return GYMNET_OK;
     });
 }

@@ -133,6 +133,7 @@ struct CartPole64 {
     static constexpr bool PIPE_PAIRS = true; // step_kernel_pipe2: ITEMS lane pairs per thread (13.1 vs 14.4 us at 2^20 lanes, round 4)
     static constexpr bool RESET_TAKES_KEY = true;                   // reset() makes its own two Philox calls (53-bit uniforms)
     static constexpr const char *NAME = "CartPole64";
+    static constexpr int32_t ACTION_N = 2;
     static constexpr bool HAS_SMALL_ANGLE_PATH = true;
     static constexpr int ANGLE_ROW = 2;
     static constexpr double SMALL_ANGLE_BOUND = kSmallAngle64;

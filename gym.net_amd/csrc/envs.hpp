@@ -181,6 +181,7 @@ struct CartPole {
     using Real = float;                      // state scalar of this engine (CartPole64 in cartpole64.hpp: the reference's float64)
     static constexpr bool RESET_TAKES_KEY = false;                  // reset() takes the four words of one Philox call
     static constexpr const char *NAME = "CartPole";
+    static constexpr int32_t ACTION_N = 2;                          // Discrete(2).Sample(): start 0 + randint(0, 2)  (Discrete.cs:17-28)
 
     // :24-36 — the float32 values of the C# consts (total_mass, polemass_length const-folded in float)
     static constexpr float gravity = 9.8f;
@@ -269,6 +270,7 @@ struct Pendulum {
     using Real = float;
     static constexpr bool RESET_TAKES_KEY = false;
     static constexpr const char *NAME = "Pendulum";
+    static constexpr float ACTION_LOW = -2.0f, ACTION_HIGH = 2.0f;  // Box(-2, 2, (1,)).Sample(): the bounded regime, uniform(low, high)  (Box.cs:85)
     static constexpr float PI = 3.14159265358979323846f;
 
     // fmodf(a, m) for the ONE modulus the env uses (m = 2 pi), in ~11 instructions instead of OCML's iterative reduction, and
@@ -342,6 +344,7 @@ struct MountainCar {
     using Real = float;
     static constexpr bool RESET_TAKES_KEY = false;
     static constexpr const char *NAME = "MountainCar";
+    static constexpr int32_t ACTION_N = 3;
 
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         float p = s[0], v = s[1];
@@ -387,6 +390,7 @@ struct Acrobot {
     using Real = float;
     static constexpr bool RESET_TAKES_KEY = false;
     static constexpr const char *NAME = "Acrobot";
+    static constexpr int32_t ACTION_N = 3;
     static constexpr float PI = 3.14159265358979323846f;
 
     // m1 = m2 = l1 = I1 = I2 = 1, lc1 = lc2 = 0.5, g = 9.8 folded into the literals.

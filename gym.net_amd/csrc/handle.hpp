@@ -92,6 +92,8 @@ struct gymnet_vecenv {
     float *pin_reward = nullptr;
     uint8_t *pin_done = nullptr;
     uint32_t *d_bad = nullptr;
+    void *d_ep_seg = nullptr;      // fused rollout: segmented episode records + shard counters (allocated on first use, grown on demand)
+    int64_t ep_seg_cap = 0;        // records per shard segment
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
     int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
     int last_cparity = -1;

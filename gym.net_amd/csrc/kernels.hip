@@ -84,6 +84,50 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const CompactArgsT<R>
     }
 }
 
+// The episode records of a fused rollout (RolloutArgs::ep_*: kShards segments of (t, lane, return, length)) gathered into compact
+// arrays; same shape as compact_done_kernel: one workgroup per shard, each recomputes the scan of the 256 shard counts in LDS.
+// A shard's count may exceed its capacity (records beyond it were dropped by the rollout kernel): only the kept ones move.
+__global__ __launch_bounds__(256) void gather_episodes_kernel(const EpisodeGatherArgs a) {
+    __shared__ uint32_t scan[kShards];
+    const int t = threadIdx.x;
+    const uint32_t raw = a.counts[t * kCountStride];
+    const uint32_t mine = (int64_t)raw < a.cap ? raw : (uint32_t)a.cap;
+    scan[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < kShards; d <<= 1) {            // Hillis-Steele inclusive scan, 8 rounds
+        const uint32_t v = t >= d ? scan[t - d] : 0u;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const int shard = blockIdx.x;
+    const uint32_t raw_s = a.counts[shard * kCountStride];
+    const uint32_t cnt = (int64_t)raw_s < a.cap ? raw_s : (uint32_t)a.cap;
+    const uint32_t start = scan[shard] - cnt;
+    if (shard == 0 && a.out_count) {
+        // out_count[0]: records written to the out arrays; out_count[1]: episodes that ENDED during the rollout (sum of the raw
+        // shard counts: larger than [0] when a segment or the caller's capacity overflowed)
+        __shared__ uint32_t raw_sum[kShards];
+        raw_sum[t] = raw;
+        __syncthreads();
+        for (int d = kShards / 2; d > 0; d >>= 1) { if (t < d) raw_sum[t] += raw_sum[t + d]; __syncthreads(); }
+        if (t == 0) {
+            const uint32_t kept = scan[kShards - 1];
+            a.out_count[0] = (int64_t)kept < a.out_capacity ? kept : (uint32_t)a.out_capacity;
+            a.out_count[1] = raw_sum[0];
+        }
+    }
+    const int64_t seg0 = (int64_t)shard * a.cap;
+    for (uint32_t k = t; k < cnt; k += 256) {
+        const uint32_t dst = start + k;
+        if ((int64_t)dst >= a.out_capacity) continue;
+        if (a.out_t) a.out_t[dst] = a.ep_t[seg0 + k];
+        if (a.out_lane) a.out_lane[dst] = a.ep_lane[seg0 + k];
+        if (a.out_ret && a.ep_ret) a.out_ret[dst] = a.ep_ret[seg0 + k];
+        if (a.out_len && a.ep_len) a.out_len[dst] = a.ep_len[seg0 + k];
+    }
+}
+
 template <class T, int O>
 __global__ __launch_bounds__(256) void export_small_kernel(const T *__restrict__ obs, int64_t stride, const float *__restrict__ reward,
                                                            const uint8_t *__restrict__ done, T *out_obs, float *out_reward,
@@ -325,19 +369,24 @@ void resolved_step_shape(int env_id, bool f64, bool autoreset, bool extras, Laun
     }
 }
 
-hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<float> &a, const RolloutArgsT<float> &r, LaunchCfg cfg, hipStream_t st) {
+hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, const RolloutArgsT<float> &r, LaunchCfg cfg, hipStream_t st) {
     switch (env_id) {
-        case 0: return launch_rollout_cartpole(autoreset, a, r, cfg, st);
-        case 1: return launch_rollout_pendulum(autoreset, a, r, cfg, st);
-        case 2: return launch_rollout_mountaincar(autoreset, a, r, cfg, st);
-        case 3: return launch_rollout_acrobot(autoreset, a, r, cfg, st);
+        case 0: return launch_rollout_cartpole(autoreset, extras, a, r, cfg, st);
+        case 1: return launch_rollout_pendulum(autoreset, extras, a, r, cfg, st);
+        case 2: return launch_rollout_mountaincar(autoreset, extras, a, r, cfg, st);
+        case 3: return launch_rollout_acrobot(autoreset, extras, a, r, cfg, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<double> &a, const RolloutArgsT<double> &r, LaunchCfg cfg, hipStream_t st) {
+hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const StepArgsT<double> &a, const RolloutArgsT<double> &r, LaunchCfg cfg, hipStream_t st) {
     if (env_id != 0) return hipErrorInvalidValue;
-    return launch_rollout_cartpole64(autoreset, a, r, cfg, st);
+    return launch_rollout_cartpole64(autoreset, extras, a, r, cfg, st);
+}
+
+hipError_t launch_gather_episodes(const EpisodeGatherArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(gather_episodes_kernel, dim3(kShards), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_reset(int env_id, const ResetArgsT<float> &a, hipStream_t st) {

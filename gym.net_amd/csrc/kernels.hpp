@@ -64,11 +64,17 @@ struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1;
     hipError_t launch_step_##tag(bool autoreset, bool extras, const StepArgsT<R> &a, LaunchCfg cfg, hipStream_t st);            \
     int describe_step_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, char *buf, size_t cap);                      \
     void resolved_shape_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential);                \
-    hipError_t launch_rollout_##tag(bool autoreset, const StepArgsT<R> &a, const RolloutArgsT<R> &r, LaunchCfg cfg, hipStream_t st); \
+    hipError_t launch_rollout_##tag(bool autoreset, bool extras, const StepArgsT<R> &a, const RolloutArgsT<R> &r, LaunchCfg cfg, hipStream_t st); \
     hipError_t launch_reset_##tag(const ResetArgsT<R> &a, hipStream_t st);                                                      \
     hipError_t launch_observe_##tag(const R *state, int64_t sstride, R *obs, int64_t ostride, int64_t n, hipStream_t st);
 
 // Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
+// Round 5: the rollout carries what its consumer needs (examples/.../PlaySessions/BasePlaySession.cs:58-69 accumulates the episode
+// reward and keeps the best episodes, MemoryTypes/ReplayMemory.cs:53-67; TrainingPlaySession.cs:46-52 draws epsilon-greedy actions
+// per step): on a bookkeeping handle the running episode return / length live in registers, max_episode_steps truncates, per-lane
+// seeds key the reset draws, and every finished episode leaves a compact (t, lane, return, length) record; and the actions can be
+// DRAWN IN THE KERNEL — the words sample_discrete_kernel / compose_discrete_kernel would produce for (action_seed, action_tick0 + t)
+// — so a random or epsilon-greedy rollout reads no action ring at all.
 template <class R>
 struct RolloutArgsT {
     int64_t steps;           // T
@@ -77,6 +83,18 @@ struct RolloutArgsT {
     R *rec_obs;              // optional [T][O][n]   (NULL = do not record)
     float *rec_reward;       // optional [T][n]
     uint8_t *rec_done;       // optional [T][n]
+    void *rec_action;        // optional [T][n] the actions TAKEN (int32 / float32): what a replay memory stores beside obs / reward / done
+    // action source: 0 = the ring (StepArgs::action); 1 = ActionSpace.Sample() per lane and step; 2 = epsilon-greedy — with
+    // probability epsilon the sampled action, else the ring's (policy) action.  Philox action stream, counter (global lane, action_tick0 + t).
+    int32_t action_source;
+    float epsilon;
+    uint64_t action_seed, action_tick0;
+    // compact episode records of the WHOLE rollout, segmented like StepArgs::done_list: wave w appends to shard w % kShards
+    // (ep_count[shard * kCountStride], one atomic per wave and step that has a finished lane), record p of shard s at s * ep_cap + p
+    int32_t *ep_t, *ep_lane;      // step index inside the rollout, lane
+    float *ep_ret; int32_t *ep_len;
+    uint32_t *ep_count;           // [kShards * kCountStride], zeroed by the launcher; counts beyond ep_cap are dropped records
+    int64_t ep_cap;
 };
 typedef RolloutArgsT<float> RolloutArgs;
 typedef RolloutArgsT<double> RolloutArgs64;
@@ -112,9 +130,18 @@ int describe_step_kernel(int env_id, bool f64, bool autoreset, bool extras, Laun
 // one after another in the multi-lane forms (1 = one-shot kernel)
 void resolved_step_shape(int env_id, bool f64, bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential);
 
-// Same results as `steps` launch_step calls (bitwise).
-hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<float> &a, const RolloutArgsT<float> &r, LaunchCfg cfg, hipStream_t st);
-hipError_t launch_rollout_fused(int env_id, bool autoreset, const StepArgsT<double> &a, const RolloutArgsT<double> &r, LaunchCfg cfg, hipStream_t st);
+// Same results as `steps` launch_step calls (bitwise) — with r.action_source != 0: as `steps` x (sample / compose actions, then step).
+hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, const RolloutArgsT<float> &r, LaunchCfg cfg, hipStream_t st);
+hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const StepArgsT<double> &a, const RolloutArgsT<double> &r, LaunchCfg cfg, hipStream_t st);
+// Gathers the kShards segments of a fused rollout's episode records (RolloutArgs::ep_*) into compact arrays out_*[0 .. *out_count);
+// records beyond out_capacity are dropped, the count is the number of records kept by the rollout.  Any out array may be NULL.
+struct EpisodeGatherArgs {
+    const uint32_t *counts; int64_t cap;
+    const int32_t *ep_t, *ep_lane; const float *ep_ret; const int32_t *ep_len;
+    int32_t *out_t, *out_lane; float *out_ret; int32_t *out_len;
+    int64_t out_capacity; uint32_t *out_count;
+};
+hipError_t launch_gather_episodes(const EpisodeGatherArgs &a, hipStream_t st);
 
 hipError_t launch_reset(int env_id, const ResetArgsT<float> &a, hipStream_t st);
 hipError_t launch_reset(int env_id, const ResetArgsT<double> &a, hipStream_t st);

@@ -259,6 +259,56 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, typename En
     }
 }
 
+// wave64 compaction of the sub-lanes flagged in `finished`: rank of every flagged sub-lane inside the wave (ballot + mbcnt),
+// returns how many the wave holds
+template <int VEC>
+__device__ __forceinline__ uint32_t rank_finished(const bool (&finished)[VEC], uint32_t (&off)[VEC]) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const uint64_t m = __ballot(finished[j]);
+        off[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        total += (uint32_t)__popcll(m);
+    }
+    return total;
+}
+
+// The done list of ONE vector step (before the reset overwrites the terminal state): ballot per sub-lane, one atomic per wave into
+// the wave's shard, order inside the list unspecified.  Everything known about a finished lane is written at ITS
+// POSITION in the list — lane id, and with the corresponding flags its episode return / length and its terminal
+// observation: a wave's ~11 finished lanes write one or two contiguous cache lines per array instead of one
+// scattered line each (compacted (lane, return, length) records, BasePlaySession.cs:58-69).
+template <class Env, int VEC>
+__device__ __forceinline__ void append_done_records(const StepArgsT<typename Env::Real> &a, const bool (&finished)[VEC], int64_t i0,
+                                                    const typename Env::Real (&s)[Env::S][VEC], const typename Env::Real (&o)[Env::O][VEC],
+                                                    const float (&fin_ret)[VEC], const int32_t (&fin_len)[VEC], bool stats) {
+    constexpr int S = Env::S, O = Env::O;
+    const uint32_t lane = lane_id();
+    uint32_t off[VEC];
+    const uint32_t total = rank_finished<VEC>(finished, off);
+    if (total) {   // wave-uniform
+        const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+        const uint32_t shard = wave_shard();
+        uint32_t base = 0;
+        if ((int)lane == leader)
+            base = atomicAdd(&a.done_count2[a.cparity * (kShards * kCountStride) + shard * kCountStride], total);
+        base = __shfl(base, leader);
+        const int64_t seg0 = (int64_t)shard * a.done_cap;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (!finished[j]) continue;
+            const int64_t pos = seg0 + base + off[j];
+            a.done_list[pos] = (int32_t)(i0 + j);
+            if (stats) { a.rec_ret[pos] = fin_ret[j]; a.rec_len[pos] = fin_len[j]; }
+            if (a.rec_obs) {
+#pragma unroll
+                for (int k = 0; k < O; ++k)
+                    a.rec_obs[((int64_t)shard * O + k) * a.done_cap + base + off[j]] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The vector step: ONE launch advances every lane by one env-step.
 //   Env       dynamics (envs.hpp)
@@ -373,43 +423,7 @@ __device__ __forceinline__ void advance_and_store(const StepArgsT<typename Env::
     store_u8<VEC, NT_O, GUARD>(a.done, i0, n, done);
 
     if constexpr (EXTRAS) {
-        if (a.done_list) {
-            // wave64 compaction (before the reset overwrites the terminal state): ballot per sub-lane, one atomic per wave into
-            // the wave's shard, order inside the list unspecified.  Everything known about a finished lane is written at ITS
-            // POSITION in the list — lane id, and with the corresponding flags its episode return / length and its terminal
-            // observation: a wave's ~11 finished lanes write one or two contiguous cache lines per array instead of one
-            // scattered line each (compacted (lane, return, length) records, BasePlaySession.cs:58-69).
-            const uint32_t lane = lane_id();
-            uint32_t off[VEC];
-            uint32_t total = 0;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const uint64_t m = __ballot(finished[j]);
-                off[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                total += (uint32_t)__popcll(m);
-            }
-            if (total) {   // wave-uniform
-                const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
-                const uint32_t shard = wave_shard();
-                uint32_t base = 0;
-                if ((int)lane == leader)
-                    base = atomicAdd(&a.done_count2[a.cparity * (kShards * kCountStride) + shard * kCountStride], total);
-                base = __shfl(base, leader);
-                const int64_t seg0 = (int64_t)shard * a.done_cap;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    if (!finished[j]) continue;
-                    const int64_t pos = seg0 + base + off[j];
-                    a.done_list[pos] = (int32_t)(i0 + j);
-                    if (stats) { a.rec_ret[pos] = fin_ret[j]; a.rec_len[pos] = fin_len[j]; }
-                    if (a.rec_obs) {
-#pragma unroll
-                        for (int k = 0; k < O; ++k)
-                            a.rec_obs[((int64_t)shard * O + k) * a.done_cap + base + off[j]] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
-                    }
-                }
-            }
-        }
+        if (a.done_list) append_done_records<Env, VEC>(a, finished, i0, s, o, fin_ret, fin_len, stats);
     }
 
     if constexpr (AUTORESET && RESETF == 1) reset_pending_wave<Env, VEC, EXTRAS>(pending, s, a, i0, n, tick, sc);
@@ -684,7 +698,18 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgsT<typename Env:
 // CartPole, and the load-phase / store-phase serialisation of the one-step kernel disappears.  The next step's
 // action is loaded before the current step's math.  Results are bit-identical to T one-step launches.
 // ---------------------------------------------------------------------------------------------
-template <class Env, int VEC, bool AUTORESET, bool GUARD>
+// ActionSpace.Sample() of one lane for one step, drawn in the kernel: the words of sample_discrete_kernel / sample_box_kernel
+// (kernels.hip) for the same (seed, global lane, tick) — word 0 is the action, word 1 the epsilon-greedy coin (compose_discrete_kernel).
+template <class Env>
+__device__ __forceinline__ typename Env::Action sampled_action(const PhiloxWords &r) {
+    if constexpr (Env::BOX_ACTION) return Env::ACTION_LOW + (Env::ACTION_HIGH - Env::ACTION_LOW) * u01_24(r.w[0]);     // Box.cs:85
+    else return (int32_t)__umulhi(r.w[0], (uint32_t)Env::ACTION_N);                                                    // Discrete.cs:27
+}
+
+//   EXTRAS  bookkeeping handle (EPISODE_STATS / DONE_LIST / FINAL_OBS / per-lane seeds): running return / length in registers,
+//           truncation, dense last-finished-episode views, per-rollout compact episode records, the done list of the LAST step
+//   SAMPLE  the actions are drawn in the kernel (RolloutArgs::action_source 1 or 2) instead of read from the ring
+template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE>
 __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &ro,
                                              const int64_t i0, const uint64_t tick0) {
     constexpr int S = Env::S, O = Env::O;
@@ -705,16 +730,45 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     };
 
     Act act[VEC], act_next[VEC];
-    load_action(0, act);
+    // the ring is read unless every action is sampled; epsilon-greedy (action_source 2) reads it as the POLICY's actions
+    bool use_ring = true;                                          // kernel-uniform
+    if constexpr (SAMPLE) {
+        use_ring = ro.action_source == 2;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { act[j] = Act(0); act_next[j] = Act(0); }
+        if (use_ring) load_action(0, act);
+    } else {
+        load_action(0, act);
+    }
     int64_t slice = 0;
     float reward[VEC];
     uint8_t done[VEC];
     Real o[O][VEC];
 
+    // bookkeeping state (EXTRAS): the running episode return / length of the thread's lanes stay in registers for the whole rollout
+    float ep_ret[VEC], fin_ret[VEC];
+    int32_t ep_len[VEC], fin_len[VEC];
+    bool stats = false;
+    if constexpr (EXTRAS) {
+        stats = a.ep_ret != nullptr;
+        if (stats) { load_f32<VEC, true, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, true, GUARD>(a.ep_len, i0, n, ep_len); }
+    }
+
     for (int64_t t = 0; t < ro.steps; ++t) {
         int64_t nslice = slice + 1;
         if (nslice == ro.ring) nslice = 0;
-        if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math
+        if constexpr (SAMPLE) {
+            if (use_ring && t + 1 < ro.steps) load_action(nslice, act_next);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const PhiloxWords r = stream_words(kStreamAction, ro.action_seed, a.lane_offset + (uint64_t)(i0 + j), ro.action_tick0 + (uint64_t)t);
+                const Act drawn = sampled_action<Env>(r);
+                if constexpr (Env::BOX_ACTION) act[j] = drawn;                   // (epsilon-greedy is defined for Discrete spaces)
+                else act[j] = (ro.action_source == 2 && !(u01_24(r.w[1]) <= ro.epsilon)) ? act[j] : drawn;   // TrainingPlaySession.cs:46-52
+            }
+        } else {
+            if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math
+        }
         uint32_t pending = 0;
         bool after[VEC];
 #pragma unroll
@@ -735,7 +789,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
                     advance_sublane<Env, AUTORESET, decltype(small_tag)::value>(sj, act[j], sbd[j], rw, dn, after[j], !GUARD || i0 + j < n, oj);
                     done[j] = dn ? 1 : 0;
                     reward[j] = rw;
-                    if constexpr (AUTORESET) pending |= dn ? (1u << j) : 0u;
+                    if constexpr (AUTORESET && !EXTRAS) pending |= dn ? (1u << j) : 0u;
 #pragma unroll
                     for (int k = 0; k < S; ++k) s[k][j] = sj[k];
                     if constexpr (!Env::OBS_ALIASES_STATE) {
@@ -756,13 +810,70 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 done[j] = dnv[j] ? 1 : 0;
-                if constexpr (AUTORESET) pending |= dnv[j] ? (1u << j) : 0u;
+                if constexpr (AUTORESET && !EXTRAS) pending |= dnv[j] ? (1u << j) : 0u;
             }
+        }
+        if constexpr (EXTRAS) {
+            // the step kernel's bookkeeping (advance_and_store), per step of the rollout: truncation, the dense "last finished
+            // episode per lane" views, and the compact records of this step's finished lanes
+            bool finished[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const bool in_range = !GUARD || i0 + j < n;
+                fin_ret[j] = 0.0f; fin_len[j] = 0;
+                if (stats) {
+                    ep_ret[j] += reward[j];
+                    ep_len[j] += 1;
+                    if (a.max_episode_steps > 0 && ep_len[j] >= a.max_episode_steps) done[j] |= 2;   // truncated (extension)
+                }
+                const bool fin = done[j] != 0;
+                finished[j] = fin && in_range;
+                if (fin && a.final_obs && in_range) {
+#pragma unroll
+                    for (int k = 0; k < O; ++k) a.final_obs[k * n + i0 + j] = Env::OBS_ALIASES_STATE ? s[k < S ? k : 0][j] : o[k][j];
+                }
+                if (stats && fin && in_range) {
+                    fin_ret[j] = ep_ret[j];
+                    fin_len[j] = ep_len[j];
+                    if (a.fin_ret) { a.fin_ret[i0 + j] = ep_ret[j]; a.fin_len[i0 + j] = ep_len[j]; }
+                    if constexpr (AUTORESET) { ep_ret[j] = 0.0f; ep_len[j] = 0; }
+                }
+                if constexpr (AUTORESET) pending |= fin ? (1u << j) : 0u;
+            }
+            if (ro.ep_lane) {
+                // (t, lane, return, length) of every episode that ended in this step, compacted per wave: ballot + ONE atomic per
+                // wave into the wave's shard — 4096 waves appending to one counter would serialise (StepArgs::done_list)
+                uint32_t off[VEC];
+                const uint32_t total = rank_finished<VEC>(finished, off);
+                if (total) {   // wave-uniform
+                    const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+                    const uint32_t shard = wave_shard();
+                    uint32_t base = 0;
+                    if ((int)lane_id() == leader) base = atomicAdd(&ro.ep_count[shard * kCountStride], total);
+                    base = __shfl(base, leader);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (!finished[j] || (int64_t)(base + off[j]) >= ro.ep_cap) continue;       // beyond the capacity: counted, not kept
+                        const int64_t pos = (int64_t)shard * ro.ep_cap + base + off[j];
+                        ro.ep_t[pos] = (int32_t)t;
+                        ro.ep_lane[pos] = (int32_t)(i0 + j);
+                        if (ro.ep_ret) { ro.ep_ret[pos] = fin_ret[j]; ro.ep_len[pos] = fin_len[j]; }
+                    }
+                }
+            }
+            // the done list "of the most recent step" (gymnet_vecenv_done_lanes / _done_records) describes the rollout's LAST step
+            if (a.done_list && t + 1 == ro.steps) append_done_records<Env, VEC>(a, finished, i0, s, o, fin_ret, fin_len, stats);
         }
         if constexpr (!AUTORESET && Env::HAS_SBD) count_after_done<VEC>(a, after);
         if (ro.rec_reward) store_f32<VEC, true, GUARD>(ro.rec_reward + t * n, i0, n, reward);
         if (ro.rec_done) store_u8<VEC, true, GUARD>(ro.rec_done + t * n, i0, n, done);
-        if constexpr (AUTORESET) reset_pending<Env, VEC, false>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
+        if constexpr (EXTRAS || SAMPLE) {
+            if (ro.rec_action) {
+                if constexpr (Env::BOX_ACTION) store_f32<VEC, true, GUARD>(static_cast<float *>(ro.rec_action) + t * n, i0, n, act);
+                else store_i32<VEC, true, GUARD>(static_cast<int32_t *>(ro.rec_action) + t * n, i0, n, act);
+            }
+        }
+        if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
         if (ro.rec_obs) {
 #pragma unroll
             for (int k = 0; k < O; ++k) {
@@ -785,18 +896,25 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     store_f32<VEC, false, GUARD>(a.reward, i0, n, reward);
     store_u8<VEC, false, GUARD>(a.done, i0, n, done);
     if constexpr (!AUTORESET && Env::HAS_SBD) store_i32<VEC, false, GUARD>(a.sbd, i0, n, sbd);
+    if constexpr (EXTRAS) {
+        if (stats) { store_f32<VEC, false, GUARD>(a.ep_ret, i0, n, ep_ret); store_i32<VEC, false, GUARD>(a.ep_len, i0, n, ep_len); }
+    }
 }
 
-template <class Env, int VEC, bool AUTORESET>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false>
 __global__ __launch_bounds__(256) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     const uint64_t tick0 = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
+    if constexpr (EXTRAS) {
+        if (blockIdx.x == 0 && a.done_count2)     // zero the NEXT step launch's half of the shard counters (as step_kernel does)
+            for (int sh = threadIdx.x; sh < kShards; sh += blockDim.x) a.done_count2[(a.cparity ^ 1) * (kShards * kCountStride) + sh * kCountStride] = 0u;
+    }
     if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {     // full workgroup: no bounds checks inside the T-step loop
-        rollout_body<Env, VEC, AUTORESET, false>(a, ro, i0, tick0);
+        rollout_body<Env, VEC, AUTORESET, false, EXTRAS, SAMPLE>(a, ro, i0, tick0);
     } else {
         if (i0 >= a.n) return;
-        rollout_body<Env, VEC, AUTORESET, true>(a, ro, i0, tick0);
+        rollout_body<Env, VEC, AUTORESET, true, EXTRAS, SAMPLE>(a, ro, i0, tick0);
     }
 }
 
@@ -882,6 +1000,10 @@ static LaunchCfg normalized(LaunchCfg cfg) {
 // two-lane packed-FP32 form (Acrobot), two lanes per thread on dwordx2 streams
 template <class Env>
 constexpr int wide_of() { return (sizeof(typename Env::Real) == 8 || Env::PACKED2) ? 2 : 4; }
+// a second wide form: FOUR float64 lanes per thread (two dwordx4 per state row and direction, 32 contiguous bytes per thread:
+// the float32 flagship's shape — dwordx4 actions / rewards, one 32-bit done store) — launch policy vec = 4 on a float64 handle
+template <class Env>
+constexpr int wide_alt_of() { return sizeof(typename Env::Real) == 8 ? 4 : 0; }
 
 template <class Env>
 static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg, int64_t n) {
@@ -901,10 +1023,39 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
             return v;
         }
     }
-    if (cfg.vec > 1) v.vec = wide_of<Env>();
-    // wave-compacted fused reset: wide variant of an env whose observation IS its state
-    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec == wide_of<Env>() && autoreset) v.resetf = 1;
+    if (cfg.vec > 1) v.vec = (wide_alt_of<Env>() != 0 && cfg.vec == wide_alt_of<Env>()) ? wide_alt_of<Env>() : wide_of<Env>();
+    // wave-compacted fused reset: wide variants of an env whose observation IS its state
+    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec > 1 && autoreset) v.resetf = 1;
     return v;
+}
+
+// the one-shot kernel with V lanes per thread: dispatch on (AUTORESET, EXTRAS, non-temporal mask, reset form)
+template <class Env, int V>
+static hipError_t launch_one_shot(const StepVariant &v, bool autoreset, bool extras, const LaunchCfg &cfg, const StepArgsT<typename Env::Real> &a,
+                                  hipStream_t st) {
+    const int64_t threads = (a.n + V - 1) / V;
+    const dim3 grid(grid_for(threads > 0 ? threads : 1, cfg.block)), blk(cfg.block);
+#define GYMNET_LAUNCH(AR, EX, NTM, RF) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM, RF>), grid, blk, (size_t)cfg.lds_bytes, st, a)
+#define GYMNET_LAUNCH_NT(AR, EX, RF)                                  \
+    do {                                                              \
+        if (v.nt == 15) GYMNET_LAUNCH(AR, EX, 15, RF);                \
+        else if (v.nt == 12) GYMNET_LAUNCH(AR, EX, 12, RF);           \
+        else GYMNET_LAUNCH(AR, EX, 0, RF);                            \
+    } while (0)
+    if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2 && V > 1) {
+        if (v.resetf == 1) {      // (resolve_variant: only with auto-reset)
+            if (extras) GYMNET_LAUNCH_NT(true, true, 1); else GYMNET_LAUNCH_NT(true, false, 1);
+            return hipGetLastError();
+        }
+    }
+    if (extras) {   // bookkeeping variants follow the same stream policy (their own arrays stay cacheable)
+        if (autoreset) GYMNET_LAUNCH_NT(true, true, 0); else GYMNET_LAUNCH_NT(false, true, 0);
+    } else {
+        if (autoreset) GYMNET_LAUNCH_NT(true, false, 0); else GYMNET_LAUNCH_NT(false, false, 0);
+    }
+#undef GYMNET_LAUNCH_NT
+#undef GYMNET_LAUNCH
+    return hipGetLastError();
 }
 
 template <class Env>
@@ -959,41 +1110,11 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
             return hipGetLastError();
         }
     }
-    constexpr int WIDE = wide_of<Env>();
-    const bool wide = v.vec > 1;
-    const int64_t threads = (a.n + v.vec - 1) / v.vec;
-    const dim3 grid(grid_for(threads > 0 ? threads : 1, cfg.block)), blk(cfg.block);
-#define GYMNET_LAUNCH(V, AR, EX, NTM) hipLaunchKernelGGL((step_kernel<Env, V, AR, EX, NTM>), grid, blk, (size_t)cfg.lds_bytes, st, a)
-#define GYMNET_LAUNCH_NT(V, AR, EX)                                   \
-    do {                                                              \
-        if (v.nt == 15) GYMNET_LAUNCH(V, AR, EX, 15);                 \
-        else if (v.nt == 12) GYMNET_LAUNCH(V, AR, EX, 12);            \
-        else GYMNET_LAUNCH(V, AR, EX, 0);                             \
-    } while (0)
-    if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2) {
-        if (v.resetf == 1) {
-#define GYMNET_LAUNCH_RF(EX)                                                                                                          \
-    do {                                                                                                                              \
-        if (v.nt == 15) hipLaunchKernelGGL((step_kernel<Env, WIDE, true, EX, 15, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);        \
-        else if (v.nt == 12) hipLaunchKernelGGL((step_kernel<Env, WIDE, true, EX, 12, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);   \
-        else hipLaunchKernelGGL((step_kernel<Env, WIDE, true, EX, 0, 1>), grid, blk, (size_t)cfg.lds_bytes, st, a);                    \
-    } while (0)
-            if (extras) GYMNET_LAUNCH_RF(true); else GYMNET_LAUNCH_RF(false);
-#undef GYMNET_LAUNCH_RF
-            return hipGetLastError();
-        }
+    if (v.vec == 1) return launch_one_shot<Env, 1>(v, autoreset, extras, cfg, a, st);
+    if constexpr (wide_alt_of<Env>() != 0) {
+        if (v.vec == wide_alt_of<Env>()) return launch_one_shot<Env, wide_alt_of<Env>()>(v, autoreset, extras, cfg, a, st);
     }
-    if (extras) {   // bookkeeping variants follow the same stream policy (their own arrays stay cacheable)
-        if (wide) { if (autoreset) GYMNET_LAUNCH_NT(WIDE, true, true); else GYMNET_LAUNCH_NT(WIDE, false, true); }
-        else      { if (autoreset) GYMNET_LAUNCH_NT(1, true, true); else GYMNET_LAUNCH_NT(1, false, true); }
-    } else if (wide) {
-        if (autoreset) GYMNET_LAUNCH_NT(WIDE, true, false); else GYMNET_LAUNCH_NT(WIDE, false, false);
-    } else {
-        if (autoreset) GYMNET_LAUNCH_NT(1, true, false); else GYMNET_LAUNCH_NT(1, false, false);
-    }
-#undef GYMNET_LAUNCH_NT
-#undef GYMNET_LAUNCH
-    return hipGetLastError();
+    return launch_one_shot<Env, wide_of<Env>()>(v, autoreset, extras, cfg, a, st);
 }
 
 template <class Env>
@@ -1018,19 +1139,23 @@ static void resolved_shape_env(bool autoreset, bool extras, LaunchCfg cfg, int64
 }
 
 template <class Env>
-static hipError_t launch_rollout_env(bool autoreset, const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &r,
+static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &r,
                                      LaunchCfg cfg, hipStream_t st) {
-    constexpr int WIDE = wide_of<Env>();
+    constexpr int WIDE = wide_of<Env>();       // (the fused rollout has no four-double form: its state already lives in registers)
     const bool wide = cfg.vec == 4 || cfg.vec == 2;
+    const bool sample = r.action_source != 0;
     const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
     const dim3 grid(grid_for(threads > 0 ? threads : 1, 256)), blk(256);
-    if (wide) {
-        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, WIDE, true>), grid, blk, 0, st, a, r);
-        else hipLaunchKernelGGL((rollout_kernel<Env, WIDE, false>), grid, blk, 0, st, a, r);
-    } else {
-        if (autoreset) hipLaunchKernelGGL((rollout_kernel<Env, 1, true>), grid, blk, 0, st, a, r);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 1, false>), grid, blk, 0, st, a, r);
-    }
+#define GYMNET_ROLL(V, AR)                                                                                              \
+    do {                                                                                                                \
+        if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true>), grid, blk, 0, st, a, r);  \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false>), grid, blk, 0, st, a, r); }      \
+        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true>), grid, blk, 0, st, a, r); \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false>), grid, blk, 0, st, a, r); }     \
+    } while (0)
+    if (wide) { if (autoreset) GYMNET_ROLL(WIDE, true); else GYMNET_ROLL(WIDE, false); }
+    else      { if (autoreset) GYMNET_ROLL(1, true); else GYMNET_ROLL(1, false); }
+#undef GYMNET_ROLL
     return hipGetLastError();
 }
 
@@ -1067,9 +1192,9 @@ static hipError_t launch_observe_env(const typename Env::Real *state, int64_t ss
     void resolved_shape_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential) {                     \
         resolved_shape_env<Env>(autoreset, extras, cfg, n, vec, sequential);                                                          \
     }                                                                                                                                 \
-    hipError_t launch_rollout_##tag(bool autoreset, const StepArgsT<Env::Real> &a, const RolloutArgsT<Env::Real> &r, LaunchCfg cfg,   \
-                                    hipStream_t st) {                                                                                 \
-        return launch_rollout_env<Env>(autoreset, a, r, cfg, st);                                                                     \
+    hipError_t launch_rollout_##tag(bool autoreset, bool extras, const StepArgsT<Env::Real> &a, const RolloutArgsT<Env::Real> &r,    \
+                                    LaunchCfg cfg, hipStream_t st) {                                                                  \
+        return launch_rollout_env<Env>(autoreset, extras, a, r, cfg, st);                                                             \
     }                                                                                                                                 \
     hipError_t launch_reset_##tag(const ResetArgsT<Env::Real> &a, hipStream_t st) { return launch_reset_env<Env>(a, st); }            \
     hipError_t launch_observe_##tag(const Env::Real *state, int64_t sstride, Env::Real *obs, int64_t ostride, int64_t n,              \

@@ -284,15 +284,30 @@ class VectorEnv:
     def RolloutDevice(self, d_actions, steps, action_stride, ring):
         capi.check(self._lib.gymnet_vecenv_rollout_device(self._h, _ptr(d_actions), int(steps), int(action_stride), int(ring)))
 
-    def RolloutFusedDevice(self, d_actions, steps, action_stride, ring, rec_obs=None, rec_reward=None, rec_done=None):
+    def RolloutFusedDevice(self, d_actions, steps, action_stride=0, ring=1, rec_obs=None, rec_reward=None, rec_done=None, actions="ring",
+                           action_seed=0, action_tick0=0, epsilon=0.0, rec_actions=None, episodes=None):
         """`steps` vector steps in ONE kernel launch (state stays in registers); optional device-side rollout
         buffers rec_obs [T][D][N] (of the handle's dtype: float64 for a float64 handle), rec_reward [T][N], rec_done [T][N]
-        (ReplayMemory.cs:25-67, batched)."""
-        rec = None
-        if rec_obs is not None or rec_reward is not None or rec_done is not None:
-            rec = capi.RolloutBuffers(_ptr(rec_obs), _ptr(rec_reward), _ptr(rec_done))
-        capi.check(self._lib.gymnet_vecenv_rollout_fused_device(self._h, _ptr(d_actions), int(steps), int(action_stride),
-                                                                int(ring), None if rec is None else C.byref(rec)))
+        (ReplayMemory.cs:25-67, batched).  gymnet_vecenv_rollout_fused_ex_device:
+          actions   "ring" (d_actions[t % ring]), "sample" (ActionSpace.Sample() drawn in the kernel: the values SampleActionsDevice
+                    (seed=action_seed, tick=action_tick0 + t) would write; d_actions may be None) or "epsilon_greedy" (ComposeActionsDevice
+                    over d_actions as the policy's actions, TrainingPlaySession.cs:46-52)
+          rec_actions  [T][N] device buffer for the actions taken
+          episodes  dict(step=, lane=, ret=, length=, capacity=, count=): device arrays for the compact records of the episodes
+                    that end during the rollout (any array may be omitted; count: uint32[2] = records written, episodes ended);
+                    needs a bookkeeping handle (BasePlaySession.cs:58-69)."""
+        src = {"ring": capi.ACTIONS_RING, "sample": capi.ACTIONS_SAMPLE, "epsilon_greedy": capi.ACTIONS_EPSILON_GREEDY}[actions]
+        ep = episodes or {}
+        unknown = set(ep) - {"step", "lane", "ret", "length", "capacity", "count"}
+        if unknown:
+            raise TypeError(f"unknown episode record field(s): {sorted(unknown)}")
+        spec = capi.RolloutSpec(struct_size=C.sizeof(capi.RolloutSpec), action_source=src, d_actions=_ptr(d_actions), steps=int(steps),
+                                action_stride=int(action_stride), ring=int(ring), action_seed=int(action_seed) & 0xFFFFFFFFFFFFFFFF,
+                                action_tick0=int(action_tick0), epsilon=float(epsilon), reserved=0,
+                                d_rec_obs=_ptr(rec_obs), d_rec_reward=_ptr(rec_reward), d_rec_done=_ptr(rec_done), d_rec_actions=_ptr(rec_actions),
+                                d_ep_step=_ptr(ep.get("step")), d_ep_lane=_ptr(ep.get("lane")), d_ep_return=_ptr(ep.get("ret")),
+                                d_ep_length=_ptr(ep.get("length")), ep_capacity=int(ep.get("capacity", 0)), d_ep_count=_ptr(ep.get("count")))
+        capi.check(self._lib.gymnet_vecenv_rollout_fused_ex_device(self._h, C.byref(spec)))
 
     def SampleActionsDevice(self, d_actions, seed=0, tick=0):
         capi.check(self._lib.gymnet_vecenv_sample_actions_device(self._h, _ptr(d_actions), int(seed), int(tick)))

@@ -280,10 +280,50 @@ typedef struct gymnet_rollout_buffers {
 /* The same `steps` vector steps as gymnet_vecenv_rollout_device — bit-identical state, reward, done — fused into ONE
  * kernel launch: every lane keeps its state in registers across the steps, so per env-step only the action is read and
  * (optionally, rec != NULL) the recorded streams are written.  For open-loop / pre-generated action sequences only: no
- * policy can look at step t's observation before step t+1.  Not available with DONE_LIST / EPISODE_STATS / FINAL_OBS /
- * per-lane seeds (GYMNET_ERR_UNSUPPORTED). */
+ * policy can look at step t's observation before step t+1.  (Since ABI 5 also on bookkeeping handles: see
+ * gymnet_vecenv_rollout_fused_ex_device below, of which this is the ring-actions, no-episode-records form.) */
 int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride,
                                        int64_t ring, const gymnet_rollout_buffers *rec);
+/* ABI 5.  The fused rollout with what its CONSUMER needs (examples/ReinforcementLearning/ReinforcementLearning/PlaySessions/
+ * BasePlaySession.cs:58-69 accumulates the episode reward and keeps the best episodes, MemoryTypes/ReplayMemory.cs:53-67 stores
+ * them; TrainingPlaySession.cs:46-52 draws an epsilon-greedy action per step) — still ONE kernel launch for `steps` vector steps:
+ *   - on a bookkeeping handle (EPISODE_STATS / DONE_LIST / FINAL_OBS / per-lane seeds; gymnet_vecenv_rollout_fused_device accepts
+ *     those too now) the running episode return / length live in registers for the whole rollout, max_episode_steps truncates,
+ *     per-lane seeds key the reset draws, the dense last-finished-episode views stay current, and the done list / records of
+ *     "the most recent step" describe the rollout's last step: the handle ends in exactly the state `steps` single steps leave;
+ *   - every episode that ends during the rollout leaves a compact record (step index t, lane, return, length) in the caller's
+ *     arrays (wave ballot + one atomic per wave inside the kernel, gathered afterwards; unordered);
+ *   - the ACTIONS can be drawn inside the kernel — GYMNET_ACTIONS_SAMPLE: ActionSpace.Sample() per lane and step, exactly the
+ *     values gymnet_vecenv_sample_actions_device(seed = action_seed, tick = action_tick0 + t) would write; GYMNET_ACTIONS_
+ *     EPSILON_GREEDY: gymnet_vecenv_compose_actions_device over the ring as the policy's actions — so a random rollout reads no
+ *     action ring at all (0 B instead of 4 B per env-step), and d_rec_actions records what was taken.
+ * Results are bit-identical to `steps` x (sample / compose, then gymnet_vecenv_step_device).  Stream-ordered, non-blocking. */
+typedef enum gymnet_action_source { GYMNET_ACTIONS_RING = 0, GYMNET_ACTIONS_SAMPLE = 1, GYMNET_ACTIONS_EPSILON_GREEDY = 2 } gymnet_action_source;
+typedef struct gymnet_rollout_spec {
+    uint32_t struct_size;        /* = sizeof(gymnet_rollout_spec) */
+    int32_t  action_source;      /* gymnet_action_source */
+    const void *d_actions;       /* RING: the actions; EPSILON_GREEDY: the policy's actions; SAMPLE: ignored (may be NULL) */
+    int64_t  steps;
+    int64_t  action_stride;      /* step t reads d_actions + (t % ring) * action_stride elements */
+    int64_t  ring;
+    uint64_t action_seed;        /* SAMPLE / EPSILON_GREEDY: Philox action stream key ... */
+    uint64_t action_tick0;       /* ... and tick of step 0 (step t draws with tick action_tick0 + t) */
+    float    epsilon;            /* EPSILON_GREEDY: exploration probability, [0, 1] */
+    int32_t  reserved;
+    /* dense per-step recording (the members of gymnet_rollout_buffers); any pointer NULL = not recorded */
+    void    *d_rec_obs;          /* [steps][obs_dim][num_envs] observation AFTER step t; float32 — float64 for a GYMNET_FLAG_F64 handle */
+    float   *d_rec_reward;       /* [steps][num_envs] */
+    uint8_t *d_rec_done;         /* [steps][num_envs] */
+    void    *d_rec_actions;      /* [steps][num_envs] the actions TAKEN (int32 / float32), or NULL */
+    /* compact records of the episodes that ended during the rollout (bookkeeping handles); all NULL = none wanted */
+    int32_t *d_ep_step;          /* [ep_capacity] step index t inside this rollout */
+    int32_t *d_ep_lane;          /* [ep_capacity] lane */
+    float   *d_ep_return;        /* [ep_capacity] episode return  (EPISODE_STATS) */
+    int32_t *d_ep_length;        /* [ep_capacity] episode length  (EPISODE_STATS) */
+    int64_t  ep_capacity;        /* records the arrays hold; a random-action CartPole rollout ends ~0.045 x num_envs episodes per step */
+    uint32_t *d_ep_count;        /* [2]: [0] records written, [1] episodes that ended (> [0]: capacity exceeded, records dropped) */
+} gymnet_rollout_spec;
+int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout_spec *spec);
 /* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout; float32, or float64 for a
  * GYMNET_FLAG_F64 handle). */
 int gymnet_vecenv_pack_obs_device(gymnet_vecenv *h, void *d_obs_rowmajor);

@@ -515,9 +515,13 @@ def test_fused_rollout_equals_stepwise_and_records(gpu_pkg, name, auto, n):
         # a following ordinary step continues from the same tick on both
         f.Step(a_host[0, :n]); e.Step(a_host[0, :n])
         assert np.array_equal(f.GetState(), e.GetState(), equal_nan=True)
-    with gpu_pkg.VectorEnv(name, 64, seed=SEED, auto_reset=True, done_list=True) as x:
-        with pytest.raises(NotImplementedError):
-            x.RolloutFusedDevice(acts, 2, stride, ring)
+    # bookkeeping handles are fused too since ABI 5 (tests/test_gpu_fused_rollout_ex.py); here: the done list of the LAST step
+    with gpu_pkg.VectorEnv(name, 64, seed=SEED, auto_reset=True, done_list=True) as x, gpu_pkg.VectorEnv(name, 64, seed=SEED, auto_reset=True, done_list=True) as y:
+        x.ResetDevice(); y.ResetDevice()
+        x.RolloutFusedDevice(acts, 9, stride, ring)
+        for t in range(9):
+            y.StepDevice(acts[t % ring])
+        assert np.array_equal(np.sort(x.DoneLanes()), np.sort(y.DoneLanes())) and np.array_equal(x.GetState(), y.GetState(), equal_nan=True)
 
 
 def test_maximum_size_batch_properties(gpu_pkg, oracle):
@@ -765,10 +769,9 @@ def test_an_all_equal_seed_vector_is_seed_int_and_keeps_the_lean_kernel(gpu_pkg)
         d = torch.from_numpy(acts[:4]).cuda().contiguous()
         b.RolloutFusedDevice(d, 8, n, 4); a.RolloutFusedDevice(d, 8, n, 4)    # GYMNET_ERR_UNSUPPORTED in round 2
         assert np.array_equal(a.GetState(), b.GetState())
-        b.Seed(np.arange(n))                                # per-lane keys: the keyed (EXTRAS) variant, fused rollout refused
+        b.Seed(np.arange(n))                                # per-lane keys: the keyed (EXTRAS) variant — fused as well since ABI 5
         assert b.KernelName().split(",")[3] == "true"      # step_kernel<Env, VEC, AUTORESET, EXTRAS, ...>
-        with pytest.raises(NotImplementedError):
-            b.RolloutFusedDevice(d, 8, n, 4)
+        b.RolloutFusedDevice(d, 8, n, 4)
         b.Seed(np.full(n, 7))                               # and back
         assert b.KernelName() == lean
 

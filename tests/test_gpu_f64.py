@@ -363,6 +363,4 @@ def test_f64_fused_rollout_is_bit_identical_to_stepwise_and_records(gpu_pkg, ora
         for t in range(3):
             e.Step(a_host[t % ring])
         assert np.array_equal(f.GetState(), e.GetState())
-    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True) as x:
-        with pytest.raises(NotImplementedError):
-            x.RolloutFusedDevice(acts, 4, stride, ring)                  # bookkeeping variants are not fused (as in float32)
+    # (bookkeeping handles are fused too since ABI 5, in both state scalars: tests/test_gpu_fused_rollout_ex.py)

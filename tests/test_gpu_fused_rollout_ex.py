@@ -1,0 +1,182 @@
+"""GPU tests of the fused rollout that carries its consumer's bookkeeping (gymnet_vecenv_rollout_fused_ex_device):
+`steps` vector steps in ONE kernel launch on a BOOKKEEPING handle — episode return / length in registers, max_episode_steps
+truncation, per-lane seeds, dense last-finished-episode views, compact (t, lane, return, length) records of every episode that
+ends (examples/.../PlaySessions/BasePlaySession.cs:58-69, MemoryTypes/ReplayMemory.cs:53-67) — with the actions read from a ring,
+DRAWN IN THE KERNEL (ActionSpace.Sample()) or composed epsilon-greedy over the ring (TrainingPlaySession.cs:46-52).
+
+Bars: bit-identical to `steps` x (SampleActionsDevice / ComposeActionsDevice -> StepDevice) on a twin handle — state, running and
+finished episode statistics, terminal observations, the done list of the last step, the recorded streams, the actions taken, the
+set of episode records — for float32 CartPole, the float64 mode, Acrobot (derived observation) and Pendulum (Box actions); and at
+BASELINE's 2^20 lanes against the oracle's replay."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED, ASEED = 0x5EED, 0xAC710
+
+
+def _episode_buffers(torch, cap):
+    return dict(step=torch.full((cap,), -1, dtype=torch.int32, device="cuda"), lane=torch.full((cap,), -1, dtype=torch.int32, device="cuda"),
+                ret=torch.zeros(cap, dtype=torch.float32, device="cuda"), length=torch.zeros(cap, dtype=torch.int32, device="cuda"),
+                capacity=cap, count=torch.zeros(2, dtype=torch.uint32, device="cuda"))
+
+
+def _records(ep):
+    c = ep["count"].cpu().numpy().astype(np.int64)
+    k = int(c[0])
+    rec = np.stack([ep["step"].cpu().numpy()[:k], ep["lane"].cpu().numpy()[:k], ep["length"].cpu().numpy()[:k]], axis=1)
+    ret = ep["ret"].cpu().numpy()[:k]
+    order = np.lexsort((rec[:, 1], rec[:, 0]))
+    return rec[order], ret[order], c
+
+
+@pytest.mark.parametrize("name,dtype", [("CartPole-v1", np.float32), ("CartPole-v1", np.float64), ("Acrobot-v1", np.float32), ("Pendulum-v1", np.float32)])
+@pytest.mark.parametrize("actions", ["ring", "sample", "epsilon_greedy"])
+@pytest.mark.parametrize("n", [4096 + 6, 1021])
+def test_fused_rollout_with_bookkeeping_equals_stepwise(gpu_pkg, name, dtype, actions, n):
+    import torch
+    if name == "Pendulum-v1" and actions == "epsilon_greedy":
+        pytest.skip("epsilon-greedy composition is defined for Discrete action spaces")
+    T, ring, limit, tick0, eps = 37, 6, 17, 1000, 0.3
+    box = name == "Pendulum-v1"
+    adt = torch.float32 if box else torch.int32
+    stride = n + (-n % 4)
+    kw = dict(seed=SEED, auto_reset=True, dtype=dtype, lane_offset=12_345, done_list=True, episode_stats=True, final_obs=True,
+              max_episode_steps=limit)
+    with gpu_pkg.VectorEnv(name, n, **kw) as f, gpu_pkg.VectorEnv(name, n, **kw) as e:
+        policy = torch.empty((ring, stride), dtype=adt, device="cuda")           # the ring: actions, or the policy's actions
+        torch.cuda.synchronize()
+        for t in range(ring):
+            e.SampleActionsDevice(policy[t], seed=77, tick=t)
+        e.Sync()
+        seeds = (np.arange(n, dtype=np.int64) * 11 + 5)
+        for env in (f, e):
+            env.Seed(seeds)                                                        # per-lane Philox keys (VecEnv.Seed(int[]))
+            env.ResetDevice()
+        D = f.ObsDim
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        rec_o = torch.zeros((T, D, n), dtype=tdt, device="cuda")
+        rec_r = torch.zeros((T, n), dtype=torch.float32, device="cuda")
+        rec_d = torch.zeros((T, n), dtype=torch.uint8, device="cuda")
+        rec_a = torch.zeros((T, n), dtype=adt, device="cuda")
+        ep = _episode_buffers(torch, n * T)
+        torch.cuda.synchronize()
+        f.RolloutFusedDevice(policy, T, stride, ring, rec_obs=rec_o, rec_reward=rec_r, rec_done=rec_d, rec_actions=rec_a, actions=actions,
+                             action_seed=ASEED, action_tick0=tick0, epsilon=eps, episodes=ep)
+        f.Sync()
+        # the twin, one launch per step: draw / compose the action, step, read this step's records
+        act = torch.empty(stride, dtype=adt, device="cuda")
+        want_rec, want_ret = [], []
+        for t in range(T):
+            if actions == "ring":
+                act.copy_(policy[t % ring])
+            elif actions == "sample":
+                e.SampleActionsDevice(act, seed=ASEED, tick=tick0 + t)
+            else:
+                e.ComposeActionsDevice(policy[t % ring], eps, act, seed=ASEED, tick=tick0 + t)
+            e.StepDevice(act)
+            e.Sync()
+            o = e.Read()
+            assert np.array_equal(rec_a[t].cpu().numpy(), act[:n].cpu().numpy()), t
+            assert np.array_equal(rec_o[t].cpu().numpy(), o.Observation.T), t
+            assert np.array_equal(rec_r[t].cpu().numpy(), o.Reward) and np.array_equal(rec_d[t].cpu().numpy() != 0, o.Done), t
+            assert np.array_equal((rec_d[t].cpu().numpy() & 2) != 0, o.Truncated), t
+            r = e.DoneRecords()
+            for lane, ret, ln in zip(r["lanes"], r["return"], r["length"]):
+                want_rec.append((t, int(lane), int(ln))); want_ret.append(float(ret))
+        got_rec, got_ret, counts = _records(ep)
+        want_rec = np.array(want_rec, dtype=np.int64).reshape(-1, 3)
+        order = np.lexsort((want_rec[:, 1], want_rec[:, 0]))
+        assert counts[0] == counts[1] == len(want_rec) > 0
+        assert np.array_equal(got_rec, want_rec[order]) and np.array_equal(got_ret, np.array(want_ret, np.float32)[order])
+        # the handle is in exactly the state T single steps leave
+        assert np.array_equal(f.GetState(), e.GetState()) and f.Tick == e.Tick
+        for arr in ("reward", "done", "episode_return", "episode_length", "finished_return", "finished_length", "final_obs"):
+            assert np.array_equal(f.GetArray(arr), e.GetArray(arr)), arr
+        a, b = f.DoneRecords(), e.DoneRecords()                                     # "the most recent step" = the rollout's last step
+        oa, ob = np.argsort(a["lanes"]), np.argsort(b["lanes"])
+        for k in ("lanes", "return", "length", "final_obs"):
+            assert np.array_equal(a[k][oa], b[k][ob]), k
+        assert f.Counters()["last_done_count"] == e.Counters()["last_done_count"]
+        # and continues identically: stepwise after fused, fused (no records) after stepwise
+        f.StepDevice(policy[0]); e.StepDevice(policy[0])
+        e.RolloutFusedDevice(policy, 5, stride, ring)
+        for t in range(5):
+            f.StepDevice(policy[t % ring])
+        f.Sync(); e.Sync()
+        assert np.array_equal(f.GetState(), e.GetState()) and np.array_equal(f.GetArray("episode_length"), e.GetArray("episode_length"))
+        assert np.array_equal(np.sort(f.DoneLanes()), np.sort(e.DoneLanes()))
+
+
+def test_fused_rollout_ex_argument_errors_and_capacity(gpu_pkg):
+    import torch
+    n, T = 2048, 20
+    acts = torch.randint(0, 2, (4, n), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True) as lean:
+        lean.ResetDevice()
+        ep = _episode_buffers(torch, 64)
+        with pytest.raises(NotImplementedError, match="bookkeeping handle"):
+            lean.RolloutFusedDevice(acts, T, n, 4, episodes=ep)
+        with pytest.raises(ValueError):
+            lean.RolloutFusedDevice(None, T, n, 4)                                  # ring source without a ring
+        with pytest.raises(ValueError):
+            lean.RolloutFusedDevice(acts, T, n, 4, actions="epsilon_greedy", epsilon=1.5)
+        lean.RolloutFusedDevice(None, T, actions="sample", action_seed=3)            # a lean handle may sample: no ring at all
+        lean.Sync()
+        assert lean.Tick == T + 1
+    with gpu_pkg.VectorEnv("Pendulum-v1", n, seed=SEED, auto_reset=True) as p:
+        with pytest.raises(NotImplementedError, match="Discrete"):
+            p.RolloutFusedDevice(acts, T, n, 4, actions="epsilon_greedy", epsilon=0.1)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, done_list=True) as d:
+        ep = _episode_buffers(torch, 64)
+        with pytest.raises(NotImplementedError, match="EPISODE_STATS"):
+            d.RolloutFusedDevice(acts, T, n, 4, episodes=ep)                        # return / length records need the statistics
+        d.ResetDevice()
+        d.RolloutFusedDevice(acts, T, n, 4, episodes={k: ep[k] for k in ("step", "lane", "capacity", "count")})
+        d.Sync()
+        c = ep["count"].cpu().numpy()
+        assert c[0] == 64 and c[1] > 64                                            # more episodes ended than the arrays hold: counted, not kept
+        lanes = ep["lane"].cpu().numpy()
+        assert ((0 <= lanes) & (lanes < n)).all()
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, validate_actions=True, episode_stats=True) as v:
+        with pytest.raises(NotImplementedError, match="VALIDATE_ACTIONS"):
+            v.RolloutFusedDevice(acts, T, n, 4)
+        v.ResetDevice()
+        v.RolloutFusedDevice(None, T, actions="sample")                             # sampled actions are valid by construction
+        v.Sync()
+
+
+def test_sampled_action_rollout_at_2p20_lanes_equals_the_oracle_replay(gpu_pkg, oracle):
+    """BASELINE's batch: 2^20 CartPole lanes, 12 steps in one launch with the actions drawn in the kernel, the episode statistics
+    and a 9-step time limit, replayed on the CPU: oracle Discrete.Sample() words -> oracle step -> the bookkeeping in NumPy."""
+    import torch
+    n, T, limit, tick0 = 1 << 20, 12, 9, 5
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True, max_episode_steps=limit) as env:
+        env.ResetDevice()
+        ep = _episode_buffers(torch, n * 3)
+        rec_a = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        env.RolloutFusedDevice(None, T, actions="sample", action_seed=ASEED, action_tick0=tick0, rec_actions=rec_a, episodes=ep)
+        env.Sync()
+        s = oracle.env_reset("CartPole-v1", SEED, 0, 0, n)
+        ln, ret = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        want = []
+        got_a = rec_a.cpu().numpy()
+        for t in range(T):
+            a = oracle.discrete_sample(ASEED, 0, tick0 + t, 2, 0, n)
+            assert np.array_equal(got_a[t], a), t
+            stepped, _, r, d = oracle.env_step("CartPole-v1", s, a, dtype=np.float32)
+            ln += 1; ret += r
+            fin = d.astype(bool) | (ln >= limit)
+            fresh = oracle.env_reset("CartPole-v1", SEED, 0, 1 + t, n)
+            s = np.where(fin, fresh, stepped)
+            lanes = np.nonzero(fin)[0]
+            want.append(np.stack([np.full(len(lanes), t), lanes, ln[fin]], axis=1))
+            ln[fin] = 0; ret[fin] = 0.0
+        assert np.array_equal(env.GetState(), s)
+        assert np.array_equal(env.GetArray("episode_length"), ln) and np.array_equal(env.GetArray("episode_return"), ret)
+        got_rec, got_ret, counts = _records(ep)
+        want = np.concatenate(want)
+        assert counts[0] == counts[1] == len(want) and np.array_equal(got_rec, want)
+        assert np.array_equal(got_ret, want[:, 2].astype(np.float32))              # CartPole: reward 1 per step, return == length

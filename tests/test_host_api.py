@@ -37,7 +37,7 @@ def abi_manifest():
 
 CTYPES_OF = {"gymnet_config": "Config", "gymnet_env_info": "EnvInfo", "gymnet_device_view": "DeviceView",
              "gymnet_counters": "Counters", "gymnet_rollout_buffers": "RolloutBuffers", "gymnet_group_config": "GroupConfig",
-             "gymnet_ipc_handle": "IpcHandle", "gymnet_launch_policy": "LaunchPolicy"}
+             "gymnet_ipc_handle": "IpcHandle", "gymnet_launch_policy": "LaunchPolicy", "gymnet_rollout_spec": "RolloutSpec"}
 
 
 def test_struct_layouts_match_the_header(gymnet):
@@ -228,7 +228,7 @@ CS_SIZES = {"uint": 4, "int": 4, "long": 8, "ulong": 8, "float": 4, "IntPtr": 8,
 CS_STRUCT_OF = {"gymnet_config": "GymnetConfig", "gymnet_env_info": "GymnetEnvInfo", "gymnet_device_view": "GymnetDeviceView",
                 "gymnet_counters": "GymnetCounters", "gymnet_rollout_buffers": "GymnetRolloutBuffers",
                 "gymnet_group_config": "GymnetGroupConfig", "gymnet_ipc_handle": "GymnetIpcHandle",
-                "gymnet_launch_policy": "GymnetLaunchPolicy"}
+                "gymnet_launch_policy": "GymnetLaunchPolicy", "gymnet_rollout_spec": "GymnetRolloutSpec"}
 
 
 def _csharp_sources():

@@ -54,8 +54,9 @@ def q(db, sql, *a):
 
 def spacing(db, min_len):
     """Begin-to-begin spacing of consecutive step-kernel launches inside regions of back-to-back launches (a gap of more than
-    30 us to the previous kernel's end starts a new region; regions shorter than min_len launches are ignored; the first 8
-    launches of a region — the ramp — are left out).  Returns (median spacing us, median duration us, regions, launches)."""
+    200 us to the previous kernel's end starts a new region — the bench's bracketed regions are separated by a synchronize and
+    host work; single hiccups inside a region stay in: the MEDIAN is reported; regions shorter than min_len launches are ignored;
+    the first 8 launches of a region — the ramp — are left out).  Returns (median spacing us, median duration us, regions, launches)."""
     import statistics as st
     if not os.path.exists(db):
         return None
@@ -66,7 +67,7 @@ def spacing(db, min_len):
         c.close()
     regions, cur = [], []
     for s_, e_ in rows:
-        if cur and s_ - cur[-1][1] > 30_000:
+        if cur and s_ - cur[-1][1] > 200_000:
             regions.append(cur); cur = []
         cur.append((s_, e_))
     if cur:
@@ -103,7 +104,8 @@ for cfg, (args, moved, algo, lanes) in CONFIGS.items():
         avg_ns = q(db, "select avg(duration) from kernels where name like '%step_kernel%'")
         row["kernel"] = q(db, "select name from kernels where name like '%step_kernel%' limit 1")
         j = bench_line(os.path.join(d, "stats.log"))
-        for key, path, min_len in (("stats", db, 2000), ("burst", os.path.join(d, "burst", "b_results.db"), 1000)):
+        for key, path, min_len in (("stats", db, 1024), ("burst", os.path.join(d, "burst", "b_results.db"), 512),
+                                   ("graph", os.path.join(d, "gburst", "g_results.db"), 512)):
             sp = spacing(path, min_len)
             if sp:
                 row[f"{key}_spacing_us"], row[f"{key}_median_duration_us"] = sp[0], sp[1]
@@ -157,7 +159,7 @@ json.dump({"tag": tag, "peak_GBps": PEAK, "lanes": N, "rows": table, "bytes_move
            "bytes_algorithmic": {k: v[2] for k, v in CONFIGS.items()}}, open(os.path.join(P, "roofline_box.json"), "w"), indent=1)
 hdr = (f"# Round 5 box {tag} at 2^20 lanes (fractions of 8 TB/s on the bytes each kernel MOVES)\n"
        f"# {'configuration':18s} {'rocprof us':>10s} {'frac':>6s} {'events us':>10s} {'frac':>6s} {'wall frac':>9s} {'VALU/step':>9s} {'HBM-side B':>12s}\n")
-hdr += "# begin-to-begin spacing (us): " + "  ".join(f"{r['cfg']} {r.get('stats_spacing_us', float('nan')):.3f}/{r.get('burst_spacing_us', float('nan')):.3f}" for r in table) + "  (4096-launch / 1024-launch regions)\n"
+hdr += "# begin-to-begin spacing (us): " + "  ".join(f"{r['cfg']} {r.get('stats_spacing_us', float('nan')):.3f}/{r.get('burst_spacing_us', float('nan')):.3f}/{r.get('graph_spacing_us', float('nan')):.3f}" for r in table) + "  (eager 4096-launch regions / eager 1024 / hipGraph replay 1024)\n"
 for r in table:
     f = lambda k, w, p: (f"{r[k]:{w}.{p}f}" if r.get(k) is not None else " " * (w - 1) + "-")  # noqa: E731
     hdr += f"# {r['cfg']:18s} {f('rocprof_us', 10, 3)} {f('frac_rocprof', 6, 3)} {f('events_us', 10, 3)} {f('frac_events', 6, 3)} {f('frac_wall', 9, 3)} {f('valu_per_step', 9, 1)} {f('traffic', 12, 0)}\n"

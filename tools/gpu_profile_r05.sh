@@ -4,6 +4,9 @@
 #   * rocprofv3 --kernel-trace --stats of the bench command: the step kernel's AVERAGE DURATION, and from the same timestamped trace
 #     the BEGIN-TO-BEGIN SPACING of consecutive launches inside the 4096-launch regions (what the unprofiled wall clock sees);
 #   * a separate burst trace with 1024-launch regions (tools/burst_trace_r04.py shape), same two figures;
+#   * the same burst with the launches replayed from a captured hipGraph (--policy graph=1): under rocprofv3 every EAGER launch costs
+#     the host 8-9 us, more than the short kernels run, so the eager traces show a starved stream; a graph replay is one host call
+#     per 1024 launches and the trace shows the GPU's own begin-to-begin spacing;
 #   * separate --pmc passes: FETCH_SIZE, WRITE_SIZE (HBM-side traffic; never share a pass) and the SQ counters (VALU per env-step);
 #   * the unprofiled bench line.
 # --pmc passes carry no trace flags (gpurun refuses the mix); the program after `--` is python3 itself.
@@ -24,6 +27,7 @@ for E in $CFGS; do
   timeout 300 python3 $R/bench.py --no-cpu-baseline --no-extras --no-traffic $A > $O/$E/unprofiled.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/$E/stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-traffic $A > $O/$E/stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace -d $O/$E/burst -o b -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-traffic $A --steps 1024 --warmup 64 --min-seconds 0.05 > $O/$E/burst.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace -d $O/$E/gburst -o g -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-traffic $A --policy graph=1 --ring 256 --steps 1024 --warmup 256 --min-seconds 0.05 > $O/$E/gburst.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $C -d $O/$E/$C -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-traffic $A --no-graph --steps 100 --warmup 10 --min-seconds 0 > $O/$E/$C.log 2>&1
   done
@@ -32,6 +36,6 @@ done
 cd $R
 rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -12 > $O/rocminfo.log 2>&1
 GYMNET_PROFILE_DIR=p5/$TAG GYMNET_PROFILES_OUT=$O/summary python3 tools/collect_profiles_r05.py $TAG > $O/collect.log 2>&1
-for E in $CFGS; do rm -rf $O/$E/stats $O/$E/burst $O/$E/FETCH_SIZE $O/$E/WRITE_SIZE $O/$E/SQ; done
+for E in $CFGS; do rm -rf $O/$E/stats $O/$E/burst $O/$E/gburst $O/$E/FETCH_SIZE $O/$E/WRITE_SIZE $O/$E/SQ; done
 du -sh $O >> $O/collect.log
 tail -12 $O/collect.log
