@@ -69,7 +69,7 @@ def test_fused_rollout_with_bookkeeping_equals_stepwise(gpu_pkg, name, dtype, ac
         want_rec, want_ret = [], []
         for t in range(T):
             if actions == "ring":
-                act.copy_(policy[t % ring])
+                act.copy_(policy[t % ring]); torch.cuda.synchronize()     # torch's stream is not the handle's: order the copy before the step
             elif actions == "sample":
                 e.SampleActionsDevice(act, seed=ASEED, tick=tick0 + t)
             else:
