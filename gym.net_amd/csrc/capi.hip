@@ -169,8 +169,7 @@ int apply_policy(gymnet_vecenv *h, const gymnet_launch_policy &p, bool strict) {
         return strict ? fail(h, GYMNET_ERR_INVALID_ARG, "launch policy: %s = %d is not available for this handle", what, v) : GYMNET_OK;
     };
     if (p.vec != -1) {
-        // 4: dwordx4 float rows — or, on a float64 handle, four doubles per thread (two dwordx4 per row); 2: Acrobot's packed form / two doubles
-        const bool ok = p.vec == 1 || (p.vec == 4 && h->can_vec4 && !acrobot) || (p.vec == 2 && h->can_vec2 && wide2);
+        const bool ok = p.vec == 1 || (p.vec == 4 && h->can_vec4 && !wide2) || (p.vec == 2 && h->can_vec2 && wide2);
         if (ok) c.vec = p.vec; else ST_TRY(bad("vec", p.vec));
     }
     if (p.block != -1) { if (p.block == 64 || p.block == 128 || p.block == 256) c.block = p.block; else ST_TRY(bad("block", p.block)); }
@@ -218,17 +217,19 @@ void default_policy(gymnet_vecenv *h) {
         // float32 path below
         const size_t step_bytes = (size_t)h->n * bytes_per_step(h);
         const bool can2 = aligned16(h->d_state) && (h->sstride % 2 == 0) && (!h->d_state_alt || aligned16(h->d_state_alt));
-        h->can_vec4 = can2; h->can_vec2 = can2; h->lds_ok = false;     // (vec = 4: four doubles per thread, the same 16-byte pieces)
+        h->can_vec4 = false; h->can_vec2 = can2; h->lds_ok = false;
         // measured at 2^20 lanes (73 MiB per step; us per step, gpurun_out r4): every stream non-temporal 14.3, state cacheable 14.8,
         // nothing non-temporal 16.2, one lane per thread 15.6
         h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, 0, 0};
         if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
-        // The multi-item kernel (step_kernel_pipe2<CartPole64, 2>: a thread owns 2 lane pairs, all loads first, then advance / store
+        // The multi-item kernel (step_kernel_pipe2<CartPole64, k>: a thread owns k lane pairs, all loads first, then advance / store
         // pair after pair) wins exactly where the one-shot kernel is ONE full lock-step generation of waves — 2^20 lanes = 2^19
-        // threads = 8 waves on every SIMD: 14.4 -> 13.1-13.2 us (0.67 -> 0.73 of 8 TB/s on its 73 B; profiles/f64_forms_r04.txt).  Below
-        // (2^19: 8.9 vs 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the generations
-        // overlap by themselves.  Lean variant and whole 1024-lane groups only (the launcher falls back otherwise).
-        if (can2 && h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = 2;
+        // threads = 8 waves on every SIMD.  Round 4 (271 VALU per env-step): one-shot 14.4, 2 pairs 13.1-13.2, 4 pairs 14.4 us.  Round 5
+        // (178 VALU per env-step after the drain-loop reset of the common skeleton and the fma-pair constant division): one-shot
+        // 13.4-13.6, 2 pairs 13.1-13.4, 4 PAIRS 12.8-13.2 us (profiles/f64_forms_r05.txt) — fatter threads win now that each pair is
+        // cheaper.  Below (2^19: 8.9 vs 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the
+        // generations overlap by themselves.  Lean variant and whole 2 * k * 256-lane groups only (the launcher falls back otherwise).
+        if (can2 && h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (h->n % 2048 == 0) ? 4 : 2;
         return;
     }
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be

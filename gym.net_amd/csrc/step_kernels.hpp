@@ -542,6 +542,10 @@ __global__ __launch_bounds__(256) void step_kernel_pipe(const StepArgsT<typename
 // lane (NOT the packed-FP32 form: PACK = false), all loads first, then advance / store pair after pair.  The shape that took the
 // float64 CartPole kernel from 14.4 to 13.1 us.  Whole batches only (n a multiple of 2 * ITEMS * 256); lean variant.  Same
 // per-lane code and Philox counters as every other form: bit-identical.  Measured: profiles/acrobot_forms_r04.txt.
+// Round 5, measured and removed again (profiles/f64_forms_r05.txt): lane QUADS per item for the float64 kernel (14.8-16.7 us against
+// 13.0), the wave-compacted reset per item (no better than the drain loop), and a reset deferred to ONE compacted pass per wave for
+// all of a thread's pairs with the drawing lanes storing the fresh states (correct, and 8 us slower: a state line written in two
+// pieces at two times costs far more than the Philox passes it saves).
 template <class Env, int ITEMS, bool AUTORESET, int NT>
 __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
     const uint64_t tick = a.tick2[a.parity];
@@ -1000,10 +1004,6 @@ static LaunchCfg normalized(LaunchCfg cfg) {
 // two-lane packed-FP32 form (Acrobot), two lanes per thread on dwordx2 streams
 template <class Env>
 constexpr int wide_of() { return (sizeof(typename Env::Real) == 8 || Env::PACKED2) ? 2 : 4; }
-// a second wide form: FOUR float64 lanes per thread (two dwordx4 per state row and direction, 32 contiguous bytes per thread:
-// the float32 flagship's shape — dwordx4 actions / rewards, one 32-bit done store) — launch policy vec = 4 on a float64 handle
-template <class Env>
-constexpr int wide_alt_of() { return sizeof(typename Env::Real) == 8 ? 4 : 0; }
 
 template <class Env>
 static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg &cfg, int64_t n) {
@@ -1023,9 +1023,9 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
             return v;
         }
     }
-    if (cfg.vec > 1) v.vec = (wide_alt_of<Env>() != 0 && cfg.vec == wide_alt_of<Env>()) ? wide_alt_of<Env>() : wide_of<Env>();
-    // wave-compacted fused reset: wide variants of an env whose observation IS its state
-    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec > 1 && autoreset) v.resetf = 1;
+    if (cfg.vec > 1) v.vec = wide_of<Env>();
+    // wave-compacted fused reset: wide variant of an env whose observation IS its state
+    if (Env::OBS_ALIASES_STATE && !Env::PACKED2 && cfg.reset_form == 1 && v.vec == wide_of<Env>() && autoreset) v.resetf = 1;
     return v;
 }
 
@@ -1064,7 +1064,8 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
     const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg, a.n);
     if constexpr (Env::PIPE_PAIRS) {
         if (v.pipe_pairs) {
-            const dim3 qgrid((unsigned)(a.n / (2 * (int64_t)v.pipe_items * 256))), qblk(256);
+            // whole groups of 2 * items * 256 lanes (resolve_variant), so any of the workgroup sizes divides the batch
+            const dim3 qgrid((unsigned)(a.n / (2 * (int64_t)v.pipe_items * cfg.block))), qblk(cfg.block);
 #define GYMNET_PIPE2(I)                                                                                                 \
     case I:                                                                                                             \
         if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a);                 \
@@ -1111,9 +1112,6 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
         }
     }
     if (v.vec == 1) return launch_one_shot<Env, 1>(v, autoreset, extras, cfg, a, st);
-    if constexpr (wide_alt_of<Env>() != 0) {
-        if (v.vec == wide_alt_of<Env>()) return launch_one_shot<Env, wide_alt_of<Env>()>(v, autoreset, extras, cfg, a, st);
-    }
     return launch_one_shot<Env, wide_of<Env>()>(v, autoreset, extras, cfg, a, st);
 }
 
@@ -1141,7 +1139,7 @@ static void resolved_shape_env(bool autoreset, bool extras, LaunchCfg cfg, int64
 template <class Env>
 static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &r,
                                      LaunchCfg cfg, hipStream_t st) {
-    constexpr int WIDE = wide_of<Env>();       // (the fused rollout has no four-double form: its state already lives in registers)
+    constexpr int WIDE = wide_of<Env>();
     const bool wide = cfg.vec == 4 || cfg.vec == 2;
     const bool sample = r.action_source != 0;
     const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);

@@ -205,7 +205,7 @@ def test_f64_at_2p20_lanes_matches_the_twin_and_the_float32_engine_statistically
     import torch
     n, steps, ring = 1 << 20, 24, 8
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64) as env:
-        assert env.KernelName() == "step_kernel_pipe2<CartPole64,2,true,15>"   # the default at this size (one lock-step generation otherwise)
+        assert env.KernelName() == "step_kernel_pipe2<CartPole64,4,true,15>"   # the default at this size (one lock-step generation otherwise)
         acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for t in range(ring):

@@ -210,7 +210,7 @@ def test_f64_config5_shape_eight_members_of_2p20_lanes_overlapped_gather(gpu_pkg
         pytest.skip("needs ~6 GiB of device memory")
     with gpu_pkg.GroupVectorEnv("CartPole-v1", n, G, devices=[0] * G, seed=SEED, auto_reset=True, gather="direct", overlap=True,
                                 dtype=np.float64) as grp:
-        assert grp.Members[0].KernelName() == "step_kernel_pipe2<CartPole64,2,true,15>"
+        assert grp.Members[0].KernelName() == "step_kernel_pipe2<CartPole64,4,true,15>"
         acts = torch.empty((ring, n), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for t in range(ring):
@@ -286,3 +286,33 @@ def test_f64_sharded_vector_env_on_the_hip_engine(gpu_pkg):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SHARDED_F64_CHILD % port], cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "SHARDED_F64_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_f64_pair_kernel_workgroup_sizes_and_reset_forms_are_bit_identical(gpu_pkg, oracle):
+    """The float64 multi-item kernel (k lane pairs per thread) at every workgroup size, and the one-shot kernel with the
+    wave-compacted fused reset, against the float64 twin at a lane offset above 2^32.  (Lane quads, a per-item compacted reset and a
+    deferred single reset pass were measured in round 5 and removed: profiles/f64_forms_r05.txt.)"""
+    import torch
+    n, ring, steps, off = 2 * 256 * 8 * 3, 6, 40, (1 << 33) + 12_288
+    acts = torch.randint(0, 2, (ring, n), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    a_host = acts.cpu().numpy()
+    s = oracle.cartpole_reset_f64(SEED, off, 0, n)
+    for t in range(steps):
+        s, r, d = oracle.cartpole_autoreset_step_f64(SEED, off, 1 + t, s, a_host[t % ring])
+    forms = [(1, 1, 256, "step_kernel<CartPole64,2,true,false,15,1>"), (1, 0, 64, "step_kernel<CartPole64,2,true,false,15,0>"),
+             (2, 0, 256, "step_kernel_pipe2<CartPole64,2,true,15>"), (3, 0, 128, "step_kernel_pipe2<CartPole64,3,true,15>"),
+             (4, 0, 64, "step_kernel_pipe2<CartPole64,4,true,15>"), (4, 1, 256, "step_kernel_pipe2<CartPole64,4,true,15>")]
+    for items, rf, block, want in forms:
+        pol = {"sequential_lanes": items, "reset_form": rf, "block": block}
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, lane_offset=off, launch_policy=pol) as env:
+            assert env.KernelName() == want, env.KernelName()
+            env.ResetDevice()
+            env.RolloutDevice(acts, steps, n, ring)
+            env.Sync()
+            out = env.Read()
+            assert np.array_equal(env.GetState(), s) and np.array_equal(out.Reward, r) and np.array_equal(out.Done, d.astype(bool)), want
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64) as env:
+        for bad in (dict(vec=4), dict(sequential_lanes=8), dict(sequential_lanes=5)):
+            with pytest.raises(ValueError):
+                env.SetLaunchPolicy(**bad)
