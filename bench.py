@@ -254,7 +254,7 @@ def allgather_model(world, bytes_per_rank):
             "note": "analytic: 16 MiB per rank at 2^20 CartPole lanes -> ~110 us direct, ~770 us ring at 8 GPUs"}
 
 
-def measure_traffic(args, timeout=90):
+def measure_traffic(args, wide16=True, timeout=90):
     """roofline.traffic measured IN THIS RUN: HBM-side bytes per launch of the step kernel from the PMC counters, collected as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (no trace
     flags beside --pmc), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both count KiB; on gfx950 FETCH_SIZE reports half the bytes
@@ -297,9 +297,16 @@ def measure_traffic(args, timeout=90):
             vals[counter] = (row[0], row[1])
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
-    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    if wide16:
+        traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+        how = "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch (the guide's gfx950 correction for 16-byte-per-lane coalesced reads)"
+    else:
+        # the guide calibrates the 2x read factor for 16 B / lane accesses only; this kernel form reads 4 (8) B per lane: raw counters
+        traffic = (vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+        how = ("UNCALIBRATED: (FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, raw counters — the kernel form in use does not make 16-byte-per-lane "
+               "reads, for which alone the guide gives the 2x FETCH_SIZE correction; the read side may be under-counted by up to 2x")
     return traffic, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes "
-                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} step-kernel dispatches), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch")
+                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} step-kernel dispatches), {how}")
 
 
 def parse_policy(text):
@@ -733,8 +740,59 @@ def main():
             f1.record(stream)
             torch.cuda.synchronize(dev)
             fused_us = f0.elapsed_time(f1) * 1e3 / fsteps
+            obs_dim = local.ObsDim
             fused = {"env_steps_per_sec_per_gpu": n / (fused_us * 1e-6), "us_per_step": fused_us, "steps_per_launch": ring,
+                     "bytes_per_env_step": 4, "bytes_note": "4 B action read per env-step (nothing recorded); state in registers",
                      "note": "T-step fused kernel, no per-step observation hand-off; not comparable to `value`"}
+
+            def fused_time(fn, reps=3):
+                fn()
+                torch.cuda.synchronize(dev)
+                ts = []
+                for _ in range(reps):
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record(stream)
+                    for _ in range(fsteps // ring):
+                        fn()
+                    g1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    ts.append(g0.elapsed_time(g1) * 1e3 / fsteps)
+                return median(ts)
+            # Round 5 (gymnet_vecenv_rollout_fused_ex_device): the actions DRAWN IN THE KERNEL — ActionSpace.Sample() per lane and
+            # step, the words gymnet_vecenv_sample_actions_device would write — so a random rollout reads no action ring at all:
+            # 0 B per env-step from memory, ~70 more VALU per lane-step for the Philox call.
+            su = fused_time(lambda: local.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, action_tick0=0))
+            fused["sampled_actions"] = {"us_per_step": su, "env_steps_per_sec_per_gpu": n / (su * 1e-6), "bytes_per_env_step": 0,
+                                        "note": "actions drawn in the kernel (Philox action stream): no action ring is read, nothing recorded"}
+            # ... and the same recording what a replay memory stores (ReplayMemory.cs:53-67): observation, action, reward, done
+            rec_o = torch.empty((ring, obs_dim, n), dtype=torch.float32, device=dev)
+            rec_r = torch.empty((ring, n), dtype=torch.float32, device=dev)
+            rec_d = torch.empty((ring, n), dtype=torch.uint8, device=dev)
+            rec_a = torch.empty((ring, n), dtype=adtype, device=dev)
+            ru = fused_time(lambda: local.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, rec_obs=rec_o.data_ptr(),
+                                                             rec_reward=rec_r.data_ptr(), rec_done=rec_d.data_ptr(), rec_actions=rec_a.data_ptr()))
+            rb = 4 * obs_dim + 4 + 4 + 1
+            fused["sampled_actions_recorded"] = {"us_per_step": ru, "env_steps_per_sec_per_gpu": n / (ru * 1e-6), "bytes_per_env_step": rb,
+                                                 "achieved_GBps": rb * n / (ru * 1e-6) / 1e9, "frac_of_peak": rb * n / (ru * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                 "note": f"{rb} B written per env-step (obs {4 * obs_dim} + action 4 + reward 4 + done 1), nothing read"}
+            del rec_o, rec_r, rec_d, rec_a
+            # ... and on a BOOKKEEPING handle: episode return / length in registers, 500-step time limit, one compact
+            # (t, lane, return, length) record per finished episode (BasePlaySession.cs:58-69)
+            if args.env == "CartPole-v1":
+                with pkg.VectorEnv(args.env, n, device=dev_index, seed=seed, auto_reset=True, episode_stats=True, max_episode_steps=500,
+                                   stream=stream.cuda_stream) as be:
+                    cap = n * ring // 8
+                    keep = {"step": torch.empty(cap, dtype=torch.int32, device=dev), "lane": torch.empty(cap, dtype=torch.int32, device=dev),
+                            "ret": torch.empty(cap, dtype=torch.float32, device=dev), "length": torch.empty(cap, dtype=torch.int32, device=dev),
+                            "capacity": cap, "count": torch.zeros(2, dtype=torch.uint32, device=dev)}
+                    ep = {k: (v.data_ptr() if hasattr(v, "data_ptr") else v) for k, v in keep.items()}
+                    be.ResetDevice()
+                    bu = fused_time(lambda: be.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, episodes=ep))
+                    cnt = keep["count"].cpu().numpy()
+                    fused["sampled_actions_with_episode_records"] = {
+                        "us_per_step": bu, "env_steps_per_sec_per_gpu": n / (bu * 1e-6), "episodes_per_launch": int(cnt[1]), "records_kept": int(cnt[0]),
+                        "note": "bookkeeping handle (EPISODE_STATS, max_episode_steps 500): episode statistics in registers + one compact "
+                                "(t, lane, return, length) record per finished episode, gathered after the launch"}
         except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
             fused = {"error": repr(e)[:300]}
 
@@ -1027,7 +1085,10 @@ def main():
                 out["group_single_process"] = run_group_child(args, world, timeout=180)
         if world == 1 and not args.no_traffic and not args.no_extras and not gather_in_region:
             try:
-                tr, how = measure_traffic(args)
+                # the guide's 2x FETCH_SIZE correction holds for 16-byte-per-lane reads: 4 float / 2 double lanes per thread
+                wide16 = launch_policy["envs_per_thread"] * (8 if f64 else 4) == 16
+                tr, how = measure_traffic(args, wide16)
+                out["roofline"]["traffic_calibrated"] = bool(wide16)
                 out["roofline"]["traffic_constant_from_profiles"] = out["roofline"]["traffic"]
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, how
                 out["roofline"]["traffic_over_moved_bytes"] = tr / out["roofline"]["bytes_per_launch"]
