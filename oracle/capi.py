@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "build", "liboracle.so")
+# GYMNET_ORACLE_SO: load another build of the same restatement (the sanitizer builds of oracle/Makefile; tests/test_sanitizers.py)
+_SO = os.environ.get("GYMNET_ORACLE_SO") or os.path.join(_HERE, "build", "liboracle.so")
 _lib = None
 
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -23,6 +24,8 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile the C restatement with oracle/Makefile (gcc).  Building the checker is not using it."""
     srcs = [os.path.join(_HERE, f) for f in ("classic_control_ref.c", "cpu_baseline.c", "Makefile")]
+    if os.environ.get("GYMNET_ORACLE_SO"):
+        return _SO                       # a sanitizer build made by `make -C oracle asan|ubsan|tsan`
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)

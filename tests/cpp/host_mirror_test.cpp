@@ -280,9 +280,68 @@ static void gpu_tests() {
     }
 }
 
+// `--stub`: the host classes against tests/cpp/abi_stub.c (a test-only, memory-honest stand-in of the C ABI: it fills / reads exactly the
+// bytes the header documents and computes nothing), built with -fsanitize=address,undefined by tests/test_sanitizers.py.  What is
+// under test is the HOST side: every buffer the classes allocate and hand across the ABI, handle lifetime, error mapping.
+static void stub_tests() {
+    for (gymnet_env_id env : {GYMNET_ENV_CARTPOLE, GYMNET_ENV_PENDULUM, GYMNET_ENV_MOUNTAINCAR, GYMNET_ENV_ACROBOT}) {
+        for (int64_t n : {1, 7, 4097}) {
+            gymnet::VectorEnv e(env, n, 0, 3, GYMNET_FLAG_AUTORESET | GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS | GYMNET_FLAG_FINAL_OBS);
+            auto obs = e.Reset();
+            CHECK((int64_t)obs.size() == n * e.ObsDim(), "Reset() -> N * obs_dim floats");
+            gymnet::BatchStep b = env == GYMNET_ENV_PENDULUM ? e.Step(std::vector<float>((size_t)n, 0.5f)) : e.Step(std::vector<int32_t>((size_t)n, 1));
+            CHECK(b.size() == n && (int64_t)b.Observation.size() == n * e.ObsDim() && b[n - 1].Observation.size() == (size_t)e.ObsDim(), "BatchStep shapes");
+            b = e.Step(0);
+            CHECK((int64_t)b.Reward.size() == n, "broadcast step");
+            std::vector<uint8_t> mask((size_t)n, 1);
+            CHECK((int64_t)e.ResetWhere(&mask).size() == n * e.ObsDim() && (int64_t)e.ResetWhere().size() == n * e.ObsDim(), "ResetWhere");
+            auto st = e.GetState();
+            CHECK((int64_t)st.size() == n * e.StateDim(), "GetState");
+            e.SetState(st);
+            auto rec = e.DoneRecords(true, true);
+            CHECK(rec.lanes.size() == (size_t)(n / 5) && rec.final_obs.size() == rec.lanes.size() * (size_t)e.ObsDim() && rec.episode_length.size() == rec.lanes.size(), "DoneRecords sizes");
+            auto pin = e.HostBuffers();
+            std::memset(pin.actions, 0, (size_t)n * 4);
+            e.StepInto(pin.actions, pin.obs, pin.reward, pin.done);
+            CHECK(pin.reward[n - 1] == 1.0f, "pinned buffers written to their end");
+            CHECK(e.GetArray<float>(GYMNET_ARRAY_FINAL_OBS, (size_t)n * (size_t)e.ObsDim()).size() == (size_t)n * (size_t)e.ObsDim(), "GetArray(FINAL_OBS)");
+            CHECK(throws<std::invalid_argument>([&] { e.GetArray<float>(GYMNET_ARRAY_REWARD, (size_t)n + 1); }), "wrong size -> ArgumentException");
+            CHECK(e.GetStepsBeyondDone().size() == (size_t)n && e.Counters().tick > 0 && e.KernelName() == "stub", "small getters");
+            if (env != GYMNET_ENV_PENDULUM) {
+                e.StepAsync(std::vector<int32_t>((size_t)n, 0));
+                CHECK(throws<gymnet::AlreadySteppingError>([&] { e.StepAsync(std::vector<int32_t>((size_t)n, 0)); }), "AlreadySteppingError");
+                CHECK(e.StepWait().size() == n, "StepWait");
+                CHECK(throws<gymnet::NotSteppingError>([&] { e.StepWait(); }), "NotSteppingError");
+            }
+            CHECK(throws<std::invalid_argument>([&] { e.Seed(std::vector<int>((size_t)n + 2, 1)); }), "seed count mismatch -> ArgumentException");
+            CHECK(throws<std::invalid_argument>([&] { e.Step(std::vector<int32_t>((size_t)n + 1, 0)); }), "action count mismatch");
+            e.Seed(std::vector<int>((size_t)n, 4));
+            e.Close();
+            e.Close();                                              // idempotent; the handle is not touched again
+        }
+    }
+    {
+        gymnet::CartPoleEnv64 e64(0, 1, GYMNET_FLAG_AUTORESET);
+        CHECK(e64.Reset().size() == 4 && e64.Step(1).Observation.size() == 4 && e64.GetState().size() == 4, "float64 single env: 4 doubles everywhere");
+        gymnet::CartPoleEnv e32(0, 1);
+        CHECK(e32.Reset().size() == 4 && e32.Step(0).Observation.size() == 4, "float32 single env");
+        CHECK(throws<std::logic_error>([] { gymnet::VectorEnv bad(GYMNET_ENV_CARTPOLE, 8, 0, 1, GYMNET_FLAG_F64); }), "float32 host class refuses a float64 handle");
+    }
+    {
+        gymnet::GroupVectorEnv g(GYMNET_ENV_ACROBOT, 4 * 513, std::vector<int32_t>{0, 0, 0, 0}, 9, GYMNET_FLAG_AUTORESET, GYMNET_GATHER_DIRECT);
+        CHECK((int64_t)g.Reset().size() == 4 * 513 * 6, "group Reset over the whole batch");
+        gymnet::BatchStep b = g.Step(std::vector<int32_t>(4 * 513, 2));
+        CHECK(b.size() == 4 * 513 && b.Observation.size() == (size_t)4 * 513 * 6, "group Step");
+        g.AllGatherObs(); g.WaitGather(); g.Sync();
+        CHECK(g.ReadReplica(3).size() == (size_t)4 * 6 * 513, "replica [G][D][N/G]");
+    }
+}
+
 int main(int argc, char **argv) {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
+    const bool stub = argc > 1 && std::strcmp(argv[1], "--stub") == 0;
     try {
+        if (stub) { stub_tests(); std::printf("stub: %d failed check(s)\n", g_failed); return g_failed ? 1 : 0; }
         cpu_tests();
         if (gpu) gpu_tests();
     } catch (const std::exception &e) {
