@@ -38,6 +38,7 @@ FLAG_FINAL_OBS = 0x10
 FLAG_DOUBLE_BUFFER = 0x20
 FLAG_F64 = 0x40
 FLAG_COMPACT_RECORDS_ONLY = 0x80
+FLAG_RESIDENT = 0x100
 
 DTYPE_F32, DTYPE_F64 = 0, 1
 (ARRAY_REWARD, ARRAY_DONE, ARRAY_STEPS_BEYOND_DONE, ARRAY_EPISODE_RETURN, ARRAY_EPISODE_LENGTH, ARRAY_FINISHED_RETURN,

@@ -5,6 +5,7 @@
 // and is never linked here.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -525,6 +526,92 @@ int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_
 
 }  // namespace gymnet
 
+namespace gymnet {
+
+// ~1.5 us per poll over PCIe: the resident kernel leaves after ~50-75 ms without a command
+constexpr uint64_t kResidentIdlePolls = 40000;
+
+template <class R>
+static int resident_start_typed(gymnet_vecenv *h) {
+    StepArgsT<R> a = make_step_args<R>(h, h->mb_dev->actions);       // the kernel reads its actions straight from the mailbox
+    ResetArgsT<R> r{};
+    r.state = static_cast<R *>(h->d_state); r.obs = static_cast<R *>(h->d_obs); r.sbd = h->d_sbd; r.done = h->d_done; r.mask = nullptr;
+    r.tick2 = h->d_tick2; r.lane_seed = h->d_lane_seed; r.ep_ret = h->d_ep_ret; r.ep_len = h->d_ep_len;
+    r.n = h->n; r.state_stride = h->sstride; r.obs_stride = h->ostride; r.lane_offset = (uint64_t)h->cfg.lane_offset; r.seed = h->seed;
+    r.parity = (int32_t)h->tslot;
+    HIP_TRY(h, launch_resident(h->cfg.env_id, h->autoreset, h->extras, a, r, h->mb_dev, kResidentIdlePolls, h->stream));
+    return GYMNET_OK;
+}
+
+static int resident_start(gymnet_vecenv *h) {
+    // the kernel picks the sequence number it continues from out of the mailbox: nothing is pending at this point
+    __atomic_store_n(&h->mb->exited, 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(&h->mb->done_seq, h->mb_seq, __ATOMIC_RELAXED);
+    __atomic_store_n(&h->mb->cmd_seq, h->mb_seq, __ATOMIC_RELEASE);
+    ST_TRY(h->f64 ? resident_start_typed<double>(h) : resident_start_typed<float>(h));
+    h->resident_running = true;
+    return GYMNET_OK;
+}
+
+// Tells a running resident kernel to leave and waits until it has; the engine tick it kept in a register comes back through
+// the mailbox (and through both halves of d_tick2 for the next launch).
+int resident_stop(gymnet_vecenv *h) {
+    if (!h->resident_running) return GYMNET_OK;
+    if (!__atomic_load_n(&h->mb->exited, __ATOMIC_ACQUIRE)) {
+        h->mb->cmd = kMailboxExit;
+        __atomic_store_n(&h->mb->cmd_seq, ++h->mb_seq, __ATOMIC_RELEASE);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->resident_running = false;
+    h->tick = h->mb->tick;
+    return GYMNET_OK;
+}
+
+// One command through the mailbox: post it, wait for its results, copy them out.  actions: host, or NULL (resets).
+static int resident_command(gymnet_vecenv *h, uint32_t cmd, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out) {
+    const EnvDesc &d = *h->desc;
+    if (h->resident_running && __atomic_load_n(&h->mb->exited, __ATOMIC_ACQUIRE)) ST_TRY(resident_stop(h));   // it timed out since the last call
+    if (!h->resident_running) ST_TRY(resident_start(h));
+    if (actions) std::memcpy(h->mb->actions, actions, (size_t)h->n * 4);
+    h->mb->cmd = cmd;
+    const uint64_t seq = ++h->mb_seq;
+    __atomic_store_n(&h->mb->cmd_seq, seq, __ATOMIC_RELEASE);
+    uint64_t spins = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    while (__atomic_load_n(&h->mb->done_seq, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3FFu) == 0) {
+            if (__atomic_load_n(&h->mb->exited, __ATOMIC_ACQUIRE)) {
+                // the kernel left (idle timeout) in the instant this command was posted, without serving it: it touches
+                // nothing any more — wait for it to be gone, start a new one, which finds the command pending
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                h->resident_running = false;
+                h->tick = h->mb->tick;
+                if (__atomic_load_n(&h->mb->done_seq, __ATOMIC_ACQUIRE) == seq) break;
+                __atomic_store_n(&h->mb->exited, 0u, __ATOMIC_RELAXED);
+                ST_TRY(h->f64 ? resident_start_typed<double>(h) : resident_start_typed<float>(h));
+                h->resident_running = true;
+            } else if (hipStreamQuery(h->stream) == hipSuccess) {
+                h->resident_running = false;
+                return fail(h, GYMNET_ERR_HIP, "the resident kernel ended without answering command %llu", (unsigned long long)seq);
+            }
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(10)) return fail(h, GYMNET_ERR_HIP, "the resident kernel does not answer (10 s)");
+        }
+    }
+    const char *mb_obs = reinterpret_cast<const char *>(h->mb) + kMailboxObsOffset;
+    if (obs_out) std::memcpy(obs_out, mb_obs, (size_t)h->n * d.obs_dim * h->esz);
+    if (reward_out) std::memcpy(reward_out, h->mb->reward, (size_t)h->n * 4);
+    if (done_out) std::memcpy(done_out, h->mb->done, (size_t)h->n);
+    h->tick = h->mb->tick;
+    if (cmd == kMailboxStep) h->lane_steps += (uint64_t)h->n;
+    return GYMNET_OK;
+}
+
+// the resident path serves this handle's host-boundary steps right now (everything that changes what the kernel's arguments
+// describe — seeds, per-lane keys, state, policy — goes through ENTER, which makes the kernel leave first; it restarts with fresh arguments)
+static bool resident_serves(const gymnet_vecenv *h) { return h->resident && !h->async_pending; }
+
+}  // namespace gymnet
+
 extern "C" {
 
 int gymnet_abi_version(void) { return GYMNET_ABI_VERSION; }
@@ -588,7 +675,9 @@ int gymnet_vecenv_destroy(gymnet_vecenv *h) {
     if (!h) return GYMNET_OK;
     DeviceScope dev_scope;
     (void)hipSetDevice(h->device);
+    if (h->resident_running) (void)resident_stop(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->mb) (void)hipHostFree(h->mb);
     drop_graphs(h);
     for (void *p : h->owned) (void)hipFree(p);
     if (h->d_ep_seg) (void)hipFree(h->d_ep_seg);
@@ -612,7 +701,8 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "num_envs %lld out of range [1, 2^31]", (long long)cfg->num_envs);
     if (cfg->lane_offset < 0) return fail(nullptr, GYMNET_ERR_INVALID_ARG, "lane_offset < 0");
     constexpr uint32_t kKnownFlags = GYMNET_FLAG_AUTORESET | GYMNET_FLAG_VALIDATE_ACTIONS | GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_EPISODE_STATS |
-                                     GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER | GYMNET_FLAG_F64 | GYMNET_FLAG_COMPACT_RECORDS_ONLY;
+                                     GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER | GYMNET_FLAG_F64 | GYMNET_FLAG_COMPACT_RECORDS_ONLY |
+                                     GYMNET_FLAG_RESIDENT;
     if (cfg->flags & ~kKnownFlags)      // a flag from a newer header must not be silently ignored by an older library
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "unknown flag bits 0x%x (this library is ABI %d)", cfg->flags & ~kKnownFlags, GYMNET_ABI_VERSION);
     if (cfg->max_episode_steps < 0 || (cfg->max_episode_steps > 0 && !(cfg->flags & GYMNET_FLAG_EPISODE_STATS)))
@@ -630,6 +720,11 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     const size_t esz_cfg = (cfg->flags & GYMNET_FLAG_F64) ? 8 : 4;
     if ((cfg->d_ext_obs && !aligned_to(cfg->d_ext_obs, (int)esz_cfg)) || (cfg->d_ext_obs_alt && !aligned_to(cfg->d_ext_obs_alt, (int)esz_cfg)))
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "d_ext_obs / d_ext_obs_alt must be aligned to the observation element (%zu bytes)", esz_cfg);
+    if (cfg->flags & GYMNET_FLAG_RESIDENT) {
+        if (cfg->num_envs > kMailboxLanes) return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_RESIDENT serves up to %d lanes (one wave)", kMailboxLanes);
+        if ((cfg->flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER)) || cfg->d_ext_obs || cfg->stream)
+            return fail(nullptr, GYMNET_ERR_UNSUPPORTED, "GYMNET_FLAG_RESIDENT cannot be combined with DONE_LIST / FINAL_OBS / DOUBLE_BUFFER / d_ext_obs / a caller's stream");
+    }
     if ((cfg->flags & GYMNET_FLAG_COMPACT_RECORDS_ONLY) && !(cfg->flags & GYMNET_FLAG_DONE_LIST))
         return fail(nullptr, GYMNET_ERR_INVALID_ARG, "GYMNET_FLAG_COMPACT_RECORDS_ONLY needs GYMNET_FLAG_DONE_LIST");
 
@@ -707,6 +802,16 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
             (void)hipGetLastError();
             h->hm_block = nullptr;             // fall back to the memcpy path
         }
+    }
+    if (cfg->flags & GYMNET_FLAG_RESIDENT) {
+        void *blk = nullptr;
+        CREATE_HIP(hipHostMalloc(&blk, kMailboxBytes, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(blk, 0, kMailboxBytes);
+        h->mb = static_cast<Mailbox *>(blk);
+        void *dev = nullptr;
+        CREATE_HIP(hipHostGetDevicePointer(&dev, blk, 0));
+        h->mb_dev = static_cast<Mailbox *>(dev);
+        h->resident = true;
     }
     if (d.has_sbd && !h->autoreset) CREATE_TRY(dalloc(h, &h->d_sbd, (size_t)padded));
     if (cfg->flags & GYMNET_FLAG_FINAL_OBS) CREATE_TRY(dalloc(h, (char **)&h->d_final_obs, (size_t)h->n * d.obs_dim * esz));
@@ -811,7 +916,9 @@ int gymnet_vecenv_reset_where_device(gymnet_vecenv *h, const uint8_t *d_mask) {
 
 int gymnet_vecenv_reset(gymnet_vecenv *h, void *obs_out) {
     return guarded([&]() -> int {
-    ENTER(h);
+    ENTER_KEEP_RESIDENT(h);
+    if (resident_serves(h)) return resident_command(h, kMailboxResetAll, nullptr, obs_out, nullptr, nullptr);
+    if (h->resident_running) ST_TRY(resident_stop(h));
     ST_TRY(launch_reset_lanes(h, nullptr));
     return copy_out(h, obs_out, nullptr, nullptr);
     });
@@ -819,7 +926,9 @@ int gymnet_vecenv_reset(gymnet_vecenv *h, void *obs_out) {
 
 int gymnet_vecenv_reset_where(gymnet_vecenv *h, const uint8_t *mask, void *obs_out) {
     return guarded([&]() -> int {
-    ENTER(h);
+    ENTER_KEEP_RESIDENT(h);
+    if (!mask && !h->autoreset && resident_serves(h)) return resident_command(h, kMailboxResetDone, nullptr, obs_out, nullptr, nullptr);
+    if (h->resident_running) ST_TRY(resident_stop(h));
     if (!mask && h->autoreset) return copy_out(h, obs_out, nullptr, nullptr);   // no-op, see gymnet_vecenv_reset_where_device
     if (mask) {
         ST_TRY(ensure_staging(h, false, false, true));
@@ -853,10 +962,26 @@ int gymnet_vecenv_host_buffers(gymnet_vecenv *h, void **actions, void **obs, flo
     });
 }
 
+// Discrete.Contains over a HOST batch (the resident path validates before it posts: nothing has been staged on the device)
+static int validate_host_actions(gymnet_vecenv *h, const void *actions) {
+    const EnvDesc &d = *h->desc;
+    if (!(h->cfg.flags & GYMNET_FLAG_VALIDATE_ACTIONS) || d.box_action) return GYMNET_OK;
+    const int32_t *a = static_cast<const int32_t *>(actions);
+    uint32_t bad = 0;
+    for (int64_t i = 0; i < h->n; ++i) bad += (a[i] < 0 || a[i] >= d.action_n) ? 1u : 0u;
+    if (bad) return fail(h, GYMNET_ERR_INVALID_ACTION, "Action is outside of the configured action space. (%u of %lld lanes, Discrete(%d))", bad, (long long)h->n, d.action_n);
+    return GYMNET_OK;
+}
+
 int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
-    ENTER(h);
+    ENTER_KEEP_RESIDENT(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
+    if (resident_serves(h)) {
+        if (!actions) return fail(h, GYMNET_ERR_INVALID_ARG, "actions is null");
+        ST_TRY(validate_host_actions(h, actions));
+        return resident_command(h, kMailboxStep, actions, obs_out, reward_out, done_out);
+    }
     const void *d_act = nullptr;
     ST_TRY(stage_host_actions(h, actions, &d_act, true));
     ST_TRY(launch_one_step(h, d_act));
@@ -866,9 +991,18 @@ int gymnet_vecenv_step(gymnet_vecenv *h, const void *actions, void *obs_out, flo
 
 int gymnet_vecenv_step_broadcast(gymnet_vecenv *h, int32_t action, void *obs_out, float *reward_out, uint8_t *done_out) {
     return guarded([&]() -> int {
-    ENTER(h);
+    ENTER_KEEP_RESIDENT(h);
     if (h->async_pending) return fail(h, GYMNET_ERR_ALREADY_STEPPING, "already running an async step");
     const EnvDesc &d = *h->desc;
+    if (resident_serves(h)) {
+        int32_t bits[kMailboxLanes];
+        float f = (float)action;                         // IVecEnv.Step(int) on a Box space: the int is the (scalar) torque
+        int32_t word = action;
+        if (d.box_action) std::memcpy(&word, &f, 4);
+        for (int64_t i = 0; i < h->n; ++i) bits[i] = word;
+        ST_TRY(validate_host_actions(h, bits));
+        return resident_command(h, kMailboxStep, bits, obs_out, reward_out, done_out);
+    }
     ST_TRY(ensure_staging(h, true, false, false));
     if (d.box_action) {   // IVecEnv.Step(int) on a Box space: the int is the (scalar) torque
         float f = (float)action;

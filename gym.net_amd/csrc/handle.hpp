@@ -92,6 +92,12 @@ struct gymnet_vecenv {
     float *pin_reward = nullptr;
     uint8_t *pin_done = nullptr;
     uint32_t *d_bad = nullptr;
+    // GYMNET_FLAG_RESIDENT (num_envs <= 64): the mailbox in coherent host memory and the state of the resident kernel
+    gymnet::Mailbox *mb = nullptr;         // host address (page-locked, device-mapped, coherent)
+    gymnet::Mailbox *mb_dev = nullptr;     // the same memory as the device sees it
+    bool resident = false;                 // the handle serves host-boundary steps / resets through the resident kernel
+    bool resident_running = false;         // a resident kernel is (or may still be) on the stream
+    uint64_t mb_seq = 0;                   // sequence number of the last command posted
     void *d_ep_seg = nullptr;      // fused rollout: segmented episode records + shard counters (allocated on first use, grown on demand)
     int64_t ep_seg_cap = 0;        // records per shard segment
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
@@ -148,13 +154,18 @@ struct BusyGuard {
     } while (0)
 
 // Entry-point prologue: null check, single-caller guard, switch to the handle's device (restored on return).
-#define ENTER(h)                                                                                                   \
+// ENTER_KEEP_RESIDENT: the entry points the resident kernel itself serves (host-boundary step / reset).  ENTER: everything else —
+// a running resident kernel is told to leave first (it owns the stream and the tick until it has), see resident_stop.
+#define ENTER_KEEP_RESIDENT(h)                                                                                     \
     if (!(h)) return ::gymnet::fail(nullptr, GYMNET_ERR_INVALID_ARG, "null handle");                                \
     ::gymnet::BusyGuard guard_(h);                                                                                 \
     if (!guard_.ok) return ::gymnet::fail(h, GYMNET_ERR_ALREADY_STEPPING, "handle is in use by another call");      \
     ::gymnet::DeviceScope dev_scope_;                                                                              \
     (void)hipGetLastError();   /* a stale error left on this thread by anyone must not fail this call's launches */ \
     HIP_TRY(h, hipSetDevice((h)->device))
+#define ENTER(h)                                                                                                   \
+    ENTER_KEEP_RESIDENT(h);                                                                                        \
+    if ((h)->resident_running) { int rs_ = ::gymnet::resident_stop(h); if (rs_ != GYMNET_OK) return rs_; }
 
 // Nothing may throw across the C ABI: every entry point body runs inside this guard.
 template <class F>
@@ -194,5 +205,6 @@ int copy_out(gymnet_vecenv *h, void *obs_out, float *reward_out, uint8_t *done_o
 int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_t action_stride, int64_t ring, int graph_mode = -1);
 int write_tick(gymnet_vecenv *h);
 int seed_handle(gymnet_vecenv *h, uint64_t seed);                    // Env.Seed(int): new key, tick 0, captured graphs dropped
+int resident_stop(gymnet_vecenv *h);                                 // tells a running resident kernel to leave and waits until it has
 
 }  // namespace gymnet

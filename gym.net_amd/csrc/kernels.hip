@@ -407,6 +407,23 @@ hipError_t launch_reset(int env_id, const ResetArgsT<double> &a, hipStream_t st)
     return launch_reset_cartpole64(a, st);
 }
 
+hipError_t launch_resident(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, const ResetArgsT<float> &r, Mailbox *mb,
+                           uint64_t idle_polls, hipStream_t st) {
+    switch (env_id) {
+        case 0: return launch_resident_cartpole(autoreset, extras, a, r, mb, idle_polls, st);
+        case 1: return launch_resident_pendulum(autoreset, extras, a, r, mb, idle_polls, st);
+        case 2: return launch_resident_mountaincar(autoreset, extras, a, r, mb, idle_polls, st);
+        case 3: return launch_resident_acrobot(autoreset, extras, a, r, mb, idle_polls, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_resident(int env_id, bool autoreset, bool extras, const StepArgsT<double> &a, const ResetArgsT<double> &r, Mailbox *mb,
+                           uint64_t idle_polls, hipStream_t st) {
+    if (env_id != 0) return hipErrorInvalidValue;
+    return launch_resident_cartpole64(autoreset, extras, a, r, mb, idle_polls, st);
+}
+
 hipError_t launch_observe(int env_id, const float *state, int64_t sstride, float *obs, int64_t ostride, int64_t n,
                           hipStream_t st) {
     switch (env_id) {

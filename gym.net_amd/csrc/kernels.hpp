@@ -66,7 +66,8 @@ struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1;
     void resolved_shape_##tag(bool autoreset, bool extras, LaunchCfg cfg, int64_t n, int *vec, int *sequential);                \
     hipError_t launch_rollout_##tag(bool autoreset, bool extras, const StepArgsT<R> &a, const RolloutArgsT<R> &r, LaunchCfg cfg, hipStream_t st); \
     hipError_t launch_reset_##tag(const ResetArgsT<R> &a, hipStream_t st);                                                      \
-    hipError_t launch_observe_##tag(const R *state, int64_t sstride, R *obs, int64_t ostride, int64_t n, hipStream_t st);
+    hipError_t launch_observe_##tag(const R *state, int64_t sstride, R *obs, int64_t ostride, int64_t n, hipStream_t st);            \
+    hipError_t launch_resident_##tag(bool autoreset, bool extras, const StepArgsT<R> &a, const ResetArgsT<R> &r, Mailbox *mb, uint64_t idle_polls, hipStream_t st);
 
 // Fused multi-step rollout: `steps` vector steps inside ONE launch; state stays in registers between steps.
 // Round 5: the rollout carries what its consumer needs (examples/.../PlaySessions/BasePlaySession.cs:58-69 accumulates the episode
@@ -112,6 +113,33 @@ struct ResetArgsT {
 typedef ResetArgsT<float> ResetArgs;
 typedef ResetArgsT<double> ResetArgs64;
 
+// ---- resident single-wave kernel (GYMNET_FLAG_RESIDENT; N <= 64 lanes: the single-instance facade's latency path) -----------------
+// The reference's usage shape is ONE env stepped in a host loop (README.md:32-52, Env.cs:13-41).  Served by one kernel launch +
+// one stream synchronize per step that costs ~25 us; served by a RESIDENT kernel — one wave that stays on the GPU, polls a mailbox
+// in page-locked, device-mapped, coherent HOST memory for commands and writes observation / reward / done back into it — a step
+// is two PCIe crossings and no launch.  The kernel leaves by itself after `idle_polls` polls without a command (or on the exit
+// command) and touches nothing afterwards; the host restarts it on the next command.  Same per-lane code (step_body / reset_lane)
+// and Philox counters as the launch path: bit-identical.
+constexpr int kMailboxLanes = 64;
+struct Mailbox {
+    uint64_t cmd_seq;                 // host -> device: sequence number of the newest command (the host writes it LAST, release)
+    uint32_t cmd;                     // kMailboxStep / ResetAll / ResetDone / Exit
+    uint32_t pad0;
+    uint64_t done_seq;                // device -> host: the last command whose results are in the mailbox (written LAST, release)
+    uint32_t exited;                  // device -> host: the kernel has left; it touches nothing afterwards
+    uint32_t pad1;
+    uint64_t tick;                    // device -> host: engine tick after the last command
+    uint64_t pad2[3];
+    int32_t actions[kMailboxLanes];   // int32 (Discrete) or float32 bits (Box), one per lane
+    float reward[kMailboxLanes];
+    uint8_t done[kMailboxLanes];
+    // the observations follow at kMailboxObsOffset: row-major [lane][obs_dim] of the handle's state scalar (<= 64 * 6 * 8 bytes)
+};
+constexpr size_t kMailboxObsOffset = 1024;
+constexpr size_t kMailboxBytes = kMailboxObsOffset + (size_t)kMailboxLanes * 8 * 8;
+static_assert(sizeof(Mailbox) <= kMailboxObsOffset, "mailbox header overlaps the observations");
+constexpr uint32_t kMailboxStep = 1, kMailboxResetAll = 2, kMailboxResetDone = 3, kMailboxExit = 4;
+
 GYMNET_DECLARE_ENV(cartpole, float)
 GYMNET_DECLARE_ENV(pendulum, float)
 GYMNET_DECLARE_ENV(mountaincar, float)
@@ -145,6 +173,9 @@ hipError_t launch_gather_episodes(const EpisodeGatherArgs &a, hipStream_t st);
 
 hipError_t launch_reset(int env_id, const ResetArgsT<float> &a, hipStream_t st);
 hipError_t launch_reset(int env_id, const ResetArgsT<double> &a, hipStream_t st);
+// starts the resident kernel of a small handle (a.n <= kMailboxLanes; a.action must point at mb->actions); mb: device-visible address
+hipError_t launch_resident(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, const ResetArgsT<float> &r, Mailbox *mb, uint64_t idle_polls, hipStream_t st);
+hipError_t launch_resident(int env_id, bool autoreset, bool extras, const StepArgsT<double> &a, const ResetArgsT<double> &r, Mailbox *mb, uint64_t idle_polls, hipStream_t st);
 
 // observations: SoA [O][stride] -> row-major [n][O]; float32, or float64 for a GYMNET_FLAG_F64 handle (here and below)
 hipError_t launch_pack_obs(int obs_dim, const float *obs, int64_t stride, float *out_rowmajor, int64_t n, hipStream_t st);

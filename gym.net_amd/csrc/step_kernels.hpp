@@ -978,6 +978,72 @@ __global__ __launch_bounds__(256) void observe_kernel(const typename Env::Real *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Resident single-wave kernel (kernels.hpp: Mailbox).  One wave; lane i serves env i.  Commands arrive through the mailbox in
+// coherent host memory: every poll is an ACQUIRE load of cmd_seq at system scope, so the loads of the command and of the actions
+// that follow cannot be satisfied from anything older; results are published by a system-scope RELEASE fence executed by the
+// whole wave followed by the store of done_seq.  The device-side state lives in the handle's ordinary arrays (so every other
+// entry point sees it after the kernel has left); the engine tick is kept in a register and written back on the way out.
+// ---------------------------------------------------------------------------------------------
+template <class Env, bool AUTORESET, bool EXTRAS>
+__global__ __launch_bounds__(64) void resident_kernel(const StepArgsT<typename Env::Real> a, const ResetArgsT<typename Env::Real> ra, Mailbox *mb,
+                                                      const uint64_t idle_polls) {
+    using Real = typename Env::Real;
+    constexpr int O = Env::O;
+    const int64_t lane = threadIdx.x;
+    const bool mine = lane < a.n;
+    Real *mb_obs = reinterpret_cast<Real *>(reinterpret_cast<char *>(mb) + kMailboxObsOffset);
+    uint64_t tick = a.tick2[a.parity];
+    uint64_t last = __hip_atomic_load(&mb->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint64_t idle = 0;
+    for (;;) {
+        const uint64_t seq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq == last) {                                     // wave-uniform (every lane read the same word)
+            if (++idle > idle_polls) break;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        idle = 0;
+        const uint32_t cmd = __hip_atomic_load(&mb->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cmd == kMailboxExit) { last = seq; break; }
+        if (mine) {
+            if (cmd == kMailboxStep) step_body<Env, 1, AUTORESET, EXTRAS, 0, true, 0>(a, lane, tick);
+            else if (cmd == kMailboxResetAll || (cmd == kMailboxResetDone && a.done[lane])) reset_lane<Env>(ra, lane, tick);
+        }
+        tick += 1;
+        if (mine) {                                            // results: this lane's observation row, reward, done flag
+            const Real *src = Env::OBS_ALIASES_STATE ? a.state_out : a.obs;
+            const int64_t stride = Env::OBS_ALIASES_STATE ? a.state_stride : a.obs_stride;
+#pragma unroll
+            for (int k = 0; k < O; ++k) mb_obs[lane * O + k] = src[k * stride + lane];
+            mb->reward[lane] = a.reward[lane];
+            mb->done[lane] = a.done[lane];
+        }
+        if (lane == 0) mb->tick = tick;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope, the whole wave: every lane's results are out
+        if (lane == 0) __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        last = seq;
+    }
+    if (lane == 0) {
+        a.tick2[0] = tick; a.tick2[1] = tick;                  // both halves: whichever the next launch reads
+        mb->tick = tick;
+        __hip_atomic_store(&mb->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <class Env>
+static hipError_t launch_resident_env(bool autoreset, bool extras, const StepArgsT<typename Env::Real> &a, const ResetArgsT<typename Env::Real> &r,
+                                      Mailbox *mb, uint64_t idle_polls, hipStream_t st) {
+    if (a.n > kMailboxLanes) return hipErrorInvalidValue;
+    const dim3 grid(1), blk(64);
+    if (autoreset) { if (extras) hipLaunchKernelGGL((resident_kernel<Env, true, true>), grid, blk, 0, st, a, r, mb, idle_polls);
+                     else hipLaunchKernelGGL((resident_kernel<Env, true, false>), grid, blk, 0, st, a, r, mb, idle_polls); }
+    else           { if (extras) hipLaunchKernelGGL((resident_kernel<Env, false, true>), grid, blk, 0, st, a, r, mb, idle_polls);
+                     else hipLaunchKernelGGL((resident_kernel<Env, false, false>), grid, blk, 0, st, a, r, mb, idle_polls); }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
@@ -1195,6 +1261,10 @@ static hipError_t launch_observe_env(const typename Env::Real *state, int64_t ss
         return launch_rollout_env<Env>(autoreset, extras, a, r, cfg, st);                                                             \
     }                                                                                                                                 \
     hipError_t launch_reset_##tag(const ResetArgsT<Env::Real> &a, hipStream_t st) { return launch_reset_env<Env>(a, st); }            \
+    hipError_t launch_resident_##tag(bool autoreset, bool extras, const StepArgsT<Env::Real> &a, const ResetArgsT<Env::Real> &r,      \
+                                     Mailbox *mb, uint64_t idle_polls, hipStream_t st) {                                              \
+        return launch_resident_env<Env>(autoreset, extras, a, r, mb, idle_polls, st);                                                 \
+    }                                                                                                                                 \
     hipError_t launch_observe_##tag(const Env::Real *state, int64_t sstride, Env::Real *obs, int64_t ostride, int64_t n,              \
                                     hipStream_t st) {                                                                                 \
         return launch_observe_env<Env>(state, sstride, obs, ostride, n, st);                                                          \

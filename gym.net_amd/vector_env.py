@@ -83,10 +83,11 @@ class VectorEnv:
     def __init__(self, env="CartPole-v1", num_envs=1, device=0, seed=0, auto_reset=False,
                  validate_actions=False, done_list=False, episode_stats=False, final_obs=False,
                  lane_offset=0, stream=None, ext_obs=None, ext_obs_stride=0, max_episode_steps=0,
-                 double_buffer=False, ext_obs_alt=None, dtype=np.float32, compact_records_only=False, launch_policy=None):
+                 double_buffer=False, ext_obs_alt=None, dtype=np.float32, compact_records_only=False, launch_policy=None, resident=False):
         """dtype=np.float64 (CartPole only) selects GYMNET_FLAG_F64: the reference's own float64 arithmetic, float64 state and
         float64 observations (what CartPoleEnv.Step actually returns, CartPoleEnv.cs:166,185); the default float32 is the
-        engine's structure-of-arrays hot path.  launch_policy: dict for SetLaunchPolicy (probes / tests that pin a kernel form)."""
+        engine's structure-of-arrays hot path.  resident=True (num_envs <= 64): GYMNET_FLAG_RESIDENT — Step / Reset / ResetWhere(None)
+        are served by a resident single-wave kernel through a mailbox in pinned host memory (no launch, no synchronize per step).  launch_policy: dict for SetLaunchPolicy (probes / tests that pin a kernel form)."""
         env_id = capi.ENV_IDS[env] if isinstance(env, str) else int(env)
         self._lib = capi.load_library()
         self._info = capi.env_describe(env_id)
@@ -97,7 +98,8 @@ class VectorEnv:
                  | (capi.FLAG_DONE_LIST if done_list else 0) | (capi.FLAG_EPISODE_STATS if episode_stats else 0)
                  | (capi.FLAG_FINAL_OBS if final_obs else 0) | (capi.FLAG_DOUBLE_BUFFER if double_buffer else 0)
                  | (capi.FLAG_F64 if self._dtype == np.float64 else 0)
-                 | (capi.FLAG_COMPACT_RECORDS_ONLY if compact_records_only else 0))
+                 | (capi.FLAG_COMPACT_RECORDS_ONLY if compact_records_only else 0)
+                 | (capi.FLAG_RESIDENT if resident else 0))
         cfg = capi.Config(struct_size=C.sizeof(capi.Config), env_id=env_id, num_envs=int(num_envs),
                           lane_offset=int(lane_offset), device=int(device), flags=flags,
                           seed=int(seed) & 0xFFFFFFFFFFFFFFFF, stream=_ptr(stream), d_ext_obs=_ptr(ext_obs),
@@ -107,6 +109,7 @@ class VectorEnv:
         self._owns_handle = True
         self._bookkeeping = bool(episode_stats or max_episode_steps)
         self._final_obs = bool(final_obs)
+        self.Resident = bool(resident)
         capi.check(self._lib.gymnet_vecenv_create(C.byref(cfg), C.byref(self._h)))
         self._describe(env_id, num_envs, auto_reset)
         if launch_policy:
@@ -122,6 +125,7 @@ class VectorEnv:
         self._owns_handle = False
         self._bookkeeping = True            # a group member: flags unknown here (DoneRecords() asks for everything it may have)
         self._final_obs = False
+        self.Resident = False
         self._dtype = np.dtype(dtype)
         self._describe(env_id, num_envs, auto_reset)
         return self
@@ -683,13 +687,17 @@ class GpuEnv:
     ENV = "CartPole-v1"
     DTYPE = np.float32          # CartPoleEnv overrides: float64, the reference's own arithmetic
 
-    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0, dtype=None):
+    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0, dtype=None, resident=True):
         """max_episode_steps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; an extension: the
         reference has no time limit): the step that reaches the limit returns Done with
-        Information["TimeLimit.truncated"] = True — the same shape as the C# GpuEnv (csharp/GpuEnv.cs)."""
+        Information["TimeLimit.truncated"] = True — the same shape as the C# GpuEnv (csharp/GpuEnv.cs).
+        resident (default): Step / Reset go through GYMNET_FLAG_RESIDENT — a resident single-wave kernel polling a mailbox in pinned
+        host memory — instead of a kernel launch + synchronize per call: the per-instance loop of README.md:32-52 is latency-bound.
+        Bit-identical results.  resident=False: one launch per call (e.g. when the process issues device-wide synchronizes elsewhere
+        and must not wait for the resident kernel's idle timeout)."""
         self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions,
                             episode_stats=max_episode_steps > 0, max_episode_steps=max_episode_steps,
-                            dtype=self.DTYPE if dtype is None else dtype)
+                            dtype=self.DTYPE if dtype is None else dtype, resident=resident)
         self.ActionSpace, self.ObservationSpace = self._v.ActionSpace, self._v.ObservationSpace
         self.Metadata, self.RewardRange = self._v.Metadata, self._v.RewardRange
         self._pending = None

@@ -99,6 +99,14 @@ typedef enum gymnet_env_id {
                                               (gymnet_vecenv_episode_stats / _final_obs, gymnet_device_view.d_finished_*) are then brought up to
                                               date on demand, for the most recent step only.  Default (flag clear): the step kernel keeps the
                                               dense views current itself, whatever the caller reads or skips */
+#define GYMNET_FLAG_RESIDENT         0x100u /* ABI 5, num_envs <= 64 (the single-instance usage shape, README.md:32-52 / Env.cs:13-41): the host-boundary
+                                              step / reset calls (gymnet_vecenv_step, _step_broadcast, _reset, _reset_where(NULL)) are served by a RESIDENT
+                                              single-wave kernel that polls a mailbox in page-locked, device-mapped host memory: no kernel launch and no
+                                              stream synchronize per step (two PCIe crossings instead of ~25 us).  Results are bit-identical to the
+                                              launch path.  The kernel leaves by itself after ~50 ms without a command and is restarted on demand; every
+                                              other entry point first tells it to leave.  While it is resident it occupies the handle's stream: a
+                                              device-wide synchronize issued elsewhere in the process waits for it (up to the idle timeout).  Not with
+                                              DONE_LIST / FINAL_OBS / DOUBLE_BUFFER / d_ext_obs / a caller's stream (GYMNET_ERR_UNSUPPORTED) */
 #define GYMNET_FLAG_DOUBLE_BUFFER    0x20u /* two observation buffers, written alternately: the step launched after buffer A was
                                               written reads A and writes B, so a consumer (an all-gather of A over xGMI, a policy
                                               reading A) may still be using A while the next step runs.  For envs whose observation

@@ -1,0 +1,90 @@
+"""GPU tests of GYMNET_FLAG_RESIDENT: the single-instance usage shape (README.md:32-52, Env.cs:13-41) served by a
+resident single-wave kernel that polls a mailbox in pinned host memory — no kernel launch and no stream synchronize per step.
+Bars: bit-identical to the launch path (same per-lane code, same Philox counters) for every env, both state scalars, with and
+without auto-reset / bookkeeping; every other entry point (state access, seeding, device-path steps, checkpoint) interleaves
+correctly because it makes the kernel leave first; the kernel leaves by itself when idle and is restarted transparently."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def _act(rng, name, n):
+    if name == "Pendulum-v1":
+        return rng.uniform(-2, 2, n).astype(np.float32)
+    return rng.integers(0, 2 if name == "CartPole-v1" else 3, n).astype(np.int32)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name,dtype", [("CartPole-v1", np.float32), ("CartPole-v1", np.float64), ("Pendulum-v1", np.float32),
+                                         ("MountainCar-v0", np.float32), ("Acrobot-v1", np.float32)])
+@pytest.mark.parametrize("n,auto", [(1, False), (7, True), (64, True)])
+def test_resident_path_is_bit_identical_to_the_launch_path(gpu_pkg, name, dtype, n, auto):
+    rng = np.random.default_rng(n)
+    kw = dict(seed=SEED, auto_reset=auto, dtype=dtype, lane_offset=1 << 34, episode_stats=(n == 7), max_episode_steps=13 if n == 7 else 0)
+    with gpu_pkg.VectorEnv(name, n, resident=True, **kw) as r, gpu_pkg.VectorEnv(name, n, **kw) as e:
+        assert np.array_equal(r.Reset(), e.Reset())
+        for t in range(120):
+            if t % 17 == 5:                                            # IVecEnv.Step(int): scalar broadcast
+                a, b = r.Step(1), e.Step(1)
+            else:
+                act = _act(rng, name, n)
+                a, b = r.Step(act), e.Step(act)
+            assert np.array_equal(a.Observation, b.Observation, equal_nan=True) and np.array_equal(a.Reward, b.Reward) and np.array_equal(a.Done, b.Done), t
+            assert np.array_equal(a.Truncated, b.Truncated)
+            if not auto and b.Done.any() and t % 3 == 0:               # the caller's `if (done) Reset()`
+                assert np.array_equal(r.ResetWhere(), e.ResetWhere())
+            if t == 40:                                                # entry points that make the kernel leave, then it comes back
+                assert np.array_equal(r.GetState(), e.GetState(), equal_nan=True) and r.Tick == e.Tick
+                r.SetState(r.GetState()); e.SetState(e.GetState())
+            if t == 60:
+                for env in (r, e):                                     # (lane_steps is a statistic, not part of a checkpoint: both take the detour)
+                    ck = env.Checkpoint()
+                    env.Step(_act(np.random.default_rng(1), name, n))
+                    env.Restore(ck)
+            if t == 80 and name != "Pendulum-v1":
+                r.Seed(np.arange(n) + 3); e.Seed(np.arange(n) + 3)     # per-lane keys: the kernel restarts with the keyed variant
+                assert np.array_equal(r.Reset(), e.Reset())
+        assert r.Counters() == e.Counters()
+        assert np.array_equal(r.GetState(), e.GetState(), equal_nan=True)
+
+
+@pytest.mark.timeout(300)
+def test_resident_facade_loop_idle_timeout_and_errors(gpu_pkg):
+    """The README loop on the single-instance facade (which asks for the resident path): the reference-test trace shape, an idle
+    pause longer than the kernel's timeout in the middle (it leaves by itself and is restarted by the next call), and the error
+    paths (invalid action before anything is posted; unsupported combinations at create)."""
+    a, b = gpu_pkg.CartPoleEnv(seed=7), gpu_pkg.CartPoleEnv(seed=7, resident=False)
+    try:
+        assert a._v.Resident and not b._v.Resident
+        done = True
+        for i in range(400):
+            if done:
+                oa, ob = a.Reset(), b.Reset()
+                assert np.array_equal(oa, ob) and oa.dtype == np.float64
+                done = False
+            else:
+                sa, sb = a.Step(i % 2), b.Step(i % 2)
+                assert np.array_equal(sa.Observation, sb.Observation) and sa.Done == sb.Done and sa.Reward == sb.Reward
+                done = sa.Done
+            if i == 200:
+                time.sleep(0.5)                                         # > the idle timeout: the kernel has left by the next call
+    finally:
+        a.CloseEnvironment(); b.CloseEnvironment()
+    with gpu_pkg.VectorEnv("CartPole-v1", 4, seed=1, resident=True, validate_actions=True) as v:
+        v.Reset()
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            v.Step(np.array([0, 1, 2, 0], np.int32))
+        with pytest.raises(gpu_pkg.InvalidActionError):
+            v.Step(5)
+        assert v.Step(1).Reward.shape == (4,)                           # the handle goes on
+        p = v.StepAsync(np.array([0, 1, 1, 0], np.int32))               # StepAsync takes the launch path
+        assert p.Result().Reward.shape == (4,)
+        assert v.Step(0).Reward.shape == (4,)
+    for kw in (dict(num_envs=65), dict(num_envs=8, done_list=True, auto_reset=True), dict(num_envs=8, double_buffer=True)):
+        n = kw.pop("num_envs")
+        with pytest.raises(NotImplementedError):
+            gpu_pkg.VectorEnv("CartPole-v1", n, resident=True, **kw)
