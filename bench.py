@@ -896,9 +896,11 @@ def main():
     facade = None
     if extras and args.env == "CartPole-v1":
         try:
-            facade = {"note": "N = 1 through the host boundary: launch + synchronize per step; the engine is built for batches"}
-            for label, dt in (("float64_default", "float64"), ("float32", "float32")):
-                cp = pkg.CartPoleEnv(device=dev_index, seed=seed, dtype=dt)
+            facade = {"note": "N = 1 through the host boundary (Python facade, ctypes): the default goes through GYMNET_FLAG_RESIDENT — a resident "
+                              "single-wave kernel polling a mailbox in pinned host memory, no launch / synchronize per step; *_launch_path = one "
+                              "kernel launch + one synchronize per call.  The engine is built for batches"}
+            for label, dt, res in (("float64_default", "float64", True), ("float32", "float32", True), ("float64_launch_path", "float64", False)):
+                cp = pkg.CartPoleEnv(device=dev_index, seed=seed, dtype=dt, resident=res)
                 try:
                     cp.Reset()
                     for i in range(200):

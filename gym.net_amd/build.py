@@ -26,13 +26,8 @@ DEPS = SOURCES + ["kernels.hpp", "step_kernels.hpp", "lanes.hpp", "envs.hpp", "c
 # bench kernels time the same either way).  Off = deterministic, purely scalar code generation.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 LIBS = ["-ldl"]          # librccl is dlopen()ed on demand by group.hip, never linked
-# Probe builds only: GYMNET_BUILD_PROBE_ENV=1 compiles the GYMNET_VEC / GYMNET_NT / ... environment overrides of the launch policy
-# back in (the round 1-3 tools/ scripts use them).  The shipped library never reads the process environment for its policy:
-# gymnet_vecenv_set_launch_policy is the interface.  A probe build goes to ITS OWN file (libgymnet_amd_probe.so; point
-# GYMNET_LIB_PATH at it), so it can never be mistaken for — or be left behind as — the shipped library.
-if os.environ.get("GYMNET_BUILD_PROBE_ENV") == "1":
-    FLAGS = FLAGS + ["-DGYMNET_PROBE_ENV"]
-    OUT = os.path.join(HERE, "lib", "libgymnet_amd_probe.so")
+# (The library never reads the process environment for its launch policy: gymnet_vecenv_set_launch_policy is the interface.  The
+# GYMNET_BUILD_PROBE_ENV probe build of rounds 1-4 went away in round 5 together with the scripts that needed it.)
 
 
 def hipcc():

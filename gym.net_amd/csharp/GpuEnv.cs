@@ -50,6 +50,9 @@ namespace Gym.Envs.Amd {
             if (validateActions) flags |= GymnetFlags.ValidateActions;
             if (maxEpisodeSteps > 0) flags |= GymnetFlags.EpisodeStats;
             if (float64) flags |= GymnetFlags.F64;
+            // the per-instance loop (README.md:32-52) is latency-bound: Step / Reset go through the resident kernel's mailbox
+            // (no kernel launch, no stream synchronize per call); bit-identical to the launch path
+            flags |= GymnetFlags.Resident;
             var cfg = new GymnetConfig {
                 struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = 1, lane_offset = 0,
                 device = device, flags = (uint) flags, seed = seed, max_episode_steps = maxEpisodeSteps

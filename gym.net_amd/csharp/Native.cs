@@ -20,7 +20,8 @@ namespace Gym.Envs.Amd {
     [Flags]
     public enum GymnetFlags : uint {
         None = 0, AutoReset = 0x01, ValidateActions = 0x02, DoneList = 0x04, EpisodeStats = 0x08, FinalObs = 0x10,
-        DoubleBuffer = 0x20, F64 = 0x40, CompactRecordsOnly = 0x80
+        DoubleBuffer = 0x20, F64 = 0x40, CompactRecordsOnly = 0x80,
+        Resident = 0x100      // ABI 5, num_envs <= 64: host-boundary Step / Reset served by a resident single-wave kernel + a host-memory mailbox
     }
 
     public enum GymnetDtype { F32 = 0, F64 = 1 }

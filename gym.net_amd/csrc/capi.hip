@@ -275,19 +275,6 @@ void default_policy(gymnet_vecenv *h) {
     // -> 4.55-4.73 us, Pendulum 5.97 -> 5.88 us; CartPole (41 MiB) does not gain (tools/gpu_nt_ab_r03.sh, profiles/block_nt_probe_r03.txt)
     if (h->lcfg.vec == 4 && step_bytes < ((size_t)40 << 20)) h->lcfg.block = 64;
     h->can_vec4 = can_vec4; h->can_vec2 = can_vec2; h->lds_ok = lds_ok;
-#ifdef GYMNET_PROBE_ENV
-    // PROBE BUILDS ONLY (build.py: GYMNET_BUILD_PROBE_ENV=1): the round 1-3 tools/ scripts steer the policy through the process
-    // environment.  The shipped library never reads it — a host process's environment must not silently change which kernel a
-    // library runs; tests, bench.py and current tools use gymnet_vecenv_set_launch_policy.
-    gymnet_launch_policy p;
-    std::memset(&p, 0xFF, sizeof p);          // every field -1 = keep
-    p.struct_size = sizeof p;
-    auto envi = [](const char *name, int32_t *dst) { if (const char *e = std::getenv(name)) *dst = std::atoi(e); };
-    envi("GYMNET_VEC", &p.vec); envi("GYMNET_NT", &p.nt); envi("GYMNET_ITEMS", &p.sequential_lanes);
-    envi("GYMNET_RESET_FORM", &p.reset_form); envi("GYMNET_LDS_PIPE", &p.lds_pipe); envi("GYMNET_LDS", &p.occupancy_lds_bytes);
-    envi("GYMNET_BLOCK", &p.block);
-    (void)apply_policy(h, p, /*strict=*/false);
-#endif
 }
 
 void recompute_extras(gymnet_vecenv *h) {
@@ -474,9 +461,6 @@ int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_
     // and loses at 2^20 (8.08 vs 7.85 us/step: a kernel node costs more than a back-to-back stream launch).
     const bool launch_bound = (size_t)h->n * bytes_per_step(h) < ((size_t)24 << 20);
     if (graph_mode < 0) graph_mode = h->graph_mode;          // gymnet_vecenv_set_launch_policy(.graph)
-#ifdef GYMNET_PROBE_ENV
-    if (graph_mode < 0) { if (const char *force = std::getenv("GYMNET_GRAPH")) graph_mode = std::atoi(force) != 0; }
-#endif
     const bool use_graph = graph_mode >= 0 ? graph_mode != 0 : launch_bound;
     if (use_graph && glen <= 4096 && steps >= glen) {
         const int parity = h->tslot, cparity = (int)(h->step_launches & 1u), cur = h->cur;

@@ -367,6 +367,8 @@ public:
         gymnet_config cfg{};
         cfg.struct_size = sizeof cfg; cfg.env_id = GYMNET_ENV_CARTPOLE; cfg.num_envs = 1; cfg.device = device;
         cfg.flags = GYMNET_FLAG_F64 | extra_flags; cfg.seed = seed;
+        // single instance: the resident latency path (see CartPoleEnv below) whenever the extra flags allow it
+        if (!(extra_flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER))) cfg.flags |= GYMNET_FLAG_RESIDENT;
         check(gymnet_vecenv_create(&cfg, &h_));
     }
     CartPoleEnv64(const CartPoleEnv64 &) = delete;
@@ -394,7 +396,9 @@ private:
 /// arithmetic: 1e-5 per teacher-forced step; CartPoleEnv64 above is the reference-exact one).
 class CartPoleEnv {
 public:
-    explicit CartPoleEnv(int device = 0, uint64_t seed = 0) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed) {}
+    /// GYMNET_FLAG_RESIDENT: the per-instance loop (README.md:32-52) is latency-bound — Step / Reset are served by a resident single-wave
+    /// kernel through a mailbox in pinned host memory (no launch, no synchronize per call); bit-identical to the launch path
+    explicit CartPoleEnv(int device = 0, uint64_t seed = 0, bool resident = true) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed, resident ? GYMNET_FLAG_RESIDENT : 0u) {}
     std::vector<float> Reset() { return v_.Reset(); }                           // CartPoleEnv.cs:63-67
     gymnet::Step Step(int action) { return v_.Step(std::vector<int32_t>{action})[0]; }   // CartPoleEnv.cs:137-186
     /// Env<TAction>.Step(TAction) where TAction : Enum (Env.cs:43-53): the enum's integer value is the discrete action

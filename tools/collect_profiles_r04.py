@@ -25,7 +25,7 @@ N = 1 << 20
 # configuration -> (bench arguments, bytes one env-step moves, algorithmic bytes, envs per lane of the kernel it runs at 2^20)
 CONFIGS = {
     "CartPole-v1": ("--env CartPole-v1", 41, 41, 4),
-    "CartPole-v1-f64": ("--env CartPole-v1 --dtype f64", 73, 73, 4),   # step_kernel_f64_pipe<2>: 2 lane pairs per thread
+    "CartPole-v1-f64": ("--env CartPole-v1 --dtype f64", 73, 73, 4),   # round 4: the float64 kernel with 2 lane pairs per thread (now step_kernel_pipe2<CartPole64,...>)
     "Pendulum-v1": ("--env Pendulum-v1", 33, 37, 4),
     "MountainCar-v0": ("--env MountainCar-v0", 25, 25, 4),
     "Acrobot-v1": ("--env Acrobot-v1", 57, 65, 4),           # step_kernel_pipe: 4 sequential lanes per thread
