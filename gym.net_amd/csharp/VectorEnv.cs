@@ -32,13 +32,13 @@ namespace Gym.Envs.Amd {
         internal int PendingLaneSeedCount;
 
         public VectorEnv(GymnetEnvId env, int numEnvs, int device = 0, ulong seed = 0, GymnetFlags flags = GymnetFlags.None,
-                         long laneOffset = 0)
+                         long laneOffset = 0, int maxEpisodeSteps = 0)
             : base(numEnvs, MakeObservationSpace(env, out int obsDim), MakeActionSpace(env, out bool box)) {
             _obsDim = obsDim; _boxAction = box;
             _f64 = (flags & GymnetFlags.F64) != 0;
             var cfg = new GymnetConfig {
                 struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = numEnvs, lane_offset = laneOffset,
-                device = device, flags = (uint) flags, seed = seed
+                device = device, flags = (uint) flags, seed = seed, max_episode_steps = maxEpisodeSteps      // (needs GymnetFlags.EpisodeStats)
             };
             Native.Check(Native.gymnet_vecenv_create(ref cfg, out _h));
             Metadata = new Dict("render.modes", new[] {"human", "rgb_array"}, "video.frames_per_second", 50);   // CartPoleEnv.cs:51
@@ -162,6 +162,8 @@ namespace Gym.Envs.Amd {
         /// TrainingPlaySession.cs:46-52): actions from a device ring, drawn in the kernel (action_source 1: ActionSpace.Sample()) or
         /// epsilon-greedy over the ring (2); dense recording; compact (step, lane, return, length) records of the episodes that end.
         /// All pointers in `spec` are DEVICE pointers; stream-ordered, does not block.
+        public void ResetDevice() => Native.Check(Native.gymnet_vecenv_reset_device(_h));      // device-resident path: nothing crosses PCIe
+        public void Sync() => Native.Check(Native.gymnet_vecenv_sync(_h));
         public void RolloutFused(GymnetRolloutSpec spec) {
             spec.struct_size = (uint) sizeof(GymnetRolloutSpec);
             Native.Check(Native.gymnet_vecenv_rollout_fused_ex_device(_h, ref spec));
