@@ -701,18 +701,35 @@ class GpuEnv:
         self.ActionSpace, self.ObservationSpace = self._v.ActionSpace, self._v.ObservationSpace
         self.Metadata, self.RewardRange = self._v.Metadata, self._v.RewardRange
         self._pending = None
+        # The per-instance loop is latency-bound (README.md:32-52): long-lived buffers and their ctypes pointers, so a Step() is one
+        # ABI call plus a 4-element copy — no array allocation, no argument marshalling per call.
+        v = self._v
+        self._discrete = isinstance(self.ActionSpace, Discrete)
+        self._a = np.zeros(1, v._adtype)
+        self._o = np.empty((1, v.ObsDim), v._dtype)
+        self._r = np.empty(1, np.float32)
+        self._d = np.empty(1, np.uint8)
+        self._pa, self._po, self._pr, self._pd = (x.ctypes.data_as(C.c_void_p) for x in (self._a, self._o, self._r, self._d))
+        self._native_step, self._native_reset = v._lib.gymnet_vecenv_step, v._lib.gymnet_vecenv_reset
 
     def Reset(self):                                                                 # CartPoleEnv.cs:63-67
-        return self._v.Reset()[0]
+        st = self._native_reset(self._v._h, self._po)
+        if st:
+            capi.check(st)
+        return self._o[0].copy()                                                     # a COPY, like CartPoleEnv.cs:66
 
     def Step(self, action):                                                          # CartPoleEnv.cs:137-186
         if isinstance(action, enum.Enum):                                            # Env<TAction> where TAction : Enum (Env.cs:43-53)
             action = int(action.value)
-        if isinstance(action, (bool, np.bool_)) or not isinstance(action, (int, np.integer)):
-            if isinstance(self.ActionSpace, Discrete):
-                raise TypeError(f"Specified cast is not valid: {type(action).__name__} -> int")   # InvalidCastException, :138
-        a = np.array([action], dtype=self._v._adtype)
-        return self._v.Step(a)[0]
+        if self._discrete and (isinstance(action, (bool, np.bool_)) or not isinstance(action, (int, np.integer))):
+            raise TypeError(f"Specified cast is not valid: {type(action).__name__} -> int")   # InvalidCastException, :138
+        self._a[0] = action
+        st = self._native_step(self._v._h, self._pa, self._po, self._pr, self._pd)
+        if st:
+            capi.check(st)
+        d = int(self._d[0])
+        # upstream gym's TimeLimit convention for the max_episode_steps extension (done byte, bit 1; the reference has none)
+        return Step(self._o[0].copy(), float(self._r[0]), d != 0, {"TimeLimit.truncated": True} if d & 2 else None)
 
     def StepAsync(self, action):                                                     # Env.cs:23-25, 48-50
         if isinstance(action, enum.Enum):
