@@ -251,7 +251,7 @@ def allgather_model(world, bytes_per_rank):
     each peer over that peer's own link, all links concurrently) vs a ring (per-link bound, G - 1 hops)."""
     direct_us = bytes_per_rank / (XGMI_LINK_GBPS * 1e9) * 1e6
     return {"link_GBps": XGMI_LINK_GBPS, "bytes_per_rank": bytes_per_rank, "direct_us": direct_us, "ring_us": direct_us * max(0, world - 1),
-            "note": "analytic: 16 MiB per rank at 2^20 CartPole lanes -> ~110 us direct, ~770 us ring at 8 GPUs"}
+            "note": "analytic: 16 MiB per rank at 2^20 float32 CartPole lanes (32 MiB in float64) -> ~110 us direct, ~770 us ring at 8 GPUs (x2 in float64)"}
 
 
 def measure_traffic(args, wide16=True, timeout=90):
@@ -277,7 +277,7 @@ def measure_traffic(args, wide16=True, timeout=90):
         try:
             cmd = [exe, "--pmc", counter, "-d", out_dir, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--no-cpu-baseline", "--no-extras", "--no-traffic", "--no-graph", "--steps", "100", "--warmup", "10", "--min-seconds", "0",
-                   "--env", args.env, "--num-envs", str(args.num_envs), "--dtype", args.dtype]
+                   "--env", args.env, "--num-envs", str(args.num_envs), "--dtype", getattr(args, "dtype", "f32")]
             if args.policy:
                 cmd += ["--policy", args.policy]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
@@ -392,7 +392,8 @@ def group_leg(args, members):
             res[label] = {"skipped": "RCCL needs one device per member"}
             continue
         try:
-            with pkg.GroupVectorEnv(args.env, n * G, G, devices=devices, seed=0x5EED, auto_reset=True, gather=gather, overlap=overlap) as grp:
+            with pkg.GroupVectorEnv(args.env, n * G, G, devices=devices, seed=0x5EED, auto_reset=True, gather=gather, overlap=overlap,
+                                    dtype="float64" if args.dtype == "f64" else "float32") as grp:
                 for m, mem in enumerate(grp.Members):
                     for t in range(ring):
                         mem.SampleActionsDevice(acts[m][t].data_ptr(), seed=0x5EED + 1, tick=t)
@@ -428,7 +429,7 @@ def group_leg(args, members):
 def run_group_child(args, members, timeout=300):
     """Starts the gymnet_group_* leg as a fresh child process and returns its JSON (or an error record)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--group-child", str(members), "--env", args.env,
-           "--num-envs", str(args.num_envs), "--steps", str(args.steps)]
+           "--num-envs", str(args.num_envs), "--steps", str(args.steps), "--dtype", getattr(args, "dtype", "f32")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT",
                                                             "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     try:
@@ -499,24 +500,15 @@ def main():
     # the headline always steps IN PLACE (double-buffered observation arrays cost the step kernel ~0.8 us at this size,
     # profiles/double_buffer_probe_r02.txt); the overlapped-gather figure below builds its own double-buffered shard
     f64 = args.dtype == "f64"
-    if f64 and (world > 1 or args.env != "CartPole-v1"):
-        raise SystemExit("--dtype f64 is the single-GPU CartPole reference-arithmetic figure")
-    if f64:        # a plain handle (float64 handles keep their own state arrays: no shard / gather buffer)
-        local = pkg.VectorEnv(args.env, n, device=dev_index, seed=seed, auto_reset=True, stream=stream.cuda_stream, dtype="float64")
-
-        class _Plain:
-            def __init__(self, v):
-                self.local, self.obs_dim = v, v.ObsDim
-            ResetDevice = lambda self: self.local.ResetDevice()
-            StepDevice = lambda self, p: self.local.StepDevice(p)
-            Sync = lambda self: self.local.Sync()
-            Close = lambda self: self.local.Close()
-        env = _Plain(local)
-    else:
-        env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
-                                   auto_reset=True, gather_obs=use_dist, tensor_device=dev,
-                                   force_gather=args.force_dist, overlap=False)
-        local = env.local
+    if f64 and args.env != "CartPole-v1":
+        raise SystemExit("--dtype f64 is CartPole's reference-arithmetic mode (the one env whose float64 arithmetic the reference defines)")
+    esz = 8 if f64 else 4          # bytes per observation element
+    dt_name = "float64" if f64 else "float32"
+    # (since round 5 the float64 mode shards, gathers and groups like the float32 engine: the same ShardedVectorEnv, gather buffers of doubles)
+    env = pkg.ShardedVectorEnv(args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed,
+                               auto_reset=True, gather_obs=use_dist, tensor_device=dev,
+                               force_gather=args.force_dist, overlap=False, dtype=dt_name)
+    local = env.local
     if args.policy:
         local.SetLaunchPolicy(**parse_policy(args.policy))
     adtype = torch.float32 if local._adtype.__name__ == "float32" else torch.int32
@@ -942,7 +934,7 @@ def main():
                 genv = env if not own else pkg.ShardedVectorEnv(
                     args.env, n * world, rank=rank, world_size=world, device=dev_index, seed=seed, auto_reset=True,
                     gather_obs=True, tensor_device=dev, force_gather=args.force_dist, overlap=overlapped, gather=how,
-                    barrier=node_barrier)
+                    barrier=node_barrier, dtype=dt_name)
                 if own:
                     genv.ResetDevice()
 
@@ -965,8 +957,8 @@ def main():
                 if own and genv is not None:
                     genv.Sync()
                     genv.Close()
-        gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * 4
-        gathered["xgmi_model"] = allgather_model(world, env.obs_dim * n * 4)
+        gathered["allgather_bytes_per_rank_per_step"] = env.obs_dim * n * esz
+        gathered["xgmi_model"] = allgather_model(world, env.obs_dim * n * esz)
         watchdog.cancel()
 
     # Attainable copy bandwidth on THIS box (read + write bytes / time of a device-to-device float copy), reported
