@@ -221,16 +221,26 @@ void default_policy(gymnet_vecenv *h) {
         h->can_vec4 = false; h->can_vec2 = can2; h->lds_ok = false;
         // measured at 2^20 lanes (73 MiB per step; us per step, gpurun_out r4): every stream non-temporal 14.3, state cacheable 14.8,
         // nothing non-temporal 16.2, one lane per thread 15.6
-        h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, 0, 0};
+        // reset_form 1 (two lanes per reset in the wave-compacted form, step_kernels.hpp) for the one-shot kernel and the fused rollout:
+        // one-shot 13.7 -> 13.4 us at 2^20 lanes, bookkeeping rollout 7.5 -> 6.9 us per step, lean rollout 5.9 -> 6.0
+        // (profiles/rollout_reset_forms_r05.txt); the multi-pair kernel below always draws once per thread-group of pairs
+        h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, can2 ? 1 : 0, 0};
         if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
-        // The multi-item kernel (step_kernel_pipe2<CartPole64, k>: a thread owns k lane pairs, all loads first, then advance / store
-        // pair after pair) wins exactly where the one-shot kernel is ONE full lock-step generation of waves — 2^20 lanes = 2^19
-        // threads = 8 waves on every SIMD.  Round 4 (271 VALU per env-step): one-shot 14.4, 2 pairs 13.1-13.2, 4 pairs 14.4 us.  Round 5
-        // (178 VALU per env-step after the drain-loop reset of the common skeleton and the fma-pair constant division): one-shot
-        // 13.4-13.6, 2 pairs 13.1-13.4, 4 PAIRS 12.8-13.2 us (profiles/f64_forms_r05.txt) — fatter threads win now that each pair is
-        // cheaper.  Below (2^19: 8.9 vs 9.2 us) the launch is ramp-bound and fewer, fatter waves lose; above (2^21: 29.6 vs 29.7) the
-        // generations overlap by themselves.  Lean variant and whole 2 * k * 256-lane groups only (the launcher falls back otherwise).
-        if (can2 && h->n >= ((int64_t)3 << 18) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (h->n % 2048 == 0) ? 4 : 2;
+        // The multi-pair kernel (step_kernel_pipe2<CartPole64, k>: a thread owns k lane pairs, all loads first, then advance pair after
+        // pair, ONE wave-compacted reset for all of them, then the state rows) wins where it runs as two or three waves on every
+        // SIMD — 2048 or 3072 waves of 128 * k lanes.  us per step, one-shot | 2 pairs | 4 pairs (profiles/f64_sizes_r05.txt, one box):
+        //   2^19 lanes 6.27 | 6.42 | 7.57      3 * 2^18  10.94 | 8.46 | 10.19      2^20  13.13 | 12.17 | 11.19
+        //   5 * 2^18   16.64 | 16.82 | 17.40   6 * 2^18  21.17 | 19.78 | 19.58     2^21  27.72 | 28.56 | 29.64   (larger: one-shot)
+        // (round 4, 271 VALU per env-step, per-pair drain-loop reset: one-shot 14.4, 2 pairs 13.1, 4 pairs 14.4 at 2^20; round 5 before
+        // the deferred reset: 13.4-13.6 | 13.1-13.4 | 12.8-13.2.)  Lean variant and whole 2 * k * 256-lane groups only (the launcher
+        // falls back otherwise).  A wave count just under a whole number per SIMD is as good; one just above adds a tail.
+        if (can2 && h->n >= ((int64_t)3 << 18)) {            // (below: ramp-bound, fewer and fatter waves lose)
+            for (int items : {4, 2}) {
+                if (h->n % ((int64_t)512 * items) != 0) continue;
+                const double waves_per_simd = (double)(h->n / ((int64_t)128 * items)) / 1024.0;      // MI355X: 256 CUs x 4 SIMDs
+                if ((waves_per_simd >= 1.9 && waves_per_simd <= 2.02) || (waves_per_simd >= 2.85 && waves_per_simd <= 3.02)) { h->lcfg.items = items; break; }
+            }
+        }
         return;
     }
     // dwordx4 streams need 16-byte aligned component arrays; external buffers may not be

@@ -174,8 +174,15 @@ struct CartPole64 {
 
     // :63-67 — state = uniform(-0.05, 0.05, 4) in float64: low + (high - low) * u, u with 53 random bits
     __device__ __forceinline__ static void reset(double (&st)[S], uint64_t key, uint64_t lane, uint64_t tick) {
-        const PhiloxWords a = lane_words(key, lane, tick);                      // the words the float32 engine draws from, too
-        const PhiloxWords b = lane_words(key ^ kStreamReset64, lane, tick);
+        const PhiloxWords a = lane_words(reset_call_key(key, 0), lane, tick);   // the words the float32 engine draws from, too
+        const PhiloxWords b = lane_words(reset_call_key(key, 1), lane, tick);
+        reset_from_words(st, a, b);
+    }
+    // The same draw in its parts, for the kernels that spread ONE reset over two lanes (step_kernels.hpp, the wave-compacted resets:
+    // lane 2r makes call 0, lane 2r + 1 call 1, so a Philox pass of the wave serves 32 resets instead of costing two passes).
+    static constexpr int RESET_CALLS = 2;
+    __host__ __device__ __forceinline__ static uint64_t reset_call_key(uint64_t key, uint32_t call) { return call ? key ^ kStreamReset64 : key; }
+    __host__ __device__ __forceinline__ static void reset_from_words(double (&st)[S], const PhiloxWords &a, const PhiloxWords &b) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) st[k] = -0.05 + (0.05 - -0.05) * u01_53(a.w[k], b.w[k]);
     }

@@ -190,6 +190,20 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, typename Env::Re
 // lanes active, and returned to their owners through LDS as one 16-byte read per finished sub-lane.  The Philox counter is
 // the slot's global lane id, exactly as in reset_pending(), so the two forms draw the same bits.  LDS traffic of one wave is
 // in order, so the only synchronisation is compiler-level (wavefront-scope fences); no s_barrier.
+// Envs whose reset is TWO Philox calls (float64 CartPole: eight words for four 53-bit uniforms, cartpole64.hpp) spread one reset
+// over two lanes in the compacted forms: lane 2r makes call 0, lane 2r + 1 call 1, a DPP exchange joins the halves and the even
+// lane converts — a Philox pass of the wave then serves 32 resets instead of costing two passes for 64.
+template <class Env>
+constexpr bool has_split_reset() { return Env::RESET_TAKES_KEY && Env::OBS_ALIASES_STATE; }
+
+// the words of the odd neighbour (quad_perm [1, 0, 3, 2]): what lane 2r needs from lane 2r + 1
+__device__ __forceinline__ PhiloxWords neighbour_words(const PhiloxWords &w) {
+    PhiloxWords o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.w[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.w[k], 0xB1, 0xF, 0xF, true);
+    return o;
+}
+
 template <class Env>
 struct ResetScratch {
     uint32_t slot[64];              // rank -> owner lane * VEC + sub-lane
@@ -221,13 +235,42 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, typename En
     const int64_t wave_i0 = i0 - (int64_t)lane * VEC;          // first lane index of this wave
     // The drawing lanes are the wave's ACTIVE lanes.  In the batch's last (partial) wave the threads past the end have left the
     // kernel; the active ones are a prefix 0 .. A-1 (the lane index grows with the thread index), and a round serves A slots.
-    const uint32_t A = (uint32_t)__popcll(__ballot(1));
+    constexpr bool SPLIT = has_split_reset<Env>();             // two lanes per reset: a round serves A / 2 slots
+    const uint32_t active = (uint32_t)__popcll(__ballot(1));
+    const uint32_t A = SPLIT ? active >> 1 : active;
+    if constexpr (SPLIT) {
+        if (A == 0) {                                          // a last wave of ONE thread: it draws for itself
+            Real o_unused[Env::O][VEC];
+            reset_pending<Env, VEC, LANE_SEEDS>(pending, s, o_unused, a, i0, n, tick);
+            return;
+        }
+    }
     for (uint32_t base = 0; base < total; base += A) {         // wave-uniform; more finished slots than lanes in a wave: ~never
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
             if (((pending >> j) & 1u) && rank[j] - base < A) sc->slot[rank[j] - base] = lane * VEC + (uint32_t)j;
         wave_lds_fence();
-        if (lane < total - base) {                             // (an active lane by construction: lane < A whenever it has a slot)
+        if constexpr (SPLIT) {
+            const uint32_t r = lane >> 1, call = lane & 1u;
+            const bool draws = r < A && r < total - base;      // (lanes 2r and 2r + 1 are both active: 2r + 1 < 2A <= active)
+            PhiloxWords w{};
+            if (draws) {
+                const uint32_t sl = sc->slot[r];
+                const int64_t gl = wave_i0 + (int64_t)sl;
+                uint64_t key = a.seed;
+                if constexpr (LANE_SEEDS) {
+                    if (a.lane_seed && gl < n) key = a.lane_seed[gl];
+                }
+                w = lane_words(Env::reset_call_key(key, call), a.lane_offset + (uint64_t)gl, tick);
+            }
+            const PhiloxWords other = neighbour_words(w);
+            if (draws && call == 0) {
+                Real sj[S];
+                Env::reset_from_words(sj, w, other);
+#pragma unroll
+                for (int k = 0; k < S; ++k) sc->draw[r][k] = sj[k];
+            }
+        } else if (lane < total - base) {                      // (an active lane by construction: lane < A whenever it has a slot)
             const uint32_t sl = sc->slot[lane];
             const int64_t gl = wave_i0 + (int64_t)sl;
             uint64_t key = a.seed;
@@ -546,6 +589,81 @@ __global__ __launch_bounds__(256) void step_kernel_pipe(const StepArgsT<typename
 // 13.0), the wave-compacted reset per item (no better than the drain loop), and a reset deferred to ONE compacted pass per wave for
 // all of a thread's pairs with the drawing lanes storing the fresh states (correct, and 8 us slower: a state line written in two
 // pieces at two times costs far more than the Philox passes it saves).
+//
+// Round 5, second pass — the fused reset of this kernel, drawn ONCE per thread-group of pairs (envs whose reset is two Philox calls:
+// float64 CartPole).  tools/skeleton_floor.hip prices the kernel's parts on one box: data movement alone 11.7 us, with the physics
+// and a constant reset 12.1, with the real reset 14.0 — the time above the skeleton was the Philox passes, not the binary64
+// arithmetic.  The per-thread drain loop costs a wave ~1.9 trips per pair, two calls per trip, ~3 of 64 lanes active: 15 call-passes
+// per wave and launch, each 20 quarter-rate v_mad_u64_u32.  reset_group_deferred() ranks the finished sub-lanes of ALL the thread's
+// pairs (ballot + mbcnt), hands them to the wave's lanes through LDS TWO LANES PER RESET (lane 2r draws call 0, lane 2r + 1 call 1:
+// one call-pass serves 32 resets, and a wave of 512 lanes holds ~23), joins the two halves with one DPP exchange, converts on the
+// even lane and hands the states back BEFORE the pairs' state rows are stored — whole rows, written once (the earlier deferred form
+// that let the drawing lanes store the fresh states wrote rows in two pieces and lost 8 us).  Same counters, words and conversions:
+// bit-identical (tools/deferred_reset_probe.hip, tests).  14.5 -> 12.5 us on the probe's box (profiles/f64_deferred_reset_r05.txt).
+template <class Env>
+struct DeferScratch {
+    uint32_t slot[32];                        // rank -> owner lane * 8 + (pair * 2 + sub-lane)
+    typename Env::Real draw[32][Env::S];      // rank -> the drawn state
+};
+
+// pending: bit (pair * 2 + sub-lane) of this thread's 2 * PAIRS sub-lanes; s(pair) returns the pair's state registers
+template <class Env, int PAIRS, class StateOf>
+__device__ __forceinline__ void reset_group_deferred(uint32_t pending, StateOf s, const StepArgsT<typename Env::Real> &a, int64_t t_wave0,
+                                                     int64_t T, int first_pair, uint64_t tick, DeferScratch<Env> *sc) {
+    static_assert(Env::RESET_CALLS == 2 && 2 * PAIRS <= 8, "two lanes per reset; the slot word keeps 3 bits for the sub-lane position");
+    constexpr int Q = 2 * PAIRS, S = Env::S;
+    using Real = typename Env::Real;
+    const uint32_t lane = lane_id();
+    uint32_t rank[Q];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const uint64_t m = __ballot((pending >> q) & 1u);
+        rank[q] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        total += (uint32_t)__popcll(m);
+    }
+    for (uint32_t base = 0; base < total; base += 32) {            // wave-uniform; 32 resets per pass
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (((pending >> q) & 1u) && rank[q] - base < 32u) sc->slot[rank[q] - base] = lane * 8u + (uint32_t)q;
+        wave_lds_fence();
+        const uint32_t r = lane >> 1, call = lane & 1u;
+        const bool draws = r < total - base;
+        PhiloxWords w{};
+        if (draws) {
+            const uint32_t sl = sc->slot[r];
+            const uint32_t owner = sl >> 3, q = sl & 7u;
+            const int64_t gl = ((t_wave0 + owner) + (int64_t)(first_pair + (int)(q >> 1)) * T) * 2 + (q & 1u);
+            w = lane_words(Env::reset_call_key(a.seed, call), a.lane_offset + (uint64_t)gl, tick);
+        }
+        // the even lane takes its odd neighbour's words (call 1) and converts
+        const PhiloxWords other = neighbour_words(w);
+        if (draws && call == 0) {
+            Real sj[S];
+            Env::reset_from_words(sj, w, other);
+#pragma unroll
+            for (int k = 0; k < S; ++k) sc->draw[r][k] = sj[k];
+        }
+        wave_lds_fence();
+        // every lane reads a row for each of its sub-lane positions (clamped index: all reads in flight together, one wait)
+        Real got[Q][S];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t rr = rank[q] - base;
+#pragma unroll
+            for (int k = 0; k < S; ++k) got[q][k] = sc->draw[rr < 32u ? rr : 0u][k];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const bool mine = ((pending >> q) & 1u) && rank[q] - base < 32u;
+            Real (&sq)[S][2] = s(q / 2);
+#pragma unroll
+            for (int k = 0; k < S; ++k) sq[k][q % 2] = mine ? got[q][k] : sq[k][q % 2];
+        }
+        wave_lds_fence();
+    }
+}
+
 template <class Env, int ITEMS, bool AUTORESET, int NT>
 __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
     const uint64_t tick = a.tick2[a.parity];
@@ -555,6 +673,37 @@ __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typenam
     LaneInputs<Env, 2> in[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) load_inputs<Env, 2, AUTORESET, NT, false>(a, (t + k * T) * 2, in[k]);
+    if constexpr (AUTORESET && has_split_reset<Env>()) {
+        using Real = typename Env::Real;
+        constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
+        __shared__ DeferScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
+        DeferScratch<Env> *sc = &scratch[threadIdx.x >> 6];
+        uint32_t pending = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if (k == 0) {
+#pragma unroll
+                for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]), "+v"(in[0].s[c][1]));
+            }
+            const int64_t i0 = (t + k * T) * 2;
+            Real o[Env::O][2];
+            float rw[2];
+            bool dn[2], after[2] = {false, false};
+            advance_all<Env, 2, true, false, false>(in[k].s, in[k].act, in[k].sbd, rw, dn, after, o, i0, a.n);
+            const uint8_t db[2] = {(uint8_t)(dn[0] ? 1 : 0), (uint8_t)(dn[1] ? 1 : 0)};
+            store_f32<2, NT_O, false>(a.reward, i0, a.n, rw);           // reward / done do not wait for the reset draw
+            store_u8<2, NT_O, false>(a.done, i0, a.n, db);
+            pending |= ((dn[0] ? 1u : 0u) | (dn[1] ? 2u : 0u)) << (2 * k);
+        }
+        reset_group_deferred<Env, ITEMS>(pending, [&](int pair) -> Real (&)[Env::S][2] { return in[pair].s; }, a, t - (int64_t)lane_id(), T, 0, tick, sc);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+#pragma unroll
+            for (int row = 0; row < Env::S; ++row)
+                store_row<Real, 2, NT_SS, false>(a.state_out + row * a.state_stride, (t + k * T) * 2, a.n, in[k].s[row]);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         if (k == 0) {   // pair 0's inputs are needed now (their first uses must not be hoisted into the load block)
@@ -713,9 +862,10 @@ __device__ __forceinline__ typename Env::Action sampled_action(const PhiloxWords
 //   EXTRAS  bookkeeping handle (EPISODE_STATS / DONE_LIST / FINAL_OBS / per-lane seeds): running return / length in registers,
 //           truncation, dense last-finished-episode views, per-rollout compact episode records, the done list of the LAST step
 //   SAMPLE  the actions are drawn in the kernel (RolloutArgs::action_source 1 or 2) instead of read from the ring
-template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE>
+//   RESETF  1 = the wave-compacted reset (reset_pending_wave) per step instead of the per-thread drain loop
+template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE, int RESETF = 0>
 __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &ro,
-                                             const int64_t i0, const uint64_t tick0) {
+                                             const int64_t i0, const uint64_t tick0, ResetScratch<Env> *sc = nullptr) {
     constexpr int S = Env::S, O = Env::O;
     using Act = typename Env::Action;
     using Real = typename Env::Real;
@@ -877,7 +1027,8 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
                 else store_i32<VEC, true, GUARD>(static_cast<int32_t *>(ro.rec_action) + t * n, i0, n, act);
             }
         }
-        if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
+        if constexpr (AUTORESET && RESETF == 1) reset_pending_wave<Env, VEC, EXTRAS>(pending, s, a, i0, n, tick0 + (uint64_t)t, sc);
+        else if constexpr (AUTORESET) reset_pending<Env, VEC, EXTRAS>(pending, s, o, a, i0, n, tick0 + (uint64_t)t);
         if (ro.rec_obs) {
 #pragma unroll
             for (int k = 0; k < O; ++k) {
@@ -905,9 +1056,14 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     }
 }
 
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0>
 __global__ __launch_bounds__(256) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    ResetScratch<Env> *sc = nullptr;
+    if constexpr (RESETF == 1) {
+        __shared__ ResetScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
+        sc = &scratch[threadIdx.x >> 6];
+    }
     const uint64_t tick0 = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
     if constexpr (EXTRAS) {
@@ -915,10 +1071,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(const StepArgsT<typename E
             for (int sh = threadIdx.x; sh < kShards; sh += blockDim.x) a.done_count2[(a.cparity ^ 1) * (kShards * kCountStride) + sh * kCountStride] = 0u;
     }
     if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {     // full workgroup: no bounds checks inside the T-step loop
-        rollout_body<Env, VEC, AUTORESET, false, EXTRAS, SAMPLE>(a, ro, i0, tick0);
+        rollout_body<Env, VEC, AUTORESET, false, EXTRAS, SAMPLE, RESETF>(a, ro, i0, tick0, sc);
     } else {
         if (i0 >= a.n) return;
-        rollout_body<Env, VEC, AUTORESET, true, EXTRAS, SAMPLE>(a, ro, i0, tick0);
+        rollout_body<Env, VEC, AUTORESET, true, EXTRAS, SAMPLE, RESETF>(a, ro, i0, tick0, sc);
     }
 }
 
@@ -1210,15 +1366,24 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
     const bool sample = r.action_source != 0;
     const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
     const dim3 grid(grid_for(threads > 0 ? threads : 1, 256)), blk(256);
-#define GYMNET_ROLL(V, AR)                                                                                              \
-    do {                                                                                                                \
-        if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true>), grid, blk, 0, st, a, r);  \
-                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false>), grid, blk, 0, st, a, r); }      \
-        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true>), grid, blk, 0, st, a, r); \
-                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false>), grid, blk, 0, st, a, r); }     \
+#define GYMNET_ROLL(V, AR, RF)                                                                                               \
+    do {                                                                                                                    \
+        if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF>), grid, blk, 0, st, a, r);  \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF>), grid, blk, 0, st, a, r); }      \
+        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r); \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false, RF>), grid, blk, 0, st, a, r); }     \
     } while (0)
-    if (wide) { if (autoreset) GYMNET_ROLL(WIDE, true); else GYMNET_ROLL(WIDE, false); }
-    else      { if (autoreset) GYMNET_ROLL(1, true); else GYMNET_ROLL(1, false); }
+    if (wide) {
+        if (autoreset) {
+            // the wave-compacted reset per step (cfg.reset_form = 1; envs whose observation IS the state, wide lanes)
+            if constexpr (Env::OBS_ALIASES_STATE && !Env::PACKED2 && WIDE > 1) {
+                if (cfg.reset_form == 1) { GYMNET_ROLL(WIDE, true, 1); return hipGetLastError(); }
+            }
+            GYMNET_ROLL(WIDE, true, 0);
+        } else GYMNET_ROLL(WIDE, false, 0);
+    } else {
+        if (autoreset) GYMNET_ROLL(1, true, 0); else GYMNET_ROLL(1, false, 0);
+    }
 #undef GYMNET_ROLL
     return hipGetLastError();
 }

@@ -294,9 +294,16 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
     torch.cuda.synchronize()
     out = {}
     for auto in (True, False):
-        for items in (1, 2, 3, 4):
-            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, launch_policy={"sequential_lanes": items}) as env:
-                want = f"step_kernel<CartPole64,2,{str(auto).lower()},false,15,0>" if items == 1 else f"step_kernel_pipe2<CartPole64,{items},{str(auto).lower()},15>"
+        # items 1: the one-shot kernel with the per-thread drain-loop reset (the reference form of this comparison); items 0 stands
+        # for the one-shot kernel with the wave-compacted reset, two lanes per reset (reset_form 1, the default with auto-reset);
+        # the multi-pair kernels draw ONCE per thread-group of pairs (reset_group_deferred) — three reset forms, the same bits
+        for items in (1, 0, 2, 3, 4):
+            policy = {"sequential_lanes": max(items, 1)}
+            if items <= 1:
+                policy["reset_form"] = 1 - items
+            with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=auto, dtype=np.float64, launch_policy=policy) as env:
+                rf = 1 if (items == 0 and auto) else 0
+                want = f"step_kernel<CartPole64,2,{str(auto).lower()},false,15,{rf}>" if items <= 1 else f"step_kernel_pipe2<CartPole64,{items},{str(auto).lower()},15>"
                 assert env.KernelName() == want, env.KernelName()
                 env.ResetDevice()
                 env.RolloutDevice(acts, steps, n, ring)
@@ -305,22 +312,67 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
                 out[(auto, items)] = (env.GetState(), r.Reward, r.Done, env.GetStepsBeyondDone() if not auto else None, env.Counters()["stepped_after_done"])
         ref = out[(auto, 1)]
         assert ref[2].any()
-        for items in (2, 3, 4):
+        for items in (0, 2, 3, 4):
             got = out[(auto, items)]
             assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(ref[:3], got[:3])), (auto, items)
             assert (ref[3] is None or np.array_equal(ref[3], got[3])) and ref[4] == got[4]
     with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64) as env:
         with pytest.raises(ValueError, match="would not take effect"):
             env.SetLaunchPolicy(sequential_lanes=4)                                    # not whole 2 * 4 * 256-lane groups
-        assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,0>" and env.GetLaunchPolicy()["sequential_lanes"] == 1
+        assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,1>" and env.GetLaunchPolicy()["sequential_lanes"] == 1
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True) as env:
         with pytest.raises(ValueError, match="would not take effect"):
             env.SetLaunchPolicy(sequential_lanes=2)                                    # bookkeeping variant: one-shot kernel only
-        assert env.KernelName() == "step_kernel<CartPole64,2,true,true,15,0>"
+        assert env.KernelName() == "step_kernel<CartPole64,2,true,true,15,1>"
         with pytest.raises(ValueError):
             env.SetLaunchPolicy(sequential_lanes=5)
         env.SetLaunchPolicy(block=64)                                                  # honoured (the float64 launcher used to ignore it)
         assert env.GetLaunchPolicy()["block"] == 64
+
+
+@pytest.mark.parametrize("case", ["everyone_falls", "one_thread_tail", "odd_tail", "lane_seeds"])
+def test_f64_two_lanes_per_reset_edges(gpu_pkg, oracle, case):
+    """The float64 reset is two Philox calls; the compacted forms spread ONE reset over two lanes (lane 2r call 0, lane 2r + 1 call 1,
+    a DPP exchange joins them: reset_pending_wave, reset_group_deferred).  Edges of that scheme against the per-thread drain loop
+    (reset_form 0) and the twin's draws: every lane of every wave finishing in the same step (512 resets per wave of the four-pair
+    kernel: sixteen rounds of 32); a last wave of ONE active thread (no neighbour lane: it draws for itself) and of an odd number of
+    threads; per-lane seeds through the compacted form of the bookkeeping kernel."""
+    import torch
+    if case == "everyone_falls":
+        n, forms = 2 * 4 * 256 * 3, [{"sequential_lanes": 1, "reset_form": 0}, {"sequential_lanes": 1, "reset_form": 1}, {"sequential_lanes": 4},
+                                     {"sequential_lanes": 2}]
+    elif case == "one_thread_tail":
+        n, forms = 2 * (64 * 5 + 1), [{"reset_form": 0}, {"reset_form": 1}]
+    elif case == "odd_tail":
+        n, forms = 2 * (64 * 5 + 3) - 1, [{"reset_form": 0}, {"reset_form": 1}]
+    else:
+        n, forms = 2 * 64 * 7 + 10, [{"reset_form": 0}, {"reset_form": 1}]
+    kw = dict(episode_stats=True) if case == "lane_seeds" else {}
+    rng = np.random.default_rng(len(case))
+    acts = rng.integers(0, 2, (12, n)).astype(np.int32)
+    seeds = rng.integers(1, 2**62, n)
+    outs = []
+    for pol in forms:
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, launch_policy=pol, **kw) as env:
+            if case == "lane_seeds":
+                env.Seed(seeds)
+            env.Reset()
+            st = env.GetState()
+            if case != "lane_seeds":
+                st[0, :] = 2.39 + 0.02 * (np.arange(n) % 2 if case != "everyone_falls" else 1)    # past (or right at) the x threshold
+                env.SetState(st)
+            tick0 = env.Tick
+            got = [env.Step(acts[t]) for t in range(12)]
+            outs.append((env.GetState(), [g.Observation.copy() for g in got], [g.Done.copy() for g in got]))
+            if case == "everyone_falls":
+                assert got[0].Done.all()
+                # ... and what they were reset to is the twin's draw for (seed, lane, tick)
+                assert np.array_equal(got[0].Observation.T, oracle.cartpole_reset_f64(SEED, 0, tick0, n))
+            if case == "lane_seeds":
+                assert any(g.Done.any() for g in got)
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0])
+        assert all(np.array_equal(u, v) for u, v in zip(outs[0][1], o[1])) and all(np.array_equal(u, v) for u, v in zip(outs[0][2], o[2]))
 
 
 @pytest.mark.parametrize("auto", [True, False])

@@ -36,7 +36,7 @@ def test_f64_done_list_records_and_final_obs_equal_the_twin(gpu_pkg, oracle, n, 
     rng = np.random.default_rng(n)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, lane_offset=off, dtype=np.float64, done_list=True, episode_stats=True,
                            final_obs=True, max_episode_steps=limit, compact_records_only=compact_only, launch_policy={"vec": vec}) as env:
-        assert env.KernelName() == f"step_kernel<CartPole64,{vec},true,true,15,0>"
+        assert env.KernelName() == f"step_kernel<CartPole64,{vec},true,true,15,{1 if vec == 2 else 0}>"   # wide lanes: wave-compacted reset
         s = env.Reset().T.copy()
         assert np.array_equal(s, oracle.cartpole_reset_f64(SEED, off, 0, n))
         ln, ret = np.zeros(n, np.int32), np.zeros(n, np.float32)
@@ -87,13 +87,16 @@ def test_f64_double_buffer_wave_reset_and_launch_forms_are_bit_identical(gpu_pkg
     acts = torch.randint(0, 2, (ring, n), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     res = {}
-    forms = {"plain": {}, "vec1": {"launch_policy": {"vec": 1}}, "block64": {"launch_policy": {"block": 64, "nt": 12}},
-             "wave_reset": {"launch_policy": {"reset_form": 1}}, "db": {"double_buffer": True},
-             "db_graph": {"double_buffer": True, "launch_policy": {"graph": 1, "reset_form": 1}}}
+    # "plain" runs the default: two lanes per thread, wave-compacted reset with two lanes per reset (reset_form 1)
+    forms = {"plain": {}, "vec1": {"launch_policy": {"vec": 1}}, "block64": {"launch_policy": {"block": 64, "nt": 12, "reset_form": 0}},
+             "drain_reset": {"launch_policy": {"reset_form": 0}}, "db": {"double_buffer": True},
+             "db_graph": {"double_buffer": True, "launch_policy": {"graph": 1, "reset_form": 0}}}
     for name, kw in forms.items():
         with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, **kw) as env:
-            if name == "wave_reset":
+            if name == "plain":
                 assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,1>"
+            if name == "drain_reset":
+                assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,0>"
             if name == "block64":
                 assert env.GetLaunchPolicy()["block"] == 64 and env.KernelName() == "step_kernel<CartPole64,2,true,false,12,0>"
             env.ResetDevice()
@@ -125,7 +128,7 @@ def test_f64_external_observation_buffers(gpu_pkg, oracle, misalign):
     rng = np.random.default_rng(8)
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, ext_obs=ext.data_ptr(), ext_obs_stride=stride,
                            double_buffer=True, ext_obs_alt=ext2.data_ptr(), stream=torch.cuda.current_stream().cuda_stream) as env:
-        assert env.KernelName() == f"step_kernel<CartPole64,{1 if misalign else 2},true,false,15,0>"
+        assert env.KernelName() == f"step_kernel<CartPole64,{1 if misalign else 2},true,false,15,{0 if misalign else 1}>"
         if misalign:
             with pytest.raises(ValueError):
                 env.SetLaunchPolicy(vec=2)                      # 16-byte accesses on an 8-byte aligned row

@@ -1,0 +1,323 @@
+// tools/skeleton_floor.hip — what the data movement of each step kernel costs WITHOUT its arithmetic.
+//
+// The roofline fraction prices a launch against 8 TB/s.  This probe prices it against the kernel's own skeleton: the very same
+// templates of csrc/step_kernels.hpp (loads, stores, stream masks, launch shape, done bookkeeping, the fused-reset code path) are
+// instantiated with an env whose step() is one add per state word and whose done flag depends on the data but never fires, and
+// timed beside the real env — same buffers, same launch configuration, same process, alternating so box noise hits both.
+//   real - floor  = the part of a launch the arithmetic (and the resets that actually run) is NOT hidden under
+//   floor / ideal = what this access pattern loses to ramp, drain and DRAM / Infinity-Cache efficiency at 2^20 lanes
+// Not part of the product: built by tools/build_skeleton_floor.sh into tools/build/, run by tools/gpu_skeleton_floor_r05.sh.
+//
+//   usage: skeleton_floor [lanes = 1048576] [launches = 2000] [rounds = 5]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <string>
+
+#include "../gym.net_amd/csrc/step_kernels.hpp"
+#include "../gym.net_amd/csrc/envs.hpp"
+#include "../gym.net_amd/csrc/cartpole64.hpp"
+
+#define HIP_OK(x)                                                                                              \
+    do {                                                                                                       \
+        hipError_t e_ = (x);                                                                                   \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); std::exit(2); } \
+    } while (0)
+
+namespace gymnet {
+
+// Base's layout, action type, launch forms and reset — and no physics.
+template <class Base>
+struct DataOnly : Base {
+    using Real = typename Base::Real;
+    using Action = typename Base::Action;
+    static constexpr int S = Base::S, O = Base::O;
+    static constexpr bool HAS_SMALL_ANGLE_PATH = false;
+    static constexpr bool PACKED2 = false;
+    __device__ __forceinline__ static void step(Real (&s)[S], Action a, float &reward, bool &done) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = s[k] + (Real)a * (Real)1e-9f;
+        reward = 1.0f;
+        done = s[0] > (Real)1e30f;        // data-dependent, never true: the reset path stays compiled in and never runs
+    }
+    __device__ __forceinline__ static void observe(const Real (&s)[S], Real (&o)[O]) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) o[k] = s[k % S];
+    }
+    __device__ __forceinline__ static void observe_fresh(const Real (&s)[S], Real (&o)[O]) { observe(s, o); }
+    __device__ __forceinline__ static void step_observe(Real (&s)[S], Action a, float &reward, bool &done, Real (&o)[O]) {
+        step(s, a, reward, done);
+        observe(s, o);
+    }
+};
+
+// Base's physics, and a reset that draws nothing (every episode starts at the same state): what the Philox passes cost.
+template <class Base>
+struct CheapReset : Base {
+    using Real = typename Base::Real;
+    static constexpr int S = Base::S;
+    static constexpr bool RESET_TAKES_KEY = false;
+    __device__ __forceinline__ static void reset(Real (&s)[S], const PhiloxWords &) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = (Real)0.01f * (Real)(k + 1);
+    }
+};
+
+}  // namespace gymnet
+
+using namespace gymnet;
+
+// Probe form (NOT in the library): the multi-item kernel of step_kernel_pipe2 over items of VEC lanes — a thread owns ITEMS groups
+// of VEC consecutive lanes (group k at thread index + k * T), every load first, then advance / store group after group.
+template <class Env, int VEC, int ITEMS, int NT, int RESETF>
+__global__ __launch_bounds__(256) void probe_multi(const StepArgsT<typename Env::Real> a) {
+    ResetScratch<Env> *sc = nullptr;
+    if constexpr (RESETF == 1) {
+        __shared__ ResetScratch<Env> scratch[256 / 64];
+        sc = &scratch[threadIdx.x >> 6];
+    }
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneInputs<Env, VEC> in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) load_inputs<Env, VEC, true, NT, false>(a, (t + k * T) * VEC, in[k]);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (k == 0) {
+#pragma unroll
+            for (int c = 0; c < Env::S; ++c)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) asm volatile("" : "+v"(in[0].s[c][j]));
+        }
+        advance_and_store<Env, VEC, true, false, NT, false, RESETF, false>(a, (t + k * T) * VEC, tick, in[k], sc);
+    }
+}
+
+struct Buffers {
+    void *state = nullptr, *obs = nullptr, *action = nullptr;
+    float *reward = nullptr; uint8_t *done = nullptr; uint64_t *tick2 = nullptr;
+};
+
+template <class Env>
+static StepArgsT<typename Env::Real> make_args(const Buffers &b, int64_t n) {
+    using R = typename Env::Real;
+    StepArgsT<R> a{};
+    a.state = (R *)b.state; a.state_out = (R *)b.state;
+    a.obs = Env::OBS_ALIASES_STATE ? (R *)b.state : (R *)b.obs;
+    a.obs_in = a.obs;
+    a.action = b.action; a.reward = b.reward; a.done = b.done; a.tick2 = b.tick2;
+    a.n = n; a.state_stride = n; a.obs_stride = n; a.lane_offset = 0; a.seed = 0x5EED;
+    return a;
+}
+
+template <class Env>
+static double time_launches(const Buffers &b, int64_t n, LaunchCfg cfg, int launches, hipStream_t st, uint64_t &tick) {
+    auto a = make_args<Env>(b, n);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < launches; ++i) {
+        a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+        HIP_OK((launch_step_env<Env>(true, false, a, cfg, st)));
+        ++tick;
+    }
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+    return (double)ms * 1000.0 / launches;
+}
+
+template <class Env, int VEC, int ITEMS, int RESETF>
+static double time_multi(const Buffers &b, int64_t n, int block, int launches, hipStream_t st, uint64_t &tick) {
+    auto a = make_args<Env>(b, n);
+    const dim3 grid((unsigned)(n / ((int64_t)VEC * ITEMS * block))), blk(block);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < launches; ++i) {
+        a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+        hipLaunchKernelGGL((probe_multi<Env, VEC, ITEMS, 15, RESETF>), grid, blk, 0, st, a);
+        ++tick;
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+    return (double)ms * 1000.0 / launches;
+}
+
+static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+
+template <class Env>
+static void run_env(const char *label, int moved_bytes, LaunchCfg cfg, int64_t n, int launches, int rounds, hipStream_t st, bool first) {
+    using R = typename Env::Real;
+    using Floor = DataOnly<Env>;
+    Buffers b;
+    const size_t esz = sizeof(R);
+    HIP_OK(hipMalloc(&b.state, (size_t)Env::S * n * esz));
+    HIP_OK(hipMalloc(&b.obs, (size_t)Env::O * n * esz));
+    HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+    HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4));
+    HIP_OK(hipMalloc((void **)&b.done, (size_t)n));
+    HIP_OK(hipMalloc((void **)&b.tick2, 16));
+    HIP_OK(hipMemsetAsync(b.state, 0, (size_t)Env::S * n * esz, st));
+    HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)Env::O * n * esz, st));
+    // actions: int32 1 / float32 bits of a small positive number — any valid action; the real env resets by itself when it ends
+    std::vector<uint32_t> act((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (Env::BOX_ACTION) { float f = ((i * 2654435761u) & 1023) / 512.0f - 1.0f; std::memcpy(&act[i], &f, 4); }
+        else act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
+    }
+    HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
+    HIP_OK(hipStreamSynchronize(st));
+    uint64_t tick = 0;
+    char name[160];
+    describe_step_env<Env>(true, false, cfg, n, name, sizeof name);
+    // warm-up of both, then alternate
+    time_launches<Env>(b, n, cfg, 300, st, tick);
+    time_launches<Floor>(b, n, cfg, 300, st, tick);
+    std::vector<double> real, flo;
+    for (int r = 0; r < rounds; ++r) {
+        real.push_back(time_launches<Env>(b, n, cfg, launches, st, tick));
+        flo.push_back(time_launches<Floor>(b, n, cfg, launches, st, tick));
+    }
+    const double mr = median(real), mf = median(flo);
+    const double ideal = (double)moved_bytes * (double)n / 8.0e12 * 1e6;
+    std::printf("%s{\"env\": \"%s\", \"kernel\": \"%s\", \"lanes\": %lld, \"moved_bytes_per_lane\": %d, \"ideal_us_at_8TBps\": %.3f, "
+                "\"real_us\": %.3f, \"real_us_min\": %.3f, \"real_us_max\": %.3f, \"skeleton_us\": %.3f, \"skeleton_us_min\": %.3f, "
+                "\"skeleton_us_max\": %.3f, \"real_over_skeleton\": %.4f, \"skeleton_frac_of_8TBps\": %.4f, \"real_frac_of_8TBps\": %.4f}",
+                first ? "" : ",\n ", label, name, (long long)n, moved_bytes, ideal, mr, *std::min_element(real.begin(), real.end()),
+                *std::max_element(real.begin(), real.end()), mf, *std::min_element(flo.begin(), flo.end()),
+                *std::max_element(flo.begin(), flo.end()), mr / mf, ideal / mf, ideal / mr);
+    std::fflush(stdout);
+    HIP_OK(hipFree(b.state)); HIP_OK(hipFree(b.obs)); HIP_OK(hipFree(b.action)); HIP_OK(hipFree(b.reward)); HIP_OK(hipFree(b.done));
+    HIP_OK(hipFree(b.tick2));
+}
+
+// multi-item forms of the dwordx4 kernels, real env and skeleton, against the library's one-shot default (same buffers)
+template <class Env, int RESETF>
+static void run_forms(const char *label, LaunchCfg dflt, int64_t n, int launches, int rounds, hipStream_t st) {
+    using R = typename Env::Real;
+    using Floor = DataOnly<Env>;
+    Buffers b;
+    const size_t esz = sizeof(R);
+    HIP_OK(hipMalloc(&b.state, (size_t)Env::S * n * esz));
+    HIP_OK(hipMalloc(&b.obs, (size_t)Env::O * n * esz));
+    HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+    HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4));
+    HIP_OK(hipMalloc((void **)&b.done, (size_t)n));
+    HIP_OK(hipMalloc((void **)&b.tick2, 16));
+    HIP_OK(hipMemsetAsync(b.state, 0, (size_t)Env::S * n * esz, st));
+    HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)Env::O * n * esz, st));
+    std::vector<uint32_t> act((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (Env::BOX_ACTION) { float f = ((i * 2654435761u) & 1023) / 512.0f - 1.0f; std::memcpy(&act[i], &f, 4); }
+        else act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
+    }
+    HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
+    HIP_OK(hipStreamSynchronize(st));
+    uint64_t tick = 0;
+    struct Row { const char *name; std::vector<double> real, flo; };
+    std::vector<Row> rows;
+    constexpr int V = 4;
+#define FORM(NAME, REAL, FLOOR)                                                          \
+    {                                                                                    \
+        Row r{NAME, {}, {}};                                                             \
+        (void)(REAL); (void)(FLOOR);                                                     \
+        for (int q = 0; q < rounds; ++q) { r.real.push_back(REAL); r.flo.push_back(FLOOR); } \
+        rows.push_back(r);                                                               \
+    }
+    FORM("one-shot (library default)", (time_launches<Env>(b, n, dflt, launches, st, tick)), (time_launches<Floor>(b, n, dflt, launches, st, tick)))
+    FORM("1 quad, block 256 (probe kernel)", (time_multi<Env, V, 1, RESETF>(b, n, 256, launches, st, tick)), (time_multi<Floor, V, 1, RESETF>(b, n, 256, launches, st, tick)))
+    FORM("2 quads, block 256", (time_multi<Env, V, 2, RESETF>(b, n, 256, launches, st, tick)), (time_multi<Floor, V, 2, RESETF>(b, n, 256, launches, st, tick)))
+    FORM("2 quads, block 64", (time_multi<Env, V, 2, RESETF>(b, n, 64, launches, st, tick)), (time_multi<Floor, V, 2, RESETF>(b, n, 64, launches, st, tick)))
+    FORM("3 quads, block 256 (n / 3072 groups)", (time_multi<Env, V, 3, RESETF>(b, n - n % 3072, 256, launches, st, tick)), (time_multi<Floor, V, 3, RESETF>(b, n - n % 3072, 256, launches, st, tick)))
+    FORM("4 quads, block 256", (time_multi<Env, V, 4, RESETF>(b, n, 256, launches, st, tick)), (time_multi<Floor, V, 4, RESETF>(b, n, 256, launches, st, tick)))
+    FORM("4 quads, block 64", (time_multi<Env, V, 4, RESETF>(b, n, 64, launches, st, tick)), (time_multi<Floor, V, 4, RESETF>(b, n, 64, launches, st, tick)))
+    FORM("2 quads, block 256, drain-loop reset", (time_multi<Env, V, 2, 0>(b, n, 256, launches, st, tick)), (time_multi<Floor, V, 2, 0>(b, n, 256, launches, st, tick)))
+    FORM("4 quads, block 256, drain-loop reset", (time_multi<Env, V, 4, 0>(b, n, 256, launches, st, tick)), (time_multi<Floor, V, 4, 0>(b, n, 256, launches, st, tick)))
+#undef FORM
+    std::printf("== %s, %lld lanes: us per launch, median of %d x %d launches (real | skeleton)\n", label, (long long)n, rounds, launches);
+    for (auto &r : rows)
+        std::printf("   %-42s real %7.3f [%.3f, %.3f]   skeleton %7.3f [%.3f, %.3f]\n", r.name, median(r.real),
+                    *std::min_element(r.real.begin(), r.real.end()), *std::max_element(r.real.begin(), r.real.end()), median(r.flo),
+                    *std::min_element(r.flo.begin(), r.flo.end()), *std::max_element(r.flo.begin(), r.flo.end()));
+    std::fflush(stdout);
+    HIP_OK(hipFree(b.state)); HIP_OK(hipFree(b.obs)); HIP_OK(hipFree(b.action)); HIP_OK(hipFree(b.reward)); HIP_OK(hipFree(b.done));
+    HIP_OK(hipFree(b.tick2));
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? std::atoll(argv[1]) : (int64_t)1 << 20;
+    const int launches = argc > 2 ? std::atoi(argv[2]) : 2000;
+    const int rounds = argc > 3 ? std::atoi(argv[3]) : 5;
+    HIP_OK(hipSetDevice(0));
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+    if (argc > 4 && std::strcmp(argv[4], "parts") == 0) {
+        // float64 CartPole: where the time above the skeleton goes — physics + Philox (real), physics only (constant reset), nothing
+        Buffers b;
+        HIP_OK(hipMalloc(&b.state, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.obs, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+        HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4)); HIP_OK(hipMalloc((void **)&b.done, (size_t)n)); HIP_OK(hipMalloc((void **)&b.tick2, 16));
+        HIP_OK(hipMemsetAsync(b.state, 0, (size_t)4 * n * 8, st));
+        std::vector<uint32_t> act((size_t)n);
+        for (int64_t i = 0; i < n; ++i) act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
+        HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
+        HIP_OK(hipStreamSynchronize(st));
+        uint64_t tick = 0;
+        for (int items : {4, 2, 1}) {
+            const LaunchCfg cfg{2, 256, 15, 0, items, 0, 0};
+            std::vector<double> r, c, f;
+            time_launches<CartPole64>(b, n, cfg, 300, st, tick);
+            for (int q = 0; q < rounds; ++q) {
+                r.push_back(time_launches<CartPole64>(b, n, cfg, launches, st, tick));
+                c.push_back(time_launches<CheapReset<CartPole64>>(b, n, cfg, launches, st, tick));
+                f.push_back(time_launches<DataOnly<CartPole64>>(b, n, cfg, launches, st, tick));
+            }
+            std::printf("CartPole64, %d pair(s) per thread: real %.3f   physics with a constant reset %.3f   skeleton %.3f us\n", items, median(r), median(c), median(f));
+        }
+        {
+            HIP_OK(hipMemsetAsync(b.state, 0, (size_t)4 * n * 8, st));
+            const LaunchCfg cfg{4, 256, 15, 0, 1, 1, 0};
+            std::vector<double> r, c, f;
+            time_launches<CartPole>(b, n, cfg, 300, st, tick);
+            for (int q = 0; q < rounds; ++q) {
+                r.push_back(time_launches<CartPole>(b, n, cfg, launches, st, tick));
+                c.push_back(time_launches<CheapReset<CartPole>>(b, n, cfg, launches, st, tick));
+                f.push_back(time_launches<DataOnly<CartPole>>(b, n, cfg, launches, st, tick));
+            }
+            std::printf("CartPole (float32), one-shot: real %.3f   physics with a constant reset %.3f   skeleton %.3f us\n", median(r), median(c), median(f));
+        }
+        return 0;
+    }
+    if (argc > 4 && std::strcmp(argv[4], "forms") == 0) {
+        run_forms<CartPole, 1>("CartPole-v1", LaunchCfg{4, 256, 15, 0, 1, 1, 0}, n, launches, rounds, st);
+        run_forms<MountainCar, 1>("MountainCar-v0", LaunchCfg{4, 64, 15, 0, 1, 1, 0}, n, launches, rounds, st);
+        run_forms<Pendulum, 0>("Pendulum-v1", LaunchCfg{4, 64, 15, 0, 1, 0, 0}, n, launches, rounds, st);
+        return 0;
+    }
+    // launch configurations: the library's defaults at 2^20 lanes (capi.hip default_policy); bytes MOVED per lane and step as in
+    // profiles/roofline_r05.json (Pendulum keeps theta_dot in the observation array: 33, Acrobot 57)
+    std::printf("[");
+    run_env<CartPole>("CartPole-v1", 41, LaunchCfg{4, 256, 15, 0, 1, 1, 0}, n, launches, rounds, st, true);
+    run_env<CartPole64>("CartPole-v1-f64", 73, LaunchCfg{2, 256, 15, 0, 4, 0, 0}, n, launches, rounds, st, false);
+    run_env<CartPole64>("CartPole-v1-f64 (one-shot)", 73, LaunchCfg{2, 256, 15, 0, 1, 0, 0}, n, launches, rounds, st, false);
+    run_env<Pendulum>("Pendulum-v1", 33, LaunchCfg{4, 64, 15, 0, 1, 0, 0}, n, launches, rounds, st, false);
+    run_env<MountainCar>("MountainCar-v0", 25, LaunchCfg{4, 64, 15, 0, 1, 1, 0}, n, launches, rounds, st, false);
+    run_env<Acrobot>("Acrobot-v1", 57, LaunchCfg{1, 256, 15, 0, 4, 0, 0}, n, launches, rounds, st, false);
+    std::printf("]\n");
+    HIP_OK(hipStreamDestroy(st));
+    return 0;
+}
