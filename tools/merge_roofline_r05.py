@@ -14,6 +14,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P5 = os.path.join(ROOT, "gpurun_out", "p5")
 OUT = os.path.join(ROOT, "profiles")
+# A kernel that CHANGED during the round is reported from the boxes sampled after the change; the earlier boxes' rows of that
+# configuration are kept beside it as `superseded` (never merged into the median, never dropped).
+#   float64 CartPole: boxB..boxE ran the per-pair drain-loop reset (13.1 us); boxF.. run the deferred two-lanes-per-reset form.
+SUPERSEDED = {"CartPole-v1-f64": {"boxes": {"boxA", "boxB", "boxC", "boxD", "boxE"},
+                                  "what": "step_kernel_pipe2<CartPole64,4> with the per-pair drain-loop reset (before commit cb25336)"}}
 boxes = sys.argv[1:] or sorted(d for d in os.listdir(P5) if os.path.exists(os.path.join(P5, d, "summary", "roofline_box.json")))
 FIGS = [("rocprof_us", "rocprofv3 --kernel-trace --stats: average step-kernel duration (us), eager launches under the profiler"),
         ("frac_rocprof", "bytes moved / that / 8 TB/s"),
@@ -35,13 +40,23 @@ merged = {"peak_GBps": 8000.0, "lanes": 1 << 20, "boxes": boxes,
 first = data[boxes[0]]
 merged["bytes_moved"], merged["bytes_algorithmic"] = first["bytes_moved"], first["bytes_algorithmic"]
 for cfg in first["bytes_moved"]:
-    rows = {b: next((r for r in data[b]["rows"] if r["cfg"] == cfg), None) for b in boxes}
-    entry = {"kernel": next((r.get("kernel") for r in rows.values() if r and r.get("kernel")), None)}
-    for fig, _ in FIGS:
-        vals = {b: r[fig] for b, r in rows.items() if r and r.get(fig) is not None}
-        if vals:
-            xs = list(vals.values())
-            entry[fig] = {"median": st.median(xs), "min": min(xs), "max": max(xs), "per_box": vals}
+    all_rows = {b: next((r for r in data[b]["rows"] if r["cfg"] == cfg), None) for b in boxes}
+    old = SUPERSEDED.get(cfg, {}).get("boxes", set())
+    if not any(b not in old and all_rows[b] for b in boxes):
+        old = set()                     # nothing newer was sampled: the old rows are the current ones
+
+    def summarise(rows):
+        entry = {"kernel": next((r.get("kernel") for r in rows.values() if r and r.get("kernel")), None)}
+        for fig, _ in FIGS:
+            vals = {b: r[fig] for b, r in rows.items() if r and r.get(fig) is not None}
+            if vals:
+                xs = list(vals.values())
+                entry[fig] = {"median": st.median(xs), "min": min(xs), "max": max(xs), "per_box": vals}
+        return entry
+
+    entry = summarise({b: r for b, r in all_rows.items() if b not in old})
+    if old:
+        entry["superseded"] = dict(summarise({b: r for b, r in all_rows.items() if b in old}), what=SUPERSEDED[cfg]["what"])
     merged["configurations"][cfg] = entry
 os.makedirs(OUT, exist_ok=True)
 json.dump(merged, open(os.path.join(OUT, "roofline_r05.json"), "w"), indent=1)

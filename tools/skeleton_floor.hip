@@ -6,7 +6,7 @@
 // timed beside the real env — same buffers, same launch configuration, same process, alternating so box noise hits both.
 //   real - floor  = the part of a launch the arithmetic (and the resets that actually run) is NOT hidden under
 //   floor / ideal = what this access pattern loses to ramp, drain and DRAM / Infinity-Cache efficiency at 2^20 lanes
-// Not part of the product: built by tools/build_skeleton_floor.sh into tools/build/, run by tools/gpu_skeleton_floor_r05.sh.
+// Not part of the product: built by tools/build_probes.sh into tools/build/ (modes: default = every env, "parts", "forms").
 //
 //   usage: skeleton_floor [lanes = 1048576] [launches = 2000] [rounds = 5]
 #include <hip/hip_runtime.h>
@@ -98,10 +98,26 @@ __global__ __launch_bounds__(256) void probe_multi(const StepArgsT<typename Env:
     }
 }
 
+constexpr int64_t kRing = 32;        // action slices (iid per lane and slice: the bench's workload, ~4.5 % of CartPole lanes finish per step)
 struct Buffers {
     void *state = nullptr, *obs = nullptr, *action = nullptr;
     float *reward = nullptr; uint8_t *done = nullptr; uint64_t *tick2 = nullptr;
 };
+
+template <class Env>
+constexpr int32_t action_count() { if constexpr (Env::BOX_ACTION) return 0; else return Env::ACTION_N; }
+
+// kRing slices of n actions: iid uniform over the Discrete(count) values, or uniform in [-1, 1) for a Box action (splitmix-style hash)
+static std::vector<uint32_t> host_actions(int64_t n, bool box, int count) {
+    std::vector<uint32_t> act((size_t)kRing * n);
+    for (int64_t i = 0; i < kRing * n; ++i) {
+        uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x5EED;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        if (box) { const float f = (float)(z >> 40) / 8388608.0f - 1.0f; std::memcpy(&act[i], &f, 4); }
+        else act[i] = (uint32_t)((z >> 33) % (uint64_t)count);
+    }
+    return act;
+}
 
 template <class Env>
 static StepArgsT<typename Env::Real> make_args(const Buffers &b, int64_t n) {
@@ -123,6 +139,7 @@ static double time_launches(const Buffers &b, int64_t n, LaunchCfg cfg, int laun
     HIP_OK(hipEventRecord(e0, st));
     for (int i = 0; i < launches; ++i) {
         a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+        a.action = static_cast<const char *>(b.action) + (int64_t)(tick % kRing) * n * 4;
         HIP_OK((launch_step_env<Env>(true, false, a, cfg, st)));
         ++tick;
     }
@@ -143,6 +160,7 @@ static double time_multi(const Buffers &b, int64_t n, int block, int launches, h
     HIP_OK(hipEventRecord(e0, st));
     for (int i = 0; i < launches; ++i) {
         a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+        a.action = static_cast<const char *>(b.action) + (int64_t)(tick % kRing) * n * 4;
         hipLaunchKernelGGL((probe_multi<Env, VEC, ITEMS, 15, RESETF>), grid, blk, 0, st, a);
         ++tick;
     }
@@ -165,19 +183,14 @@ static void run_env(const char *label, int moved_bytes, LaunchCfg cfg, int64_t n
     const size_t esz = sizeof(R);
     HIP_OK(hipMalloc(&b.state, (size_t)Env::S * n * esz));
     HIP_OK(hipMalloc(&b.obs, (size_t)Env::O * n * esz));
-    HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+    HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
     HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4));
     HIP_OK(hipMalloc((void **)&b.done, (size_t)n));
     HIP_OK(hipMalloc((void **)&b.tick2, 16));
     HIP_OK(hipMemsetAsync(b.state, 0, (size_t)Env::S * n * esz, st));
     HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)Env::O * n * esz, st));
-    // actions: int32 1 / float32 bits of a small positive number — any valid action; the real env resets by itself when it ends
-    std::vector<uint32_t> act((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (Env::BOX_ACTION) { float f = ((i * 2654435761u) & 1023) / 512.0f - 1.0f; std::memcpy(&act[i], &f, 4); }
-        else act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
-    }
-    HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> act = host_actions(n, Env::BOX_ACTION, Env::BOX_ACTION ? 0 : (int)action_count<Env>());
+    HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
     HIP_OK(hipStreamSynchronize(st));
     uint64_t tick = 0;
@@ -213,18 +226,14 @@ static void run_forms(const char *label, LaunchCfg dflt, int64_t n, int launches
     const size_t esz = sizeof(R);
     HIP_OK(hipMalloc(&b.state, (size_t)Env::S * n * esz));
     HIP_OK(hipMalloc(&b.obs, (size_t)Env::O * n * esz));
-    HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+    HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
     HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4));
     HIP_OK(hipMalloc((void **)&b.done, (size_t)n));
     HIP_OK(hipMalloc((void **)&b.tick2, 16));
     HIP_OK(hipMemsetAsync(b.state, 0, (size_t)Env::S * n * esz, st));
     HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)Env::O * n * esz, st));
-    std::vector<uint32_t> act((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (Env::BOX_ACTION) { float f = ((i * 2654435761u) & 1023) / 512.0f - 1.0f; std::memcpy(&act[i], &f, 4); }
-        else act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
-    }
-    HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> act = host_actions(n, Env::BOX_ACTION, Env::BOX_ACTION ? 0 : (int)action_count<Env>());
+    HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
     HIP_OK(hipStreamSynchronize(st));
     uint64_t tick = 0;
@@ -268,17 +277,16 @@ int main(int argc, char **argv) {
     if (argc > 4 && std::strcmp(argv[4], "parts") == 0) {
         // float64 CartPole: where the time above the skeleton goes — physics + Philox (real), physics only (constant reset), nothing
         Buffers b;
-        HIP_OK(hipMalloc(&b.state, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.obs, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.action, (size_t)n * 4));
+        HIP_OK(hipMalloc(&b.state, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.obs, (size_t)4 * n * 8)); HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
         HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4)); HIP_OK(hipMalloc((void **)&b.done, (size_t)n)); HIP_OK(hipMalloc((void **)&b.tick2, 16));
         HIP_OK(hipMemsetAsync(b.state, 0, (size_t)4 * n * 8, st));
-        std::vector<uint32_t> act((size_t)n);
-        for (int64_t i = 0; i < n; ++i) act[i] = (uint32_t)((i * 2654435761u >> 7) % 2);
-        HIP_OK(hipMemcpyAsync(b.action, act.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        std::vector<uint32_t> act = host_actions(n, false, 2);
+        HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
         HIP_OK(hipStreamSynchronize(st));
         uint64_t tick = 0;
         for (int items : {4, 2, 1}) {
-            const LaunchCfg cfg{2, 256, 15, 0, items, 0, 0};
+            const LaunchCfg cfg{2, 256, 15, 0, items, items == 1 ? 1 : 0, 0};
             std::vector<double> r, c, f;
             time_launches<CartPole64>(b, n, cfg, 300, st, tick);
             for (int q = 0; q < rounds; ++q) {
@@ -313,7 +321,7 @@ int main(int argc, char **argv) {
     std::printf("[");
     run_env<CartPole>("CartPole-v1", 41, LaunchCfg{4, 256, 15, 0, 1, 1, 0}, n, launches, rounds, st, true);
     run_env<CartPole64>("CartPole-v1-f64", 73, LaunchCfg{2, 256, 15, 0, 4, 0, 0}, n, launches, rounds, st, false);
-    run_env<CartPole64>("CartPole-v1-f64 (one-shot)", 73, LaunchCfg{2, 256, 15, 0, 1, 0, 0}, n, launches, rounds, st, false);
+    run_env<CartPole64>("CartPole-v1-f64 (one-shot)", 73, LaunchCfg{2, 256, 15, 0, 1, 1, 0}, n, launches, rounds, st, false);
     run_env<Pendulum>("Pendulum-v1", 33, LaunchCfg{4, 64, 15, 0, 1, 0, 0}, n, launches, rounds, st, false);
     run_env<MountainCar>("MountainCar-v0", 25, LaunchCfg{4, 64, 15, 0, 1, 1, 0}, n, launches, rounds, st, false);
     run_env<Acrobot>("Acrobot-v1", 57, LaunchCfg{1, 256, 15, 0, 4, 0, 0}, n, launches, rounds, st, false);
