@@ -314,6 +314,7 @@ int main(int argc, char **argv) {
         run_forms<CartPole, 1>("CartPole-v1", LaunchCfg{4, 256, 15, 0, 1, 1, 0}, n, launches, rounds, st);
         run_forms<MountainCar, 1>("MountainCar-v0", LaunchCfg{4, 64, 15, 0, 1, 1, 0}, n, launches, rounds, st);
         run_forms<Pendulum, 0>("Pendulum-v1", LaunchCfg{4, 64, 15, 0, 1, 0, 0}, n, launches, rounds, st);
+        if (argc > 5) run_forms<Acrobot, 0>("Acrobot-v1 (16-byte lanes: not a library form)", LaunchCfg{1, 256, 15, 0, 4, 0, 0}, n, launches, rounds, st);
         return 0;
     }
     // launch configurations: the library's defaults at 2^20 lanes (capi.hip default_policy); bytes MOVED per lane and step as in
