@@ -232,13 +232,15 @@ void default_policy(gymnet_vecenv *h) {
         //   2^19 lanes 6.27 | 6.42 | 7.57      3 * 2^18  10.94 | 8.46 | 10.19      2^20  13.13 | 12.17 | 11.19
         //   5 * 2^18   16.64 | 16.82 | 17.40   6 * 2^18  21.17 | 19.78 | 19.58     2^21  27.72 | 28.56 | 29.64   (larger: one-shot)
         // (round 4, 271 VALU per env-step, per-pair drain-loop reset: one-shot 14.4, 2 pairs 13.1, 4 pairs 14.4 at 2^20; round 5 before
-        // the deferred reset: 13.4-13.6 | 13.1-13.4 | 12.8-13.2.)  Lean variant and whole 2 * k * 256-lane groups only (the launcher
-        // falls back otherwise).  A wave count just under a whole number per SIMD is as good; one just above adds a tail.
+        // the deferred reset: 13.4-13.6 | 13.1-13.4 | 12.8-13.2.)  Lean variant only; without auto-reset whole 2 * k * 256-lane groups
+        // only (the launcher falls back otherwise).  A wave count just under a whole number per SIMD is as good (10^6 lanes: 11.7 us against 13.0).
         if (can2 && h->n >= ((int64_t)3 << 18)) {            // (below: ramp-bound, fewer and fatter waves lose)
             for (int items : {4, 2}) {
-                if (h->n % ((int64_t)512 * items) != 0) continue;
-                const double waves_per_simd = (double)(h->n / ((int64_t)128 * items)) / 1024.0;      // MI355X: 256 CUs x 4 SIMDs
-                if ((waves_per_simd >= 1.9 && waves_per_simd <= 2.02) || (waves_per_simd >= 2.85 && waves_per_simd <= 3.02)) { h->lcfg.items = items; break; }
+                if (!h->autoreset && h->n % ((int64_t)512 * items) != 0) continue;     // (the auto-reset form takes any batch size)
+                const double waves_per_simd = (double)((h->n + 128 * items - 1) / ((int64_t)128 * items)) / 1024.0;      // MI355X: 256 CUs x 4 SIMDs
+                // NOT one wave more: the kernel holds 191 VGPRs, two waves per SIMD are resident, and a 2049th wave starts when an
+                // earlier one has finished — 2^20 + 2 lanes: 19.2 us against 11.1 (profiles/f64_sizes_r05.txt, second table)
+                if ((waves_per_simd >= 1.9 && waves_per_simd <= 2.0) || (waves_per_simd >= 2.85 && waves_per_simd <= 3.0)) { h->lcfg.items = items; break; }
             }
         }
         return;

@@ -386,6 +386,25 @@ __device__ __forceinline__ void load_inputs(const StepArgsT<typename Env::Real> 
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, in.sbd);
 }
 
+// The inputs of the batch's ragged end for the multi-item kernels: UNCONDITIONAL element loads, a lane past the end re-reads the
+// last valid lane (only its stores are suppressed).  The bounds-checked load_row<GUARD> branches per access, and a branch around
+// a load makes the compiler wait for it at the join: a thread's twenty loads then cost twenty memory latencies in a row (measured:
+// 2^20 + 2 float64 lanes 19.6 us per step with branching loads in the last workgroups against 11.1 for the whole batch).
+template <class Env, int VEC, int NT>
+__device__ __forceinline__ void load_inputs_clamped(const StepArgsT<typename Env::Real> &a, const int64_t i0, LaneInputs<Env, VEC> &in) {
+    constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
+    auto ld = [](const auto *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; };
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int64_t i = i0 + j < a.n ? i0 + j : a.n - 1;
+#pragma unroll
+        for (int k = 0; k < Env::S; ++k) in.s[k][j] = ld(state_row_src<Env>(a.state, a.state_stride, a.obs_in, a.obs_stride, k) + i, NT_SL);
+        if constexpr (Env::BOX_ACTION) in.act[j] = ld(static_cast<const float *>(a.action) + i, NT_A);
+        else in.act[j] = ld(static_cast<const int32_t *>(a.action) + i, NT_A);
+        in.sbd[j] = 0;
+    }
+}
+
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD, int RESETF = 0, bool PACK = true>
 __device__ __forceinline__ void advance_and_store(const StepArgsT<typename Env::Real> &a, const int64_t i0, const uint64_t tick,
                                                   LaneInputs<Env, VEC> &in, ResetScratch<Env> *sc = nullptr) {
@@ -664,46 +683,64 @@ __device__ __forceinline__ void reset_group_deferred(uint32_t pending, StateOf s
     }
 }
 
+// the thread's ITEMS pairs with ONE deferred reset: all loads | advance pair after pair (reward / done leave at once) | one
+// wave-compacted draw for all of them | the state rows.  GUARD: the batch's ragged end (a lane past the end re-reads the last valid
+// lane, is advanced like any other, never pends a reset and stores nothing) — only the batch's last workgroups run it.
+template <class Env, int ITEMS, int NT, bool GUARD>
+__device__ __forceinline__ void pipe2_split_body(const StepArgsT<typename Env::Real> &a, int64_t t, int64_t T, uint64_t tick, DeferScratch<Env> *sc) {
+    using Real = typename Env::Real;
+    constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
+    LaneInputs<Env, 2> in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if constexpr (GUARD) load_inputs_clamped<Env, 2, NT>(a, (t + k * T) * 2, in[k]);
+        else load_inputs<Env, 2, true, NT, false>(a, (t + k * T) * 2, in[k]);
+    }
+    uint32_t pending = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (k == 0) {   // pair 0's inputs are needed now (their first uses must not be hoisted into the load block)
+#pragma unroll
+            for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]), "+v"(in[0].s[c][1]));
+        }
+        const int64_t i0 = (t + k * T) * 2;
+        Real o[Env::O][2];
+        float rw[2];
+        bool dn[2], after[2] = {false, false};
+        advance_all<Env, 2, true, GUARD, false>(in[k].s, in[k].act, in[k].sbd, rw, dn, after, o, i0, a.n);
+        const uint8_t db[2] = {(uint8_t)(dn[0] ? 1 : 0), (uint8_t)(dn[1] ? 1 : 0)};
+        store_f32<2, NT_O, GUARD>(a.reward, i0, a.n, rw);           // reward / done do not wait for the reset draw
+        store_u8<2, NT_O, GUARD>(a.done, i0, a.n, db);
+        const bool p0 = dn[0] && (!GUARD || i0 < a.n), p1 = dn[1] && (!GUARD || i0 + 1 < a.n);
+        pending |= ((p0 ? 1u : 0u) | (p1 ? 2u : 0u)) << (2 * k);
+    }
+    reset_group_deferred<Env, ITEMS>(pending, [&](int pair) -> Real (&)[Env::S][2] { return in[pair].s; }, a, t - (int64_t)lane_id(), T, 0, tick, sc);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+#pragma unroll
+        for (int row = 0; row < Env::S; ++row)
+            store_row<Real, 2, NT_SS, GUARD>(a.state_out + row * a.state_stride, (t + k * T) * 2, a.n, in[k].s[row]);
+    }
+}
+
 template <class Env, int ITEMS, bool AUTORESET, int NT>
 __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
     const uint64_t tick = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (AUTORESET && has_split_reset<Env>()) {
+        __shared__ DeferScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
+        DeferScratch<Env> *sc = &scratch[threadIdx.x >> 6];
+        // ANY batch size: the grid is ceil(n / (2 * ITEMS * block)) workgroups; a workgroup whose last pair of its last item lies
+        // inside the batch runs the unguarded body (workgroup-uniform), the batch's last few run the guarded one
+        if ((((int64_t)blockIdx.x + 1) * blockDim.x + (int64_t)(ITEMS - 1) * T) * 2 <= a.n) pipe2_split_body<Env, ITEMS, NT, false>(a, t, T, tick, sc);
+        else pipe2_split_body<Env, ITEMS, NT, true>(a, t, T, tick, sc);
+        return;
+    }
     LaneInputs<Env, 2> in[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) load_inputs<Env, 2, AUTORESET, NT, false>(a, (t + k * T) * 2, in[k]);
-    if constexpr (AUTORESET && has_split_reset<Env>()) {
-        using Real = typename Env::Real;
-        constexpr bool NT_SS = (NT & 2) != 0, NT_O = (NT & 8) != 0;
-        __shared__ DeferScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
-        DeferScratch<Env> *sc = &scratch[threadIdx.x >> 6];
-        uint32_t pending = 0;
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            if (k == 0) {
-#pragma unroll
-                for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]), "+v"(in[0].s[c][1]));
-            }
-            const int64_t i0 = (t + k * T) * 2;
-            Real o[Env::O][2];
-            float rw[2];
-            bool dn[2], after[2] = {false, false};
-            advance_all<Env, 2, true, false, false>(in[k].s, in[k].act, in[k].sbd, rw, dn, after, o, i0, a.n);
-            const uint8_t db[2] = {(uint8_t)(dn[0] ? 1 : 0), (uint8_t)(dn[1] ? 1 : 0)};
-            store_f32<2, NT_O, false>(a.reward, i0, a.n, rw);           // reward / done do not wait for the reset draw
-            store_u8<2, NT_O, false>(a.done, i0, a.n, db);
-            pending |= ((dn[0] ? 1u : 0u) | (dn[1] ? 2u : 0u)) << (2 * k);
-        }
-        reset_group_deferred<Env, ITEMS>(pending, [&](int pair) -> Real (&)[Env::S][2] { return in[pair].s; }, a, t - (int64_t)lane_id(), T, 0, tick, sc);
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-#pragma unroll
-            for (int row = 0; row < Env::S; ++row)
-                store_row<Real, 2, NT_SS, false>(a.state_out + row * a.state_stride, (t + k * T) * 2, a.n, in[k].s[row]);
-        }
-        return;
-    }
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         if (k == 0) {   // pair 0's inputs are needed now (their first uses must not be hoisted into the load block)
@@ -1240,7 +1277,9 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
     }
     if constexpr (Env::PIPE_PAIRS) {
         // lane pairs: 2..4 pairs per thread, whole batches only — otherwise the ordinary forms below
-        if (cfg.items > 1 && cfg.items <= 4 && !extras && cfg.vec == 2 && !cfg.lds_pipe && n > 0 && n % (2 * (int64_t)cfg.items * 256) == 0) {
+        // (the form with the deferred reset — envs whose reset is two Philox calls, auto-reset — takes any batch size)
+        const bool any_n = has_split_reset<Env>() && autoreset;
+        if (cfg.items > 1 && cfg.items <= 4 && !extras && cfg.vec == 2 && !cfg.lds_pipe && n > 0 && (any_n || n % (2 * (int64_t)cfg.items * 256) == 0)) {
             v.nt = 15; v.vec = 2; v.pipe_items = cfg.items; v.pipe_pairs = true;
             return v;
         }
@@ -1286,8 +1325,10 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
     const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg, a.n);
     if constexpr (Env::PIPE_PAIRS) {
         if (v.pipe_pairs) {
-            // whole groups of 2 * items * 256 lanes (resolve_variant), so any of the workgroup sizes divides the batch
-            const dim3 qgrid((unsigned)(a.n / (2 * (int64_t)v.pipe_items * cfg.block))), qblk(cfg.block);
+            // whole groups of 2 * items * 256 lanes (resolve_variant: any workgroup size divides the batch) — or, for the form with
+            // the deferred reset, any batch: the last workgroups run the guarded body
+            const int64_t per_block = 2 * (int64_t)v.pipe_items * cfg.block;
+            const dim3 qgrid((unsigned)((a.n + per_block - 1) / per_block)), qblk(cfg.block);
 #define GYMNET_PIPE2(I)                                                                                                 \
     case I:                                                                                                             \
         if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a);                 \

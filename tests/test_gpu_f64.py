@@ -316,10 +316,13 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
             got = out[(auto, items)]
             assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(ref[:3], got[:3])), (auto, items)
             assert (ref[3] is None or np.array_equal(ref[3], got[3])) and ref[4] == got[4]
-    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64) as env:
+    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=False, dtype=np.float64) as env:
         with pytest.raises(ValueError, match="would not take effect"):
             env.SetLaunchPolicy(sequential_lanes=4)                                    # not whole 2 * 4 * 256-lane groups
-        assert env.KernelName() == "step_kernel<CartPole64,2,true,false,15,1>" and env.GetLaunchPolicy()["sequential_lanes"] == 1
+        assert env.KernelName() == "step_kernel<CartPole64,2,false,false,15,0>" and env.GetLaunchPolicy()["sequential_lanes"] == 1
+    with gpu_pkg.VectorEnv("CartPole-v1", n + 2, seed=SEED, auto_reset=True, dtype=np.float64) as env:
+        env.SetLaunchPolicy(sequential_lanes=4)                                        # the auto-reset form takes any batch size
+        assert env.KernelName() == "step_kernel_pipe2<CartPole64,4,true,15>"
     with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, episode_stats=True) as env:
         with pytest.raises(ValueError, match="would not take effect"):
             env.SetLaunchPolicy(sequential_lanes=2)                                    # bookkeeping variant: one-shot kernel only
@@ -328,6 +331,39 @@ def test_f64_multi_item_kernel_forms_are_bit_identical(gpu_pkg):
             env.SetLaunchPolicy(sequential_lanes=5)
         env.SetLaunchPolicy(block=64)                                                  # honoured (the float64 launcher used to ignore it)
         assert env.GetLaunchPolicy()["block"] == 64
+
+
+@pytest.mark.parametrize("n", [2 * 4 * 256 * 3 + 1, 2 * 4 * 256 * 2 + 2 * 4 * 64 - 3, 1000, 7, 2 * 4 * 256 * 4 - 2])
+def test_f64_multi_pair_kernel_takes_any_batch_size(gpu_pkg, oracle, n):
+    """step_kernel_pipe2<CartPole64, k, auto-reset> on batches that are not whole 2 * k * block-lane groups: the last workgroups run
+    the guarded body (lanes past the end load zeros, never pend a reset, store nothing).  Against the one-shot kernel with the
+    drain-loop reset, bit for bit, over enough steps that every lane is reset; and the memory after the batch stays untouched."""
+    import torch
+    rng = np.random.default_rng(n)
+    acts = rng.integers(0, 2, (40, n)).astype(np.int32)
+    outs = []
+    for pol in ({"sequential_lanes": 1, "reset_form": 0}, {"sequential_lanes": 4}, {"sequential_lanes": 2, "block": 64}, {"sequential_lanes": 3, "block": 128}):
+        stride = (n + 65) // 2 * 2                     # even: two doubles per thread need 16-byte aligned rows
+        buf = torch.full((4 * stride + 8,), 777.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, ext_obs=buf.data_ptr(), ext_obs_stride=stride,
+                               launch_policy=pol) as env:
+            if pol["sequential_lanes"] > 1:
+                assert env.KernelName() == f"step_kernel_pipe2<CartPole64,{pol['sequential_lanes']},true,15>"
+            env.Reset()
+            env.Sync()
+            pad0 = buf[:4 * stride].view(4, stride)[:, n:].cpu().numpy().copy()      # (create / reset may initialise the rows' padding)
+            got = [env.Step(acts[t]) for t in range(40)]
+            outs.append((env.GetState(), [g.Observation.copy() for g in got], [g.Done.copy() for g in got], [g.Reward.copy() for g in got]))
+            env.Sync()
+            pad = buf[:4 * stride].view(4, stride)[:, n:].cpu().numpy()
+            # the step kernels write nothing past the batch: the rows' padding is what it was, the words after the buffer untouched
+            assert np.array_equal(pad, pad0) and (buf[4 * stride:].cpu().numpy() == 777.0).all()
+    assert sum(int(d.sum()) for d in outs[0][2]) > n
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0])
+        for k in (1, 2, 3):
+            assert all(np.array_equal(u, v) for u, v in zip(outs[0][k], o[k]))
 
 
 @pytest.mark.parametrize("case", ["everyone_falls", "one_thread_tail", "odd_tail", "lane_seeds"])
