@@ -250,7 +250,7 @@ void default_policy(gymnet_vecenv *h) {
                           (!h->d_obs_alt || aligned16(h->d_obs_alt));
     // Launch policy, measured on MI355X with tools/probe_step.hip and bench.py (profiles/probe_r01.txt),
     // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
-    //  - <= 24 MiB (2^19 CartPole lanes): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
+    //  - <= 2^19 lanes (round 1-4: "<= 24 MiB per vector step"): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
     //  - <= 48 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
     //  - <= 768 MiB (state fits the 256 MiB Infinity Cache): dwordx4, state cacheable, action / reward / done streamed
     //    past it, so the next launch re-reads the state from the cache;
@@ -258,7 +258,13 @@ void default_policy(gymnet_vecenv *h) {
     //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
     const size_t step_bytes = (size_t)h->n * (size_t)d.algorithmic_bytes;
     const bool alu_bound = cfg->env_id == GYMNET_ENV_ACROBOT;
-    if (alu_bound || step_bytes <= ((size_t)24 << 20)) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    // Round 5: the small-batch rule is a LANE count, not a byte count.  Scalar lanes win while the launch is ONE resident generation
+    // of waves — n <= 8 waves x 1024 SIMDs x 64 lanes = 2^19 — and lose beyond it (a second generation of 64-lane waves starts when the
+    // first retires); the byte threshold had been fitted on CartPole alone (2^19 lanes = 21.5 MB) and kept MountainCar (25 B per lane)
+    // on scalar lanes up to 10^6 lanes: 5.53 us against 4.53 with 16-byte lanes; 3 * 2^18 lanes 4.35 against 3.93
+    // (profiles/small_batches_r05.txt; CartPole and Pendulum cross over at the same lane count).
+    const bool one_generation = h->n <= ((int64_t)8 * 1024 * 64);
+    if (alu_bound || one_generation) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
     else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
     else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
     else { h->lcfg.vec = 1; h->lcfg.nt = 15; }
@@ -273,7 +279,9 @@ void default_policy(gymnet_vecenv *h) {
     // stores drain under the next lane's arithmetic.  Measured (profiles/acrobot_probes_r02.txt, us per 2^20 lanes, one-shot
     // vs k = ceil(n / 2^18) lanes per thread): n = 2^19 15.1 vs 14.5, 3*2^18 13.9 vs 13.9, 2^20 14.9 vs 13.1, 5*2^18 13.7 vs
     // 13.1; beyond that the one-shot kernel's generations overlap by themselves (6*2^18: 13.7 vs 13.8; 2^21: 13.4 vs 13.3).
-    if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n <= ((int64_t)5 << 18)) h->lcfg.items = (int)((h->n + (((int64_t)1 << 18) - 1)) >> 18);
+    // k is n / 2^18 ROUNDED, not rounded up: one lane more than 2^20 used to select k = 5 — 17.5 us per step against 12.5 at 2^20 lanes
+    // (profiles/ragged_r05.txt); with k = 4 the 4097th workgroup is one more wave on a chip that holds eight per SIMD.
+    if (alu_bound && h->n >= ((int64_t)1 << 19) && h->n < ((int64_t)11 << 17)) h->lcfg.items = (int)((h->n + ((int64_t)1 << 17)) >> 18);
     // Wave-compacted fused reset (kernels.hip: reset_pending_wave) wherever the dwordx4 lean kernel of an env whose observation IS
     // its state runs: the wave's finished sub-lanes are drawn in ONE Philox pass by its first lanes instead of 1.6 mostly idle
     // passes.  CartPole at 2^20 lanes: 6.91 -> 6.52 us per launch, bit-identical (profiles/forms_probe_r03.txt).

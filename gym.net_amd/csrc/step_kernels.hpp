@@ -372,9 +372,37 @@ struct LaneInputs {
     int32_t sbd[VEC];
 };
 
+// The inputs of the batch's ragged end (the GUARD bodies of every kernel form): UNCONDITIONAL element loads, a lane past the end
+// re-reads the last valid lane (only its stores are suppressed).  The bounds-checked load_row<GUARD> branches per access, and a branch around
+// a load makes the compiler wait for it at the join: a thread's twenty loads then cost twenty memory latencies in a row (measured:
+// 2^20 + 2 float64 lanes 19.6 us per step with branching loads in the last workgroups against 11.1 for the whole batch).
+template <bool NT, class T>
+__device__ __forceinline__ T load_elem(const T *p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+
+// one row's VEC elements, index clamped to the last valid lane
+template <class T, int VEC, bool NT>
+__device__ __forceinline__ void load_row_clamped(const T *__restrict__ p, int64_t i0, int64_t n, T (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = load_elem<NT>(p + (i0 + j < n ? i0 + j : n - 1));
+}
+
+template <class Env, int VEC, bool AUTORESET, int NT>
+__device__ __forceinline__ void load_inputs_clamped(const StepArgsT<typename Env::Real> &a, const int64_t i0, LaneInputs<Env, VEC> &in) {
+    constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k)
+        load_row_clamped<typename Env::Real, VEC, NT_SL>(state_row_src<Env>(a.state, a.state_stride, a.obs_in, a.obs_stride, k), i0, a.n, in.s[k]);
+    if constexpr (Env::BOX_ACTION) load_row_clamped<float, VEC, NT_A>(static_cast<const float *>(a.action), i0, a.n, in.act);
+    else load_row_clamped<int32_t, VEC, NT_A>(static_cast<const int32_t *>(a.action), i0, a.n, in.act);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) in.sbd[j] = 0;
+    if constexpr (!AUTORESET && Env::HAS_SBD) load_row_clamped<int32_t, VEC, NT_SL>(a.sbd, i0, a.n, in.sbd);
+}
+
 template <class Env, int VEC, bool AUTORESET, int NT, bool GUARD>
 __device__ __forceinline__ void load_inputs(const StepArgsT<typename Env::Real> &a, const int64_t i0, LaneInputs<Env, VEC> &in) {
     constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
+    if constexpr (GUARD) { load_inputs_clamped<Env, VEC, AUTORESET, NT>(a, i0, in); return; }
     const int64_t n = a.n;
 #pragma unroll
     for (int k = 0; k < Env::S; ++k)
@@ -384,25 +412,6 @@ __device__ __forceinline__ void load_inputs(const StepArgsT<typename Env::Real> 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) in.sbd[j] = 0;
     if constexpr (!AUTORESET && Env::HAS_SBD) load_i32<VEC, NT_SL, GUARD>(a.sbd, i0, n, in.sbd);
-}
-
-// The inputs of the batch's ragged end for the multi-item kernels: UNCONDITIONAL element loads, a lane past the end re-reads the
-// last valid lane (only its stores are suppressed).  The bounds-checked load_row<GUARD> branches per access, and a branch around
-// a load makes the compiler wait for it at the join: a thread's twenty loads then cost twenty memory latencies in a row (measured:
-// 2^20 + 2 float64 lanes 19.6 us per step with branching loads in the last workgroups against 11.1 for the whole batch).
-template <class Env, int VEC, int NT>
-__device__ __forceinline__ void load_inputs_clamped(const StepArgsT<typename Env::Real> &a, const int64_t i0, LaneInputs<Env, VEC> &in) {
-    constexpr bool NT_SL = (NT & 1) != 0, NT_A = (NT & 4) != 0;
-    auto ld = [](const auto *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; };
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const int64_t i = i0 + j < a.n ? i0 + j : a.n - 1;
-#pragma unroll
-        for (int k = 0; k < Env::S; ++k) in.s[k][j] = ld(state_row_src<Env>(a.state, a.state_stride, a.obs_in, a.obs_stride, k) + i, NT_SL);
-        if constexpr (Env::BOX_ACTION) in.act[j] = ld(static_cast<const float *>(a.action) + i, NT_A);
-        else in.act[j] = ld(static_cast<const int32_t *>(a.action) + i, NT_A);
-        in.sbd[j] = 0;
-    }
 }
 
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS, int NT, bool GUARD, int RESETF = 0, bool PACK = true>
@@ -423,7 +432,10 @@ __device__ __forceinline__ void advance_and_store(const StepArgsT<typename Env::
     if constexpr (EXTRAS) {
         stats = a.ep_ret != nullptr;
         // running return / length: read-modify-write streams like the state, same non-temporal policy
-        if (stats) { load_f32<VEC, NT_SL, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, NT_SL, GUARD>(a.ep_len, i0, n, ep_len); }
+        if (stats) {
+            if constexpr (GUARD) { load_row_clamped<float, VEC, NT_SL>(a.ep_ret, i0, n, ep_ret); load_row_clamped<int32_t, VEC, NT_SL>(a.ep_len, i0, n, ep_len); }
+            else { load_f32<VEC, NT_SL, false>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, NT_SL, false>(a.ep_len, i0, n, ep_len); }
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { fin_ret[j] = 0.0f; fin_len[j] = 0; }
     }
@@ -693,8 +705,7 @@ __device__ __forceinline__ void pipe2_split_body(const StepArgsT<typename Env::R
     LaneInputs<Env, 2> in[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-        if constexpr (GUARD) load_inputs_clamped<Env, 2, NT>(a, (t + k * T) * 2, in[k]);
-        else load_inputs<Env, 2, true, NT, false>(a, (t + k * T) * 2, in[k]);
+        load_inputs<Env, 2, true, NT, GUARD>(a, (t + k * T) * 2, in[k]);
     }
     uint32_t pending = 0;
 #pragma unroll
