@@ -735,6 +735,8 @@ __device__ __forceinline__ void pipe2_split_body(const StepArgsT<typename Env::R
 }
 
 template <class Env, int ITEMS, bool AUTORESET, int NT>
+// (No occupancy hint: the float64 four-pair kernel holds 185 VGPRs = two waves per SIMD; capped at 168 for three it spills 48 bytes and
+// runs at 14.0 instead of 11.1 us per 2^20-lane step — profiles/occupancy_hints_r05.txt.)
 __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
     const uint64_t tick = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
@@ -1104,8 +1106,13 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     }
 }
 
+// Occupancy: a float32 rollout at 2^20 lanes is 4096 waves of four lanes per thread — FOUR per SIMD.  The bookkeeping variants
+// allocate 131-152 VGPRs by themselves (three waves per SIMD: a quarter of the launch runs as a second generation); capped at 128
+// (four blocks of four waves per CU) they fit in one — 4.1 -> 3.2 us per vector step with episode statistics, 7.3 -> 6.3 with sampled
+// actions and episode records, at the price of 36-92 bytes of scratch (profiles/occupancy_hints_r05.txt).  The float64 variants lose under
+// the same cap (bookkeeping rollout with the compacted reset 6.9 -> 7.7 us) and are left alone.
 template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0>
-__global__ __launch_bounds__(256) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
+__global__ __launch_bounds__(256, sizeof(typename Env::Real) == 4 ? 4 : 1) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     ResetScratch<Env> *sc = nullptr;
     if constexpr (RESETF == 1) {
