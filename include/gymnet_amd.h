@@ -195,10 +195,13 @@ typedef struct gymnet_launch_policy {
     int32_t  block;                /* threads per workgroup: 64 / 128 / 256 */
     int32_t  nt;                   /* non-temporal stream mask: 0 none, 12 action + reward / done, 15 every stream */
     int32_t  sequential_lanes;     /* multi-lane kernels (lean variant): Acrobot with vec 1 — lanes per thread, 1 (one-shot kernel) .. 5;
-                                      Acrobot / F64 handles with vec 2 — lane PAIRS per thread, 1 .. 4, num_envs a multiple of
-                                      2 * sequential_lanes * 256.  A value > 1 the launcher would not resolve to -> GYMNET_ERR_INVALID_ARG */
+                                      Acrobot / F64 handles with vec 2 — lane PAIRS per thread, 1 .. 4; num_envs a multiple of
+                                      2 * sequential_lanes * 256, except F64 handles with auto-reset (any batch size; their
+                                      multi-pair kernel draws the fused reset once per thread-group of pairs whatever reset_form
+                                      says).  A value > 1 the launcher would not resolve to -> GYMNET_ERR_INVALID_ARG */
     int32_t  reset_form;           /* fused auto-reset: 0 per-thread drain loop, 1 wave-compacted (wide kernels of the envs whose
-                                      observation is the state: CartPole in both state scalars, MountainCar) */
+                                      observation is the state: CartPole in both state scalars — F64: two lanes per reset —,
+                                      MountainCar); also selects the per-step reset of the fused rollout */
     int32_t  lds_pipe;             /* Acrobot: 1 = producer / consumer form of the multi-lane kernel (needs num_envs % 512 == 0) */
     int32_t  occupancy_lds_bytes;  /* unused dynamic LDS per workgroup, for the one purpose of capping occupancy in probes */
     int32_t  graph;                /* gymnet_vecenv_rollout_device: 0 eager launches, 1 hipGraph replay, -2 back to "by batch size" */
