@@ -16,6 +16,7 @@
 #include <vector>
 #include <algorithm>
 #include <string>
+#include <chrono>
 
 #include "../gym.net_amd/csrc/step_kernels.hpp"
 #include "../gym.net_amd/csrc/envs.hpp"
@@ -274,6 +275,104 @@ int main(int argc, char **argv) {
     HIP_OK(hipSetDevice(0));
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
+    if (argc > 4 && std::strcmp(argv[4], "split") == 0) {
+        // The step kernels are WRITE-bound at this size (profiles/write_path_probe_r02.txt: the write half of CartPole's pattern alone
+        // takes 5.0 us, the read half 2.8, a copy of both 5.3) and a launch cannot store before its first loads are back.  Lanes are
+        // independent, so the batch can run as K chains of n / K lanes on K streams: chain A's store phase then overlaps chain B's
+        // load phase ACROSS launches.  us per vector step (all K launches), host clock around `launches` steps + one synchronize.
+        const int parts_list[] = {1, 2, 3, 4};
+        auto run_split = [&](auto env_tag, const char *label, LaunchCfg cfg) {
+            using Env = decltype(env_tag);
+            using R = typename Env::Real;
+            Buffers b;
+            HIP_OK(hipMalloc(&b.state, (size_t)Env::S * n * sizeof(R))); HIP_OK(hipMalloc(&b.obs, (size_t)Env::O * n * sizeof(R)));
+            HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
+            HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4)); HIP_OK(hipMalloc((void **)&b.done, (size_t)n));
+            HIP_OK(hipMalloc((void **)&b.tick2, 16 * 8));
+            HIP_OK(hipMemsetAsync(b.state, 0, (size_t)Env::S * n * sizeof(R), st)); HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)Env::O * n * sizeof(R), st));
+            std::vector<uint32_t> act = host_actions(n, Env::BOX_ACTION, Env::BOX_ACTION ? 0 : (int)action_count<Env>());
+            HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipStreamSynchronize(st));
+            hipStream_t ss[4];
+            for (auto &q : ss) HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+            std::printf("== %s, %lld lanes as K chains on K streams: us per vector step\n", label, (long long)n);
+            for (int K : parts_list) {
+                const int64_t m = n / K / 1024 * 1024;           // lanes per chain (whole workgroups; the remainder is ignored by the probe)
+                std::vector<double> us;
+                for (int r = 0; r < rounds + 1; ++r) {
+                    HIP_OK(hipMemsetAsync(b.tick2, 0, 16 * 8, st));
+                    HIP_OK(hipStreamSynchronize(st));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (int l = 0; l < launches; ++l) {
+                        for (int c = 0; c < K; ++c) {
+                            StepArgsT<R> a{};
+                            a.state = (R *)b.state + c * m; a.state_out = a.state;
+                            a.obs = Env::OBS_ALIASES_STATE ? a.state : (R *)b.obs + c * m; a.obs_in = a.obs;
+                            a.action = static_cast<const char *>(b.action) + ((int64_t)(l % kRing) * n + c * m) * 4;
+                            a.reward = b.reward + c * m; a.done = b.done + c * m; a.tick2 = b.tick2 + 2 * c;
+                            a.n = m; a.state_stride = n; a.obs_stride = n; a.lane_offset = (uint64_t)(c * m); a.seed = 0x5EED;
+                            a.parity = l & 1; a.cparity = a.parity;
+                            HIP_OK((launch_step_env<Env>(true, false, a, cfg, ss[c])));
+                        }
+                    }
+                    for (int c = 0; c < K; ++c) HIP_OK(hipStreamSynchronize(ss[c]));
+                    const auto t1 = std::chrono::steady_clock::now();
+                    if (r) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count() / launches);
+                }
+                std::printf("   K = %d (%lld lanes per launch): eager %7.3f us per step  [%.3f, %.3f]", K, (long long)m, median(us),
+                            *std::min_element(us.begin(), us.end()), *std::max_element(us.begin(), us.end()));
+                // the same as ONE hipGraph of K parallel chains x 64 steps, replayed (no host cost per launch)
+                {
+                    constexpr int L = 64;
+                    hipEvent_t fork, join[4];
+                    HIP_OK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+                    for (auto &e : join) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    HIP_OK(hipMemsetAsync(b.tick2, 0, 16 * 8, st));
+                    HIP_OK(hipStreamSynchronize(st));
+                    hipGraph_t graph; hipGraphExec_t exec;
+                    HIP_OK(hipStreamBeginCapture(ss[0], hipStreamCaptureModeGlobal));
+                    HIP_OK(hipEventRecord(fork, ss[0]));
+                    for (int c = 1; c < K; ++c) HIP_OK(hipStreamWaitEvent(ss[c], fork, 0));
+                    for (int l = 0; l < L; ++l) {
+                        for (int c = 0; c < K; ++c) {
+                            StepArgsT<R> a{};
+                            a.state = (R *)b.state + c * m; a.state_out = a.state;
+                            a.obs = Env::OBS_ALIASES_STATE ? a.state : (R *)b.obs + c * m; a.obs_in = a.obs;
+                            a.action = static_cast<const char *>(b.action) + ((int64_t)(l % kRing) * n + c * m) * 4;
+                            a.reward = b.reward + c * m; a.done = b.done + c * m; a.tick2 = b.tick2 + 2 * c;
+                            a.n = m; a.state_stride = n; a.obs_stride = n; a.lane_offset = (uint64_t)(c * m); a.seed = 0x5EED;
+                            a.parity = l & 1; a.cparity = a.parity;
+                            HIP_OK((launch_step_env<Env>(true, false, a, cfg, ss[c])));
+                        }
+                    }
+                    for (int c = 1; c < K; ++c) { HIP_OK(hipEventRecord(join[c], ss[c])); HIP_OK(hipStreamWaitEvent(ss[0], join[c], 0)); }
+                    HIP_OK(hipStreamEndCapture(ss[0], &graph));
+                    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                    std::vector<double> gus;
+                    const int replays = launches / L > 0 ? launches / L : 1;
+                    for (int r = 0; r < rounds + 1; ++r) {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        for (int q = 0; q < replays; ++q) HIP_OK(hipGraphLaunch(exec, ss[0]));
+                        HIP_OK(hipStreamSynchronize(ss[0]));
+                        const auto t1 = std::chrono::steady_clock::now();
+                        if (r) gus.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count() / (replays * L));
+                    }
+                    std::printf("   graph of K chains %7.3f us per step  [%.3f, %.3f]\n", median(gus), *std::min_element(gus.begin(), gus.end()),
+                                *std::max_element(gus.begin(), gus.end()));
+                    HIP_OK(hipGraphExecDestroy(exec)); HIP_OK(hipGraphDestroy(graph));
+                    HIP_OK(hipEventDestroy(fork)); for (auto &e : join) HIP_OK(hipEventDestroy(e));
+                }
+                std::fflush(stdout);
+            }
+            for (auto &q : ss) HIP_OK(hipStreamDestroy(q));
+            HIP_OK(hipFree(b.state)); HIP_OK(hipFree(b.obs)); HIP_OK(hipFree(b.action)); HIP_OK(hipFree(b.reward)); HIP_OK(hipFree(b.done)); HIP_OK(hipFree(b.tick2));
+        };
+        run_split(CartPole{}, "CartPole-v1 (float32), one-shot 16-byte lanes", LaunchCfg{4, 256, 15, 0, 1, 1, 0});
+        run_split(MountainCar{}, "MountainCar-v0", LaunchCfg{4, 64, 15, 0, 1, 1, 0});
+        run_split(Pendulum{}, "Pendulum-v1", LaunchCfg{4, 64, 15, 0, 1, 0, 0});
+        run_split(CartPole64{}, "CartPole-v1 float64, one-shot", LaunchCfg{2, 256, 15, 0, 1, 1, 0});
+        return 0;
+    }
     if (argc > 4 && std::strcmp(argv[4], "parts") == 0) {
         // float64 CartPole: where the time above the skeleton goes — physics + Philox (real), physics only (constant reset), nothing
         Buffers b;
