@@ -319,3 +319,25 @@ def test_f64_pair_kernel_workgroup_sizes_and_reset_forms_are_bit_identical(gpu_p
         for bad in (dict(vec=4), dict(sequential_lanes=8), dict(sequential_lanes=5)):
             with pytest.raises(ValueError):
                 env.SetLaunchPolicy(**bad)
+
+
+@pytest.mark.parametrize("env_id,dtype,n,want", [
+    ("MountainCar-v0", "float32", 1 << 19, "step_kernel<MountainCar,1,true,false,15,0>"),          # one resident generation: scalar lanes
+    ("MountainCar-v0", "float32", (1 << 19) + 64, "step_kernel<MountainCar,4,true,false,15,1>"),   # beyond it: 16-byte lanes (was scalar up to 24 MiB)
+    ("MountainCar-v0", "float32", 1_000_000, "step_kernel<MountainCar,4,true,false,15,1>"),
+    ("CartPole-v1", "float32", 1 << 19, "step_kernel<CartPole,1,true,false,15,0>"),
+    ("CartPole-v1", "float32", 3 << 18, "step_kernel<CartPole,4,true,false,15,1>"),
+    ("Acrobot-v1", "float32", 1 << 20, "step_kernel_pipe<Acrobot,4,true,15>"),
+    ("Acrobot-v1", "float32", (1 << 20) + 1, "step_kernel_pipe<Acrobot,4,true,15>"),               # rounded, not rounded up (was 5 lanes per thread)
+    ("Acrobot-v1", "float32", 5 << 18, "step_kernel_pipe<Acrobot,5,true,15>"),
+    ("CartPole-v1", "float64", 1 << 20, "step_kernel_pipe2<CartPole64,4,true,15>"),
+    ("CartPole-v1", "float64", 1_000_000, "step_kernel_pipe2<CartPole64,4,true,15>"),               # any batch size just under two waves per SIMD
+    ("CartPole-v1", "float64", (1 << 20) + 2, "step_kernel<CartPole64,2,true,false,15,1>"),         # one wave more would be a second round
+    ("CartPole-v1", "float64", 3 << 18, "step_kernel_pipe2<CartPole64,2,true,15>"),
+    ("CartPole-v1", "float64", 1 << 19, "step_kernel<CartPole64,2,true,false,15,1>"),
+])
+def test_default_launch_policy_by_batch_size(gpu_pkg, env_id, dtype, n, want):
+    """The launch policy's round-5 rules, as the kernel the library itself names (profiles/small_batches_r05.txt, ragged_r05.txt, f64_sizes_r05.txt)."""
+    kw = {"dtype": np.float64} if dtype == "float64" else {}
+    with gpu_pkg.VectorEnv(env_id, n, seed=SEED, auto_reset=True, **kw) as env:
+        assert env.KernelName() == want
