@@ -373,6 +373,49 @@ int main(int argc, char **argv) {
         run_split(CartPole64{}, "CartPole-v1 float64, one-shot", LaunchCfg{2, 256, 15, 0, 1, 1, 0});
         return 0;
     }
+    if (argc > 4 && std::strcmp(argv[4], "ntmask") == 0) {
+        // every non-temporal mask of the shipped CartPole kernel (1 state loads, 2 state stores, 4 action load, 8 reward / done stores);
+        // the launcher offers 0, 12 and 15 — tools/store_flavour_probe.hip suggested nt loads + PLAIN state stores (13) for the in-place copy
+        Buffers b;
+        HIP_OK(hipMalloc(&b.state, (size_t)4 * n * 4)); HIP_OK(hipMalloc(&b.obs, 64)); HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
+        HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4)); HIP_OK(hipMalloc((void **)&b.done, (size_t)n)); HIP_OK(hipMalloc((void **)&b.tick2, 16));
+        HIP_OK(hipMemsetAsync(b.state, 0, (size_t)4 * n * 4, st));
+        std::vector<uint32_t> act = host_actions(n, false, 2);
+        HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
+        HIP_OK(hipStreamSynchronize(st));
+        uint64_t tick = 0;
+        const dim3 grid((unsigned)((n / 4 + 255) / 256)), blk(256);
+        auto time_mask = [&](auto mask_tag) {
+            constexpr int M = decltype(mask_tag)::value;
+            auto a = make_args<CartPole>(b, n);
+            hipEvent_t e0, e1;
+            HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+            HIP_OK(hipEventRecord(e0, st));
+            for (int i = 0; i < launches; ++i) {
+                a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+                a.action = static_cast<const char *>(b.action) + (int64_t)(tick % kRing) * n * 4;
+                hipLaunchKernelGGL((step_kernel<CartPole, 4, true, false, M, 1>), grid, blk, 0, st, a);
+                ++tick;
+            }
+            HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipEventSynchronize(e1));
+            float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+            return (double)ms * 1000.0 / launches;
+        };
+        std::vector<double> t[8];
+        time_mask(std::integral_constant<int, 15>{});
+        for (int q = 0; q < rounds; ++q) {
+            t[0].push_back(time_mask(std::integral_constant<int, 15>{})); t[1].push_back(time_mask(std::integral_constant<int, 13>{}));
+            t[2].push_back(time_mask(std::integral_constant<int, 12>{})); t[3].push_back(time_mask(std::integral_constant<int, 14>{}));
+            t[4].push_back(time_mask(std::integral_constant<int, 9>{}));  t[5].push_back(time_mask(std::integral_constant<int, 5>{}));
+            t[6].push_back(time_mask(std::integral_constant<int, 7>{}));  t[7].push_back(time_mask(std::integral_constant<int, 0>{}));
+        }
+        const int masks[] = {15, 13, 12, 14, 9, 5, 7, 0};
+        std::printf("CartPole step kernel, %lld lanes, us per launch by non-temporal mask (1 state loads, 2 state stores, 4 action load, 8 reward / done stores):\n", (long long)n);
+        for (int i = 0; i < 8; ++i) std::printf("   mask %2d   %7.3f  [%.3f, %.3f]\n", masks[i], median(t[i]), *std::min_element(t[i].begin(), t[i].end()), *std::max_element(t[i].begin(), t[i].end()));
+        return 0;
+    }
     if (argc > 4 && std::strcmp(argv[4], "parts") == 0) {
         // float64 CartPole: where the time above the skeleton goes — physics + Philox (real), physics only (constant reset), nothing
         Buffers b;
