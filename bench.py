@@ -246,6 +246,11 @@ def make_watchdog(rank, out, emitted, section, seconds, exit_fn=os._exit):
     return t
 
 
+# bytes a step WRITES per env-step (new state rows the kernel owns + observation rows + reward + done): the write path is what binds
+WRITTEN_BYTES = {("CartPole-v1", False): 21, ("CartPole-v1", True): 37, ("Pendulum-v1", False): 21, ("MountainCar-v0", False): 13,
+                 ("Acrobot-v1", False): 37}
+
+
 def allgather_model(world, bytes_per_rank):
     """what a per-step observation all-gather costs on point-to-point xGMI — direct (every rank stores its slice to
     each peer over that peer's own link, all links concurrently) vs a ring (per-link bound, G - 1 hops)."""
@@ -667,7 +672,13 @@ def main():
                          "bytes_per_launch": bytes_per_step * n, "algorithmic_bytes_per_launch": algo_bytes_per_step * n,
                          "launch_us": launch_us, "achieved_by_events": by_events, "frac_by_events": by_events / HBM_PEAK_GBPS,
                          "frac_by_wall": achieved / HBM_PEAK_GBPS,
-                         "note": "at 2^20 lanes the working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM"},
+                         "note": "at 2^20 lanes the working set is Infinity-Cache resident; see hbm_resident_2p27 for real HBM",
+                         # the step kernels are short of WRITE bandwidth, not of total bytes: the written half of this pattern alone runs
+                         # at 4.4-4.8 TB/s whatever the store flavour, the read half overlaps it almost entirely (a copy of both takes
+                         # 5-6 % longer than the writes alone) — profiles/write_path_probe_r02.txt, store_flavour_r05.txt, skeleton_floor_r05.txt
+                         "write_path": {"written_bytes_per_env_step": WRITTEN_BYTES.get((args.env, f64)),
+                                        "measured_pure_write_GBps": [4400, 4800],
+                                        "note": "launch time ~ time to the first store (~1-1.7 us) + written bytes / pure-write rate"}},
         }
 
     out = headline() if rank == 0 else {}
