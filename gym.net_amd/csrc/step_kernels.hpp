@@ -913,9 +913,15 @@ __device__ __forceinline__ typename Env::Action sampled_action(const PhiloxWords
 //           truncation, dense last-finished-episode views, per-rollout compact episode records, the done list of the LAST step
 //   SAMPLE  the actions are drawn in the kernel (RolloutArgs::action_source 1 or 2) instead of read from the ring
 //   RESETF  1 = the wave-compacted reset (reset_pending_wave) per step instead of the per-thread drain loop
-template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE, int RESETF = 0>
+// Episode records of a rollout are STAGED per wave in LDS (64 records: ~5 steps' worth at CartPole's rate) and flushed with one atomic
+// and full-line stores; appending each step's ~11 records directly cost one atomic round trip per wave and step on the critical path.
+struct EpisodeStage { int32_t t[64], lane[64]; float ret[64]; int32_t len[64]; };
+
+//   RECORDS the rollout keeps compact episode records (RolloutArgs::ep_*; bookkeeping handles): a variant of its own, so that the
+//           rollouts that keep none do not carry the staging code's registers (128-VGPR budget, above)
+template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE, int RESETF = 0, bool RECORDS = false>
 __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &ro,
-                                             const int64_t i0, const uint64_t tick0, ResetScratch<Env> *sc = nullptr) {
+                                             const int64_t i0, const uint64_t tick0, ResetScratch<Env> *sc = nullptr, EpisodeStage *stage = nullptr) {
     constexpr int S = Env::S, O = Env::O;
     using Act = typename Env::Action;
     using Real = typename Env::Real;
@@ -957,6 +963,32 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
         stats = a.ep_ret != nullptr;
         if (stats) { load_f32<VEC, true, GUARD>(a.ep_ret, i0, n, ep_ret); load_i32<VEC, true, GUARD>(a.ep_len, i0, n, ep_len); }
     }
+
+    uint32_t staged = 0;               // records waiting in the wave's LDS stage (wave-uniform)
+    auto flush_stage = [&]() {
+        if constexpr (EXTRAS && RECORDS) {
+            if (staged == 0) return;                                   // wave-uniform
+            wave_lds_fence();
+            const uint64_t act_mask = __ballot(1);
+            const int leader = __ffsll((unsigned long long)act_mask) - 1;
+            const uint32_t A = (uint32_t)__popcll(act_mask);           // the active lanes are a prefix (a partial last wave)
+            const uint32_t shard = wave_shard();
+            uint32_t base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(&ro.ep_count[shard * kCountStride], staged);
+            base = __shfl(base, leader);
+            for (uint32_t b0 = 0; b0 < staged; b0 += A) {
+                const uint32_t q = b0 + lane_id();
+                if (q < staged && (int64_t)(base + q) < ro.ep_cap) {   // beyond the capacity: counted, not kept
+                    const int64_t pos = (int64_t)shard * ro.ep_cap + base + q;
+                    ro.ep_t[pos] = stage->t[q];
+                    ro.ep_lane[pos] = stage->lane[q];
+                    if (ro.ep_ret) { ro.ep_ret[pos] = stage->ret[q]; ro.ep_len[pos] = stage->len[q]; }
+                }
+            }
+            wave_lds_fence();
+            staged = 0;
+        }
+    };
 
     for (int64_t t = 0; t < ro.steps; ++t) {
         int64_t nslice = slice + 1;
@@ -1044,12 +1076,15 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
                 }
                 if constexpr (AUTORESET) pending |= fin ? (1u << j) : 0u;
             }
-            if (ro.ep_lane) {
-                // (t, lane, return, length) of every episode that ended in this step, compacted per wave: ballot + ONE atomic per
-                // wave into the wave's shard — 4096 waves appending to one counter would serialise (StepArgs::done_list)
+            if constexpr (RECORDS) {
+                // (t, lane, return, length) of every episode that ended in this step, compacted per wave (ballot + mbcnt) into the wave's
+                // LDS stage; a full stage is flushed with ONE atomic into the wave's shard (4096 waves appending to one counter would
+                // serialise: StepArgs::done_list) and contiguous stores.  A step with more finished lanes than the stage holds (every
+                // lane hitting the time limit in the same step) flushes and appends directly.
                 uint32_t off[VEC];
                 const uint32_t total = rank_finished<VEC>(finished, off);
-                if (total) {   // wave-uniform
+                if (total && staged + total > 64u) flush_stage();   // wave-uniform
+                if (total > 64u) {
                     const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
                     const uint32_t shard = wave_shard();
                     uint32_t base = 0;
@@ -1063,6 +1098,14 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
                         ro.ep_lane[pos] = (int32_t)(i0 + j);
                         if (ro.ep_ret) { ro.ep_ret[pos] = fin_ret[j]; ro.ep_len[pos] = fin_len[j]; }
                     }
+                } else if (total) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (!finished[j]) continue;
+                        const uint32_t q = staged + off[j];
+                        stage->t[q] = (int32_t)t; stage->lane[q] = (int32_t)(i0 + j); stage->ret[q] = fin_ret[j]; stage->len[q] = fin_len[j];
+                    }
+                    staged += total;
                 }
             }
             // the done list "of the most recent step" (gymnet_vecenv_done_lanes / _done_records) describes the rollout's LAST step
@@ -1090,6 +1133,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
         for (int j = 0; j < VEC; ++j) act[j] = act_next[j];
         slice = nslice;
     }
+    flush_stage();
 
 #pragma unroll
     for (int k = 0; k < S; ++k)
@@ -1111,13 +1155,18 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
 // (four blocks of four waves per CU) they fit in one — 4.1 -> 3.2 us per vector step with episode statistics, 7.3 -> 6.3 with sampled
 // actions and episode records, at the price of 36-92 bytes of scratch (profiles/occupancy_hints_r05.txt).  The float64 variants lose under
 // the same cap (bookkeeping rollout with the compacted reset 6.9 -> 7.7 us) and are left alone.
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0, bool RECORDS = false>
 __global__ __launch_bounds__(256, sizeof(typename Env::Real) == 4 ? 4 : 1) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     ResetScratch<Env> *sc = nullptr;
     if constexpr (RESETF == 1) {
         __shared__ ResetScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
         sc = &scratch[threadIdx.x >> 6];
+    }
+    EpisodeStage *stage = nullptr;
+    if constexpr (EXTRAS && RECORDS) {
+        __shared__ EpisodeStage stages[256 / 64];                  // one per wave of the workgroup
+        stage = &stages[threadIdx.x >> 6];
     }
     const uint64_t tick0 = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick0 + (uint64_t)ro.steps;
@@ -1126,10 +1175,10 @@ __global__ __launch_bounds__(256, sizeof(typename Env::Real) == 4 ? 4 : 1) void 
             for (int sh = threadIdx.x; sh < kShards; sh += blockDim.x) a.done_count2[(a.cparity ^ 1) * (kShards * kCountStride) + sh * kCountStride] = 0u;
     }
     if (((int64_t)blockIdx.x + 1) * blockDim.x * VEC <= a.n) {     // full workgroup: no bounds checks inside the T-step loop
-        rollout_body<Env, VEC, AUTORESET, false, EXTRAS, SAMPLE, RESETF>(a, ro, i0, tick0, sc);
+        rollout_body<Env, VEC, AUTORESET, false, EXTRAS, SAMPLE, RESETF, RECORDS>(a, ro, i0, tick0, sc, stage);
     } else {
         if (i0 >= a.n) return;
-        rollout_body<Env, VEC, AUTORESET, true, EXTRAS, SAMPLE, RESETF>(a, ro, i0, tick0, sc);
+        rollout_body<Env, VEC, AUTORESET, true, EXTRAS, SAMPLE, RESETF, RECORDS>(a, ro, i0, tick0, sc, stage);
     }
 }
 
@@ -1425,12 +1474,15 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
     const bool sample = r.action_source != 0;
     const int64_t threads = (a.n + (wide ? WIDE : 1) - 1) / (wide ? WIDE : 1);
     const dim3 grid(grid_for(threads > 0 ? threads : 1, 256)), blk(256);
-#define GYMNET_ROLL(V, AR, RF)                                                                                               \
-    do {                                                                                                                    \
-        if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF>), grid, blk, 0, st, a, r);  \
-                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF>), grid, blk, 0, st, a, r); }      \
-        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r); \
-                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false, RF>), grid, blk, 0, st, a, r); }     \
+    const bool records = extras && r.ep_lane != nullptr;
+#define GYMNET_ROLL(V, AR, RF)                                                                                                     \
+    do {                                                                                                                          \
+        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF, true>), grid, blk, 0, st, a, r); \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF, true>), grid, blk, 0, st, a, r); }     \
+        else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF>), grid, blk, 0, st, a, r);   \
+                           else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF>), grid, blk, 0, st, a, r); }       \
+        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r);       \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false, RF>), grid, blk, 0, st, a, r); }           \
     } while (0)
     if (wide) {
         if (autoreset) {
