@@ -61,6 +61,12 @@ __device__ __forceinline__ void store_row(T *__restrict__ p, int64_t i0, int64_t
                 V t;
                 if constexpr (P == 4) t = V{v[q * P], v[q * P + 1], v[q * P + 2], v[q * P + 3]};
                 else t = V{v[q * P], v[q * P + 1]};
+#ifdef GYMNET_PROBE_STORE_SC1     // probe builds only (tools/skeleton_floor.hip, mode "sc1"): 16-byte float rows written through (`sc1`)
+                if constexpr (NT && sizeof(T) == 4 && P == 4) {
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p + i0 + q * P), "v"(t) : "memory");
+                    continue;
+                }
+#endif
                 if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<V *>(p + i0 + q * P));
                 else *reinterpret_cast<V *>(p + i0 + q * P) = t;
             }
