@@ -1169,12 +1169,17 @@ int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout
     // wide accesses on the streams a rollout touches: 16-byte rows of observations (4 floats / 2 doubles per thread), vec rewards /
     // actions, vec done bytes; anything less aligned runs one lane per thread (same bits)
     if (cfg.vec > 1) {
+        auto streams_fit = [&](int w) {
+            bool ok = (h->n % w) == 0;
+            if (ring_read) ok = ok && aligned_to(sp.d_actions, 4 * w) && (sp.action_stride % w) == 0;
+            return ok && (!sp.d_rec_obs || aligned16(sp.d_rec_obs)) && (!sp.d_rec_reward || aligned_to(sp.d_rec_reward, 4 * w)) &&
+                   (!sp.d_rec_done || aligned_to(sp.d_rec_done, w)) && (!sp.d_rec_actions || aligned_to(sp.d_rec_actions, 4 * w));
+        };
         const int w = h->f64 ? 2 : cfg.vec;               // the fused rollout's wide form: 2 doubles / 4 floats (2: Acrobot) per thread
-        bool ok = (h->n % w) == 0;
-        if (ring_read) ok = ok && aligned_to(sp.d_actions, 4 * w) && (sp.action_stride % w) == 0;
-        ok = ok && (!sp.d_rec_obs || aligned16(sp.d_rec_obs)) && (!sp.d_rec_reward || aligned_to(sp.d_rec_reward, 4 * w)) &&
-             (!sp.d_rec_done || aligned_to(sp.d_rec_done, w)) && (!sp.d_rec_actions || aligned_to(sp.d_rec_actions, 4 * w));
-        if (!ok) cfg.vec = 1;
+        // float64: FOUR lanes per thread where every stream allows it (the state sits in registers for the whole rollout, so this is
+        // about how many lanes share a wave's per-step overheads, not about access width; launch_rollout_env) — else two, else one
+        if (h->f64 && h->desc->alias && (h->sstride % 4) == 0 && streams_fit(4)) cfg.vec = 4;
+        else if (!streams_fit(w)) cfg.vec = 1;
     }
     if (episodes) ST_TRY(ensure_episode_segments(h, sp.ep_capacity));
     ST_TRY(h->f64 ? rollout_fused_typed<double>(h, sp, cfg, episodes) : rollout_fused_typed<float>(h, sp, cfg, episodes));

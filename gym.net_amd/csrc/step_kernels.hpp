@@ -1466,6 +1466,10 @@ static void resolved_shape_env(bool autoreset, bool extras, LaunchCfg cfg, int64
     *sequential = v.lds_tiles > 1 ? v.lds_tiles : v.pipe_items;
 }
 
+// envs whose fused rollout has a four-lanes-per-thread form beyond their widest step-kernel form (float64 state, observation = state)
+template <class Env>
+constexpr bool rollout_quad_form() { return sizeof(typename Env::Real) == 8 && Env::OBS_ALIASES_STATE && !Env::PACKED2; }
+
 template <class Env>
 static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &r,
                                      LaunchCfg cfg, hipStream_t st) {
@@ -1484,6 +1488,29 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
         else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r);       \
                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false, RF>), grid, blk, 0, st, a, r); }           \
     } while (0)
+    if constexpr (rollout_quad_form<Env>()) {
+        // float64: FOUR lanes per thread in the rollout (cfg.vec == 4: capi selects it when every stream is aligned for it).  The state
+        // lives in registers for all T steps, so the lane count per thread only decides how many lanes share one wave's per-step
+        // overheads — the wave-compacted reset pass, its LDS hand-off, the loop — and how many independent binary64 chains a
+        // thread interleaves: 187 -> ~150 VALU per env-step (SQ counters, profiles/pmc_rollout_r05.txt).
+        if (cfg.vec == 4) {
+            const int64_t threads4 = (a.n + 3) / 4;
+            const dim3 grid4(grid_for(threads4 > 0 ? threads4 : 1, 256));
+#define GYMNET_ROLL4(AR, RF)                                                                                                        \
+    do {                                                                                                                            \
+        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, true, RF, true>), grid4, blk, 0, st, a, r);  \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, false, RF, true>), grid4, blk, 0, st, a, r); }      \
+        else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, true, RF>), grid4, blk, 0, st, a, r);    \
+                           else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, false, RF>), grid4, blk, 0, st, a, r); }        \
+        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, false, true, RF>), grid4, blk, 0, st, a, r);        \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, false, false, RF>), grid4, blk, 0, st, a, r); }            \
+    } while (0)
+            if (autoreset) { if (cfg.reset_form == 1) GYMNET_ROLL4(true, 1); else GYMNET_ROLL4(true, 0); }
+            else GYMNET_ROLL4(false, 0);
+#undef GYMNET_ROLL4
+            return hipGetLastError();
+        }
+    }
     if (wide) {
         if (autoreset) {
             // the wave-compacted reset per step (cfg.reset_form = 1; envs whose observation IS the state, wide lanes)
