@@ -1176,8 +1176,9 @@ int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout
                    (!sp.d_rec_done || aligned_to(sp.d_rec_done, w)) && (!sp.d_rec_actions || aligned_to(sp.d_rec_actions, 4 * w));
         };
         const int w = h->f64 ? 2 : cfg.vec;               // the fused rollout's wide form: 2 doubles / 4 floats (2: Acrobot) per thread
-        // float64: FOUR lanes per thread where every stream allows it (the state sits in registers for the whole rollout, so this is
-        // about how many lanes share a wave's per-step overheads, not about access width; launch_rollout_env) — else two, else one
+        // the FAT form where every stream allows it — float64: FOUR lanes per thread (the state sits in registers for the whole rollout, so
+        // this is about how many lanes share a wave's per-step overheads, not about access width; launch_rollout_env) — else two, else one;
+        // (float32 has no fat form: eight floats per thread were measured slower, step_kernels.hpp rollout_fat_lanes)
         if (h->f64 && h->desc->alias && (h->sstride % 4) == 0 && streams_fit(4)) cfg.vec = 4;
         else if (!streams_fit(w)) cfg.vec = 1;
     }

@@ -1466,9 +1466,11 @@ static void resolved_shape_env(bool autoreset, bool extras, LaunchCfg cfg, int64
     *sequential = v.lds_tiles > 1 ? v.lds_tiles : v.pipe_items;
 }
 
-// envs whose fused rollout has a four-lanes-per-thread form beyond their widest step-kernel form (float64 state, observation = state)
+// Lanes per thread of the fused rollout's FAT form — beyond the widest step-kernel form: four doubles per thread for the float64 env
+// whose observation is the state.  0 = the env has none.  (Measured and NOT kept for float32: eight floats per thread save 5 of 102
+// VALU per env-step and halve the waves — 2.6 -> 3.3 us per vector step, profiles/pmc_rollout_r05.txt.)
 template <class Env>
-constexpr bool rollout_quad_form() { return sizeof(typename Env::Real) == 8 && Env::OBS_ALIASES_STATE && !Env::PACKED2; }
+constexpr int rollout_fat_lanes() { return (sizeof(typename Env::Real) == 8 && Env::OBS_ALIASES_STATE && !Env::PACKED2) ? 4 : 0; }
 
 template <class Env>
 static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &r,
@@ -1488,22 +1490,24 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
         else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r);       \
                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, false, RF>), grid, blk, 0, st, a, r); }           \
     } while (0)
-    if constexpr (rollout_quad_form<Env>()) {
-        // float64: FOUR lanes per thread in the rollout (cfg.vec == 4: capi selects it when every stream is aligned for it).  The state
-        // lives in registers for all T steps, so the lane count per thread only decides how many lanes share one wave's per-step
-        // overheads — the wave-compacted reset pass, its LDS hand-off, the loop — and how many independent binary64 chains a
-        // thread interleaves: 187 -> ~150 VALU per env-step (SQ counters, profiles/pmc_rollout_r05.txt).
-        if (cfg.vec == 4) {
-            const int64_t threads4 = (a.n + 3) / 4;
+    if constexpr (rollout_fat_lanes<Env>() > 0) {
+        // The FAT form (cfg.vec == rollout_fat_lanes: capi selects it when every stream is aligned for it): 8 floats / 4 doubles per
+        // thread.  The state lives in registers for all T steps, so the lane count per thread only decides how many lanes share one
+        // wave's per-step overheads — the wave-compacted reset pass, its LDS hand-off, the loop — and how many independent chains a
+        // thread interleaves; the rollouts are instruction-issue bound (SQ counters, profiles/pmc_rollout_r05.txt: float64 187 -> 145
+        // VALU per env-step).
+        constexpr int FAT = rollout_fat_lanes<Env>();
+        if (cfg.vec == FAT) {
+            const int64_t threads4 = (a.n + FAT - 1) / FAT;
             const dim3 grid4(grid_for(threads4 > 0 ? threads4 : 1, 256));
 #define GYMNET_ROLL4(AR, RF)                                                                                                        \
     do {                                                                                                                            \
-        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, true, RF, true>), grid4, blk, 0, st, a, r);  \
-                       else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, false, RF, true>), grid4, blk, 0, st, a, r); }      \
-        else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, true, RF>), grid4, blk, 0, st, a, r);    \
-                           else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, true, false, RF>), grid4, blk, 0, st, a, r); }        \
-        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, false, true, RF>), grid4, blk, 0, st, a, r);        \
-                      else hipLaunchKernelGGL((rollout_kernel<Env, 4, AR, false, false, RF>), grid4, blk, 0, st, a, r); }            \
+        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF, true>), grid4, blk, 0, st, a, r);  \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF, true>), grid4, blk, 0, st, a, r); }      \
+        else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF>), grid4, blk, 0, st, a, r);    \
+                           else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF>), grid4, blk, 0, st, a, r); }        \
+        else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, false, true, RF>), grid4, blk, 0, st, a, r);        \
+                      else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, false, false, RF>), grid4, blk, 0, st, a, r); }            \
     } while (0)
             if (autoreset) { if (cfg.reset_form == 1) GYMNET_ROLL4(true, 1); else GYMNET_ROLL4(true, 0); }
             else GYMNET_ROLL4(false, 0);
