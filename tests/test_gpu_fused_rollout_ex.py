@@ -32,7 +32,7 @@ def _records(ep):
 
 @pytest.mark.parametrize("name,dtype", [("CartPole-v1", np.float32), ("CartPole-v1", np.float64), ("Acrobot-v1", np.float32), ("Pendulum-v1", np.float32)])
 @pytest.mark.parametrize("actions", ["ring", "sample", "epsilon_greedy"])
-@pytest.mark.parametrize("n", [4096 + 6, 1021])
+@pytest.mark.parametrize("n", [4096 + 6, 1021, 8192])        # 8192: every stream aligned — the float64 rollout's four-lanes-per-thread form
 def test_fused_rollout_with_bookkeeping_equals_stepwise(gpu_pkg, name, dtype, actions, n):
     import torch
     if name == "Pendulum-v1" and actions == "epsilon_greedy":
