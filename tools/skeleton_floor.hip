@@ -274,7 +274,12 @@ int main(int argc, char **argv) {
     const int rounds = argc > 3 ? std::atoi(argv[3]) : 5;
     HIP_OK(hipSetDevice(0));
     hipStream_t st;
-    HIP_OK(hipStreamCreate(&st));
+    if (std::getenv("SKELETON_HIGH_PRIORITY")) {       // probe of the probe: does a high-priority stream shorten the launch-to-launch gap?
+        int lo = 0, hi = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_OK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+        std::fprintf(stderr, "stream priority %d (range %d .. %d)\n", hi, lo, hi);
+    } else HIP_OK(hipStreamCreate(&st));
     if (argc > 4 && std::strcmp(argv[4], "split") == 0) {
         // The step kernels are WRITE-bound at this size (profiles/write_path_probe_r02.txt: the write half of CartPole's pattern alone
         // takes 5.0 us, the read half 2.8, a copy of both 5.3) and a launch cannot store before its first loads are back.  Lanes are
