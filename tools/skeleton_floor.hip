@@ -100,6 +100,28 @@ __global__ __launch_bounds__(256) void probe_multi(const StepArgsT<typename Env:
 }
 
 constexpr int64_t kRing = 32;        // action slices (iid per lane and slice: the bench's workload, ~4.5 % of CartPole lanes finish per step)
+// Probe form (NOT in the library): step_kernel_pipe2's shape — ITEMS lane pairs per thread, all loads first — with the pair advanced by the env's
+// PACKED two-lane arithmetic (v_pk_*_f32; the library's pair kernel advances lane after lane).  SQ counters say Acrobot's launch is VALU-issue
+// bound (419 instructions per env-step x 4 cycles = 11.2 of its 12.6 us); the packed form is 287.
+template <class Env, int ITEMS, int NT, bool PACK>
+__global__ __launch_bounds__(256) void probe_pairs(const StepArgsT<typename Env::Real> a) {
+    const uint64_t tick = a.tick2[a.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneInputs<Env, 2> in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) load_inputs<Env, 2, true, NT, false>(a, (t + k * T) * 2, in[k]);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (k == 0) {
+#pragma unroll
+            for (int c = 0; c < Env::S; ++c) asm volatile("" : "+v"(in[0].s[c][0]), "+v"(in[0].s[c][1]));
+        }
+        advance_and_store<Env, 2, true, false, NT, false, 0, PACK>(a, (t + k * T) * 2, tick, in[k]);
+    }
+}
+
 struct Buffers {
     void *state = nullptr, *obs = nullptr, *action = nullptr;
     float *reward = nullptr; uint8_t *done = nullptr; uint64_t *tick2 = nullptr;
@@ -376,6 +398,53 @@ int main(int argc, char **argv) {
         run_split(MountainCar{}, "MountainCar-v0", LaunchCfg{4, 64, 15, 0, 1, 1, 0});
         run_split(Pendulum{}, "Pendulum-v1", LaunchCfg{4, 64, 15, 0, 1, 0, 0});
         run_split(CartPole64{}, "CartPole-v1 float64, one-shot", LaunchCfg{2, 256, 15, 0, 1, 1, 0});
+        return 0;
+    }
+    if (argc > 4 && std::strcmp(argv[4], "acrobot_packed") == 0) {
+        Buffers b;
+        HIP_OK(hipMalloc(&b.state, (size_t)4 * n * 4)); HIP_OK(hipMalloc(&b.obs, (size_t)6 * n * 4)); HIP_OK(hipMalloc(&b.action, (size_t)kRing * n * 4));
+        HIP_OK(hipMalloc((void **)&b.reward, (size_t)n * 4)); HIP_OK(hipMalloc((void **)&b.done, (size_t)n)); HIP_OK(hipMalloc((void **)&b.tick2, 16));
+        HIP_OK(hipMemsetAsync(b.state, 0, (size_t)4 * n * 4, st)); HIP_OK(hipMemsetAsync(b.obs, 0, (size_t)6 * n * 4, st));
+        std::vector<uint32_t> act = host_actions(n, false, 3);
+        HIP_OK(hipMemcpyAsync(b.action, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(b.tick2, 0, 16, st));
+        HIP_OK(hipStreamSynchronize(st));
+        uint64_t tick = 0;
+        auto time_pairs = [&](auto items_tag, auto pack_tag) {
+            constexpr int I = decltype(items_tag)::value;
+            constexpr bool P = decltype(pack_tag)::value;
+            auto a = make_args<Acrobot>(b, n);
+            const dim3 grid((unsigned)(n / (2 * I * 256))), blk(256);
+            hipEvent_t e0, e1;
+            HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+            HIP_OK(hipEventRecord(e0, st));
+            for (int i = 0; i < launches; ++i) {
+                a.parity = (int32_t)(tick & 1); a.cparity = a.parity;
+                a.action = static_cast<const char *>(b.action) + (int64_t)(tick % kRing) * n * 4;
+                hipLaunchKernelGGL((probe_pairs<Acrobot, I, 15, P>), grid, blk, 0, st, a);
+                ++tick;
+            }
+            HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipEventSynchronize(e1));
+            float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+            return (double)ms * 1000.0 / launches;
+        };
+        std::vector<double> t[7];
+        const LaunchCfg dflt{1, 256, 15, 0, 4, 0, 0};
+        time_launches<Acrobot>(b, n, dflt, 300, st, tick);
+        for (int q = 0; q < rounds; ++q) {
+            t[0].push_back(time_launches<Acrobot>(b, n, dflt, launches, st, tick));
+            t[1].push_back(time_pairs(std::integral_constant<int, 2>{}, std::false_type{}));
+            t[2].push_back(time_pairs(std::integral_constant<int, 2>{}, std::true_type{}));
+            t[3].push_back(time_pairs(std::integral_constant<int, 4>{}, std::false_type{}));
+            t[4].push_back(time_pairs(std::integral_constant<int, 4>{}, std::true_type{}));
+            t[5].push_back(time_pairs(std::integral_constant<int, 1>{}, std::true_type{}));
+            t[6].push_back(time_pairs(std::integral_constant<int, 8>{}, std::true_type{}));
+        }
+        const char *names[] = {"library default: step_kernel_pipe<Acrobot,4> (4 scalar lanes per thread)", "2 pairs per thread, lane after lane", "2 pairs per thread, PACKED",
+                               "4 pairs per thread, lane after lane", "4 pairs per thread, PACKED", "1 pair per thread, PACKED", "8 pairs per thread, PACKED"};
+        std::printf("Acrobot, %lld lanes, us per launch:\n", (long long)n);
+        for (int i = 0; i < 7; ++i) std::printf("   %-78s %7.3f  [%.3f, %.3f]\n", names[i], median(t[i]), *std::min_element(t[i].begin(), t[i].end()), *std::max_element(t[i].begin(), t[i].end()));
         return 0;
     }
     if (argc > 4 && std::strcmp(argv[4], "ntmask") == 0) {
