@@ -45,7 +45,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
  ARRAY_FINISHED_LENGTH, ARRAY_FINAL_OBS, ARRAY_LANE_SEEDS) = range(9)
 
 GATHER_NONE, GATHER_DIRECT, GATHER_RCCL = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Config(C.Structure):

@@ -224,7 +224,7 @@ void default_policy(gymnet_vecenv *h) {
         // reset_form 1 (two lanes per reset in the wave-compacted form, step_kernels.hpp) for the one-shot kernel and the fused rollout:
         // one-shot 13.7 -> 13.4 us at 2^20 lanes, bookkeeping rollout 7.5 -> 6.9 us per step, lean rollout 5.9 -> 6.0
         // (profiles/rollout_reset_forms_r05.txt); the multi-pair kernel below always draws once per thread-group of pairs
-        h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, can2 ? 1 : 0, 0};
+        h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, can2 ? 1 : 0, 0, h->simds};
         if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
         // The multi-pair kernel (step_kernel_pipe2<CartPole64, k>: a thread owns k lane pairs, all loads first, then advance pair after
         // pair, ONE wave-compacted reset for all of them, then the state rows) wins where it runs as two or three waves on every
@@ -237,7 +237,7 @@ void default_policy(gymnet_vecenv *h) {
         if (can2 && h->n >= ((int64_t)3 << 18)) {            // (below: ramp-bound, fewer and fatter waves lose)
             for (int items : {4, 2}) {
                 if (!h->autoreset && h->n % ((int64_t)512 * items) != 0) continue;     // (the auto-reset form takes any batch size)
-                const double waves_per_simd = (double)((h->n + 128 * items - 1) / ((int64_t)128 * items)) / 1024.0;      // MI355X: 256 CUs x 4 SIMDs
+                const double waves_per_simd = (double)((h->n + 128 * items - 1) / ((int64_t)128 * items)) / (double)h->simds;   // MI355X: 256 CUs x 4 SIMDs
                 // NOT one wave more: the kernel holds 191 VGPRs, two waves per SIMD are resident, and a 2049th wave starts when an
                 // earlier one has finished — 2^20 + 2 lanes: 19.2 us against 11.1 (profiles/f64_sizes_r05.txt, second table)
                 if ((waves_per_simd >= 1.9 && waves_per_simd <= 2.0) || (waves_per_simd >= 2.85 && waves_per_simd <= 3.0)) { h->lcfg.items = items; break; }
@@ -258,12 +258,13 @@ void default_policy(gymnet_vecenv *h) {
     //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
     const size_t step_bytes = (size_t)h->n * (size_t)d.algorithmic_bytes;
     const bool alu_bound = cfg->env_id == GYMNET_ENV_ACROBOT;
+    h->lcfg.simds = h->simds;
     // Round 5: the small-batch rule is a LANE count, not a byte count.  Scalar lanes win while the launch is ONE resident generation
     // of waves — n <= 8 waves x 1024 SIMDs x 64 lanes = 2^19 — and lose beyond it (a second generation of 64-lane waves starts when the
     // first retires); the byte threshold had been fitted on CartPole alone (2^19 lanes = 21.5 MB) and kept MountainCar (25 B per lane)
     // on scalar lanes up to 10^6 lanes: 5.53 us against 4.53 with 16-byte lanes; 3 * 2^18 lanes 4.35 against 3.93
     // (profiles/small_batches_r05.txt; CartPole and Pendulum cross over at the same lane count).
-    const bool one_generation = h->n <= ((int64_t)8 * 1024 * 64);
+    const bool one_generation = h->n <= ((int64_t)8 * h->simds * 64);
     if (alu_bound || one_generation) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
     else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
     else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
@@ -768,6 +769,12 @@ int gymnet_vecenv_create(const gymnet_config *cfg, gymnet_vecenv **out) {
     } while (0)
 
     CREATE_HIP(hipSetDevice(h->device));
+    {   // SIMD units of this device: the launch policy's waves-per-SIMD arithmetic (default_policy) and the looped multi-pair kernel's
+        // resident generation (pipe2_shape) are sized from the device the handle lives on, not from an MI355X literal
+        int cus = 0;
+        CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->simds = cus > 0 ? cus * 4 : 1024;
+    }
     if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); }
     else { CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
 

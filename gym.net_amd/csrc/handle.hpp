@@ -105,6 +105,7 @@ struct gymnet_vecenv {
     int last_cparity = -1;
     bool async_pending = false;
     std::atomic<bool> busy{false};
+    int simds = 1024;              // SIMD units of the device (multiProcessorCount x 4), read at create
     gymnet::LaunchCfg lcfg{4, 256, 0, 0, 1};
     int graph_mode = -1;           // gymnet_launch_policy.graph: -1 = by batch size, 0 = eager launches, 1 = hipGraph replay
     bool can_vec4 = false, can_vec2 = false, lds_ok = false;   // what the buffers' alignment / the batch size allow (set at create)

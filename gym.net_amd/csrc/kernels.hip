@@ -210,103 +210,131 @@ __global__ __launch_bounds__(256) void validate_discrete_kernel(const int32_t *_
     if (m && lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(bad, (uint32_t)__popcll(m));
 }
 
-// Discrete.Sample() (Discrete.cs:17-28, no mask): start + randint(0, n)
+// ---- stand-alone space sampling: action stream v2 (philox.hpp) ------------------------------------------------------------------
+// One thread per GROUP of four consecutive GLOBAL lanes (the lanes that share a Philox call): thread t of a launch serves group
+// (lane_offset >> 2) + t, whose first lane has local index i0 = 4 t - (lane_offset & 3) — negative for a batch that starts inside a
+// group; elements outside [0, n) are not written.  A whole group that lies inside the batch on a 16-byte aligned address leaves as
+// one dwordx4 store.
+struct LaneGroup { uint64_t group; int64_t i0; };
+__device__ __forceinline__ LaneGroup my_lane_group(uint64_t lane_offset) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    return LaneGroup{(lane_offset >> 2) + (uint64_t)t, 4 * t - (int64_t)(lane_offset & 3u)};
+}
+
+template <class T>
+__device__ __forceinline__ void store_group(T *__restrict__ out, int64_t i0, int64_t n, const T (&v)[4]) {
+    typedef typename VecOf<T, 4>::type V;
+    if (i0 >= 0 && i0 + 4 <= n && (reinterpret_cast<uintptr_t>(out + i0) & 15u) == 0) {
+        *reinterpret_cast<V *>(out + i0) = V{v[0], v[1], v[2], v[3]};
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j >= 0 && i0 + j < n) out[i0 + j] = v[j];
+}
+
+// Discrete.Sample() (Discrete.cs:17-28, no mask): start + randint(0, n) = start + hi32(word A * n)
 __global__ __launch_bounds__(256) void sample_discrete_kernel(int32_t *__restrict__ out, int64_t n, int32_t nvals,
                                                               int32_t start, uint64_t seed, uint64_t lane_offset,
                                                               uint64_t tick) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
-    out[i] = start + (int32_t)__umulhi(r.w[0], (uint32_t)nvals);
+    const LaneGroup g = my_lane_group(lane_offset);
+    if (g.i0 >= n) return;
+    const PhiloxWords r = action_group_words(seed, g.group, tick);
+    int32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = start + (int32_t)__umulhi(r.w[j], (uint32_t)nvals);
+    store_group<int32_t>(out, g.i0, n, v);
 }
 
 // Discrete.Sample(mask) (Discrete.cs:18-26): valid = nonzero(mask == 1); any -> start + valid[choice(len(valid))], none -> start.
-// choice(k) = hi32(w0 * k) with the same Philox word the unmasked draw uses.  One row of `nvals` mask bytes per lane
+// choice(k) = hi32(word A * k) with the same Philox word the unmasked draw uses.  One row of `nvals` mask bytes per lane
 // (mask_stride = nvals) or one shared row (mask_stride = 0).
 __global__ __launch_bounds__(256) void sample_discrete_masked_kernel(int32_t *__restrict__ out, int64_t n, int32_t nvals, int32_t start,
                                                                      const uint8_t *__restrict__ mask, int64_t mask_stride,
                                                                      uint64_t seed, uint64_t lane_offset, uint64_t tick) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t *m = mask + i * mask_stride;
-    int32_t valid = 0;
-    for (int32_t k = 0; k < nvals; ++k) valid += m[k] == 1 ? 1 : 0;
-    int32_t pick = 0;
-    if (valid > 0) {
-        const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
-        int32_t want = (int32_t)__umulhi(r.w[0], (uint32_t)valid);     // index into the list of valid actions
-        for (int32_t k = 0; k < nvals; ++k) {
-            if (m[k] == 1) { if (want == 0) { pick = k; break; } --want; }
+    const LaneGroup g = my_lane_group(lane_offset);
+    if (g.i0 >= n) return;
+    const PhiloxWords r = action_group_words(seed, g.group, tick);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = g.i0 + j;
+        if (i < 0 || i >= n) continue;
+        const uint8_t *m = mask + i * mask_stride;
+        int32_t valid = 0;
+        for (int32_t k = 0; k < nvals; ++k) valid += m[k] == 1 ? 1 : 0;
+        int32_t pick = 0;
+        if (valid > 0) {
+            int32_t want = (int32_t)__umulhi(r.w[j], (uint32_t)valid);     // index into the list of valid actions
+            for (int32_t k = 0; k < nvals; ++k) {
+                if (m[k] == 1) { if (want == 0) { pick = k; break; } --want; }
+            }
         }
+        out[i] = start + pick;
     }
-    out[i] = start + pick;
 }
 
 // The caller's epsilon-greedy composer (examples/.../PlaySessions/TrainingPlaySession.cs:46-52), batched:
 //   if (Random.NextDouble() <= epsilon) action = ActionSpace.Sample(); else action = policy action
-// Lane i uses the ACTION stream of Philox(seed, (lane_offset + i, tick)): word 0 is the sampled action (identical to sample_discrete_kernel),
-// word 1 the 24-bit uniform that is compared with epsilon.
+// Lane i: word A is the sampled action (identical to sample_discrete_kernel for the same seed / tick), word B the 24-bit uniform
+// that is compared with epsilon.
 __global__ __launch_bounds__(256) void compose_discrete_kernel(const int32_t *__restrict__ policy, int32_t *__restrict__ out,
                                                                int64_t n, int32_t nvals, float epsilon, uint64_t seed,
                                                                uint64_t lane_offset, uint64_t tick) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
-    const bool explore = u01_24(r.w[1]) <= epsilon;
-    out[i] = explore ? (int32_t)__umulhi(r.w[0], (uint32_t)nvals) : policy[i];
+    const LaneGroup g = my_lane_group(lane_offset);
+    if (g.i0 >= n) return;
+    const PhiloxWords r = action_group_words(seed, g.group, tick), c = aux_group_words(seed, g.group, tick);
+    int32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = g.i0 + j;
+        const int32_t pol = policy[i < 0 ? 0 : i < n ? i : n - 1];       // clamped: a lane outside the batch stores nothing
+        v[j] = u01_24(c.w[j]) <= epsilon ? (int32_t)__umulhi(r.w[j], (uint32_t)nvals) : pol;
+    }
+    store_group<int32_t>(out, g.i0, n, v);
 }
 
-// Box.Sample() (Box.cs:69-90): the reference's four regimes, selected by which bounds are finite
+// Box.Sample() of one element (Box.cs:69-90): the reference's four regimes, selected by which bounds are finite.  wa = the
+// element's word A; the unbounded regime alone needs a second uniform — word B, fetched through `wb()` only there.
+template <class AuxWord>
+__device__ __forceinline__ float box_sample_value(float low, float high, uint32_t wa, AuxWord wb) {
+    const bool blo = low > -INFINITY, bhi = high < INFINITY;     // Box.CheckBounded (Box.cs:53-58)
+    const float u = u01_24(wa);
+    if (blo && bhi) return low + (high - low) * u;                // Box.cs:85 uniform(low, high)
+    if (blo) return -logf(1.0f - u) + low;                        // Box.cs:83 exponential(1) + low
+    if (bhi) return -logf(1.0f - u) + high;                       // Box.cs:84 exponential(1) + high (sic)
+    const float u1 = (float)((wa >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = u01_24(wb());
+    return 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
+}
+
+// Box.Sample() with scalar bounds (the four envs' action spaces): one regime for the launch
 __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out, int64_t n, float low, float high,
                                                          uint64_t seed, uint64_t lane_offset, uint64_t tick) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PhiloxWords r = stream_words(kStreamAction, seed, lane_offset + (uint64_t)i, tick);
-    const bool blo = low > -INFINITY, bhi = high < INFINITY;     // Box.CheckBounded (Box.cs:53-58)
-    const float u = u01_24(r.w[0]);
-    float v;
-    if (blo && bhi) {
-        v = low + (high - low) * u;                               // Box.cs:85 uniform(low, high)
-    } else if (blo) {
-        v = -logf(1.0f - u) + low;                                // Box.cs:83 exponential(1) + low
-    } else if (bhi) {
-        v = -logf(1.0f - u) + high;                               // Box.cs:84 exponential(1) + high (sic)
-    } else {
-        const float u1 = (float)((r.w[0] >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
-        const float u2 = u01_24(r.w[1]);
-        v = 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
-    }
-    out[i] = v;
+    const LaneGroup g = my_lane_group(lane_offset);
+    if (g.i0 >= n) return;
+    const PhiloxWords r = action_group_words(seed, g.group, tick);
+    PhiloxWords c{};
+    if (!(low > -INFINITY) && !(high < INFINITY)) c = aux_group_words(seed, g.group, tick);     // launch-uniform
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = box_sample_value(low, high, r.w[j], [&]() { return c.w[j]; });
+    store_group<float>(out, g.i0, n, v);
 }
 
 // Box.Sample() for a Box whose Low / High are ARRAYS (Box.cs:25-51): the regime is chosen PER ELEMENT from that element's own
 // bounds (Box.cs:74-85: unbounded / low-bounded / high-bounded / bounded masks), `dim` elements per lane, output row-major
-// [count][dim].  Element e of lane i draws from Philox(key = action-stream key + e * odd constant, counter = (lane, tick)):
-// element 0 uses exactly the words of the scalar sampler above, so a (1,)-shaped Box samples the same values either way.
+// [count][dim].  Element e of lane i draws words A / B of the stream keyed by seed + e * odd constant: element 0 uses exactly the
+// words of the scalar sampler above, so a (1,)-shaped Box samples the same values either way.  One thread per ELEMENT (coalesced
+// row-major stores), each making its group's call and keeping its own word: a utility (ObservationSpace.Sample()), not a hot path.
 __global__ __launch_bounds__(256) void sample_box_elementwise_kernel(float *__restrict__ out, int64_t n, int32_t dim,
                                                                      const float *__restrict__ low, const float *__restrict__ high,
                                                                      uint64_t seed, uint64_t lane_offset, uint64_t tick) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per ELEMENT: coalesced row-major stores
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * dim) return;
     const int64_t i = idx / dim;
     const int32_t e = (int32_t)(idx - i * dim);
-    const PhiloxWords r = stream_words(kStreamAction, seed + (uint64_t)e * 0xD1B54A32D192ED03ull, lane_offset + (uint64_t)i, tick);
-    const float lo = low[e], hi = high[e];
-    const bool blo = lo > -INFINITY, bhi = hi < INFINITY;           // Box.CheckBounded (Box.cs:53-58)
-    const float u = u01_24(r.w[0]);
-    float v;
-    if (blo && bhi) {
-        v = lo + (hi - lo) * u;                                     // Box.cs:85 uniform(low, high)
-    } else if (blo) {
-        v = -logf(1.0f - u) + lo;                                   // Box.cs:83 exponential(1) + low
-    } else if (bhi) {
-        v = -logf(1.0f - u) + hi;                                   // Box.cs:84 exponential(1) + high (sic)
-    } else {
-        const float u1 = (float)((r.w[0] >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
-        const float u2 = u01_24(r.w[1]);
-        v = 0.5f + sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);    // Box.cs:82 normal(0.5, 1) (sic)
-    }
-    out[idx] = v;
+    const uint64_t key = seed + (uint64_t)e * 0xD1B54A32D192ED03ull, lane = lane_offset + (uint64_t)i;
+    out[idx] = box_sample_value(low[e], high[e], action_word(key, lane, tick), [&]() { return aux_word(key, lane, tick); });
 }
 
 // Direct (full-mesh) all-gather of observations, push form: this member's slice [D][N/G] is stored into
@@ -333,6 +361,8 @@ __global__ __launch_bounds__(256) void push_obs_kernel(const PushArgs a) {
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(int64_t items, int block) { return (unsigned)((items + block - 1) / block); }
+// workgroups of a stand-alone sampler launch: one thread per group of four global lanes (my_lane_group)
+static inline unsigned group_grid(int64_t n, uint64_t lane_offset) { return grid_for((n + (int64_t)(lane_offset & 3u) + 3) / 4, 256); }
 
 hipError_t launch_step(int env_id, bool autoreset, bool extras, const StepArgsT<float> &a, LaunchCfg cfg, hipStream_t st) {
     switch (env_id) {
@@ -517,7 +547,7 @@ hipError_t launch_validate_discrete(const int32_t *a, int64_t n, int32_t nvals, 
 hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_t start, uint64_t seed,
                                   uint64_t lane_offset, uint64_t tick, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sample_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, seed,
+    hipLaunchKernelGGL(sample_discrete_kernel, dim3(group_grid(n, lane_offset)), dim3(256), 0, st, out, n, nvals, start, seed,
                        lane_offset, tick);
     return hipGetLastError();
 }
@@ -525,7 +555,7 @@ hipError_t launch_sample_discrete(int32_t *out, int64_t n, int32_t nvals, int32_
 hipError_t launch_sample_discrete_masked(int32_t *out, int64_t n, int32_t nvals, int32_t start, const uint8_t *mask,
                                          int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sample_discrete_masked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, nvals, start, mask,
+    hipLaunchKernelGGL(sample_discrete_masked_kernel, dim3(group_grid(n, lane_offset)), dim3(256), 0, st, out, n, nvals, start, mask,
                        mask_stride, seed, lane_offset, tick);
     return hipGetLastError();
 }
@@ -551,7 +581,7 @@ hipError_t launch_sample_box_elementwise(float *out, int64_t n, int32_t dim, con
 hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t n, int32_t nvals, float epsilon, uint64_t seed,
                                    uint64_t lane_offset, uint64_t tick, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(compose_discrete_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, policy, out, n, nvals, epsilon, seed,
+    hipLaunchKernelGGL(compose_discrete_kernel, dim3(group_grid(n, lane_offset)), dim3(256), 0, st, policy, out, n, nvals, epsilon, seed,
                        lane_offset, tick);
     return hipGetLastError();
 }
@@ -559,7 +589,7 @@ hipError_t launch_compose_discrete(const int32_t *policy, int32_t *out, int64_t 
 hipError_t launch_sample_box(float *out, int64_t n, float low, float high, uint64_t seed, uint64_t lane_offset,
                              uint64_t tick, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sample_box_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, low, high, seed,
+    hipLaunchKernelGGL(sample_box_kernel, dim3(group_grid(n, lane_offset)), dim3(256), 0, st, out, n, low, high, seed,
                        lane_offset, tick);
     return hipGetLastError();
 }

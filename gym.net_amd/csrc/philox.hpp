@@ -33,11 +33,37 @@ __host__ __device__ __forceinline__ PhiloxWords lane_words(uint64_t seed, uint64
 }
 
 // Independent streams by purpose: reset draws use the caller's key unchanged (stream 0); space sampling and the
-// epsilon-greedy composer (action stream) XOR a constant into it, so ActionSpace.Sample() with the env's own (seed, tick) can
-// never replay the words that produced a reset state.
-constexpr uint64_t kStreamReset = 0ull, kStreamAction = 0x9E3779B97F4A7C15ull;
+// epsilon-greedy composer XOR a constant into it, so ActionSpace.Sample() with the env's own (seed, tick) can never replay the
+// words that produced a reset state.
+//
+// ACTION STREAM v2 (ABI 6).  A sampled action consumes ONE 32-bit word, a Philox4x32-10 call yields four: the call is
+// therefore shared by the four consecutive GLOBAL lanes of a group,
+//     word A of global lane L at tick t = word (L & 3) of Philox(key = seed ^ kStreamAction, counter = (L >> 2, t))
+//     word B of global lane L at tick t = word (L & 3) of Philox(key = seed ^ kStreamAux,    counter = (L >> 2, t))
+// A is the ActionSpace.Sample() word (Discrete.cs:27 randint, Box.cs:85 uniform, the first uniform of the other Box regimes); B is
+// the second word of the consumers that need one (the epsilon-greedy coin of TrainingPlaySession.cs:46, the second uniform of
+// Box.cs:82's normal) and is only drawn by them.  A thread that owns four aligned lanes (the dwordx4 forms) pays one call per step
+// instead of four; v1 drew a whole call per lane (counter (L, t)) and used words 0 and 1 of it.
+constexpr uint64_t kStreamReset = 0ull, kStreamAction = 0x9E3779B97F4A7C15ull, kStreamAux = 0xD6E8FEB86659FD93ull;
 __host__ __device__ __forceinline__ PhiloxWords stream_words(uint64_t stream, uint64_t seed, uint64_t lane, uint64_t tick) {
     return lane_words(seed ^ stream, lane, tick);
+}
+// the four A (or B) words of the group of global lanes 4 * group .. 4 * group + 3
+__host__ __device__ __forceinline__ PhiloxWords action_group_words(uint64_t seed, uint64_t group, uint64_t tick) {
+    return stream_words(kStreamAction, seed, group, tick);
+}
+__host__ __device__ __forceinline__ PhiloxWords aux_group_words(uint64_t seed, uint64_t group, uint64_t tick) {
+    return stream_words(kStreamAux, seed, group, tick);
+}
+// word (L & 3) of a group's call, for the forms that serve one lane at a time
+__host__ __device__ __forceinline__ uint32_t word_of(const PhiloxWords &r, uint32_t k) {
+    return k == 0 ? r.w[0] : k == 1 ? r.w[1] : k == 2 ? r.w[2] : r.w[3];
+}
+__host__ __device__ __forceinline__ uint32_t action_word(uint64_t seed, uint64_t lane, uint64_t tick) {
+    return word_of(action_group_words(seed, lane >> 2, tick), (uint32_t)lane & 3u);
+}
+__host__ __device__ __forceinline__ uint32_t aux_word(uint64_t seed, uint64_t lane, uint64_t tick) {
+    return word_of(aux_group_words(seed, lane >> 2, tick), (uint32_t)lane & 3u);
 }
 
 // 24-bit uniform in [0,1): exactly representable in binary32

@@ -734,10 +734,17 @@ __device__ __forceinline__ void pipe2_split_body(const StepArgsT<typename Env::R
     }
 }
 
+// Round 6 — GENERATIONS.  Beyond the lanes its resident waves hold (two waves per SIMD x 1024 SIMDs x 512 lanes = 2^20 for the four-pair
+// float64 kernel) a launch used to run as several hardware-scheduled generations of workgroups, each new workgroup waiting for four
+// wave slots (one per SIMD of a CU) to drain: 2^21 lanes 29.6 us, worse than the one-shot kernel's 27.7 (profiles/f64_sizes_r05.txt).
+// The form with the deferred reset now LOOPS instead: the grid stays at one resident generation (the launcher balances it,
+// grid = ceil(workgroups / gens)), and every thread walks `gens` groups of ITEMS pairs, generation g at pair offset g * ITEMS * T.
+// No workgroup is ever launched into a draining chip, the waves drift apart so that one wave's stores overlap its neighbour's
+// loads, and the per-launch ramp is paid once.  Same pairs, same counters: bit-identical.
 template <class Env, int ITEMS, bool AUTORESET, int NT>
 // (No occupancy hint: the float64 four-pair kernel holds 185 VGPRs = two waves per SIMD; capped at 168 for three it spills 48 bytes and
 // runs at 14.0 instead of 11.1 us per 2^20-lane step — profiles/occupancy_hints_r05.txt.)
-__global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
+__global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a, const int gens) {
     const uint64_t tick = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
@@ -745,10 +752,15 @@ __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typenam
     if constexpr (AUTORESET && has_split_reset<Env>()) {
         __shared__ DeferScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
         DeferScratch<Env> *sc = &scratch[threadIdx.x >> 6];
-        // ANY batch size: the grid is ceil(n / (2 * ITEMS * block)) workgroups; a workgroup whose last pair of its last item lies
-        // inside the batch runs the unguarded body (workgroup-uniform), the batch's last few run the guarded one
-        if ((((int64_t)blockIdx.x + 1) * blockDim.x + (int64_t)(ITEMS - 1) * T) * 2 <= a.n) pipe2_split_body<Env, ITEMS, NT, false>(a, t, T, tick, sc);
-        else pipe2_split_body<Env, ITEMS, NT, true>(a, t, T, tick, sc);
+        // ANY batch size: gens * gridDim.x workgroup-generations cover ceil(n / (2 * ITEMS * block)) groups; a workgroup whose last pair
+        // of its last item lies inside the batch runs the unguarded body (workgroup-uniform), the batch's last few the guarded one
+        for (int g = 0; g < gens; ++g) {
+            const int64_t g0 = (int64_t)g * ITEMS * T;             // pair offset of generation g
+            const int64_t wg0 = g0 + (int64_t)blockIdx.x * blockDim.x;
+            if (wg0 * 2 >= a.n) break;                             // this workgroup's share of the generation is past the end
+            if ((wg0 + blockDim.x + (int64_t)(ITEMS - 1) * T) * 2 <= a.n) pipe2_split_body<Env, ITEMS, NT, false>(a, g0 + t, T, tick, sc);
+            else pipe2_split_body<Env, ITEMS, NT, true>(a, g0 + t, T, tick, sc);
+        }
         return;
     }
     LaneInputs<Env, 2> in[ITEMS];
@@ -762,6 +774,20 @@ __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typenam
         }
         advance_and_store<Env, 2, AUTORESET, false, NT, false, 0, false>(a, (t + k * T) * 2, tick, in[k]);
     }
+}
+
+// How the multi-pair kernel's launch is shaped: `gens` generations walked by a grid of ONE resident generation.  A workgroup is four
+// waves, one per SIMD of a CU, so the chip holds (SIMDs / 4) x (waves per SIMD the kernel's registers allow) of them at once: two for
+// the four-pair float64 kernel (185 VGPRs), three for fewer pairs (tests/test_kernel_resources.py asserts both).
+struct Pipe2Shape { unsigned grid; int gens; };
+template <class Env>
+static Pipe2Shape pipe2_shape(int64_t n, int items, int block, bool looped, int simds) {
+    const int64_t per_block = 2 * (int64_t)items * block;
+    const int64_t wgs = n > 0 ? (n + per_block - 1) / per_block : 1;
+    if (!looped) return Pipe2Shape{(unsigned)wgs, 1};
+    const int64_t resident = (int64_t)(simds > 0 ? simds : 1024) / 4 * (items >= 4 ? 2 : 3) * (256 / block);
+    const int64_t gens = (wgs + resident - 1) / resident;
+    return Pipe2Shape{(unsigned)((wgs + gens - 1) / gens), (int)gens};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -901,12 +927,50 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgsT<typename Env:
 // CartPole, and the load-phase / store-phase serialisation of the one-step kernel disappears.  The next step's
 // action is loaded before the current step's math.  Results are bit-identical to T one-step launches.
 // ---------------------------------------------------------------------------------------------
-// ActionSpace.Sample() of one lane for one step, drawn in the kernel: the words of sample_discrete_kernel / sample_box_kernel
-// (kernels.hip) for the same (seed, global lane, tick) — word 0 is the action, word 1 the epsilon-greedy coin (compose_discrete_kernel).
+// ActionSpace.Sample() of one lane for one step, drawn in the kernel from the lane's word A of the action stream (philox.hpp, action
+// stream v2): the value sample_discrete_kernel / sample_box_kernel (kernels.hip) write for the same (seed, global lane, tick); word B
+// is the epsilon-greedy coin (compose_discrete_kernel).
 template <class Env>
-__device__ __forceinline__ typename Env::Action sampled_action(const PhiloxWords &r) {
-    if constexpr (Env::BOX_ACTION) return Env::ACTION_LOW + (Env::ACTION_HIGH - Env::ACTION_LOW) * u01_24(r.w[0]);     // Box.cs:85
-    else return (int32_t)__umulhi(r.w[0], (uint32_t)Env::ACTION_N);                                                    // Discrete.cs:27
+__device__ __forceinline__ typename Env::Action sampled_action(uint32_t word_a) {
+    if constexpr (Env::BOX_ACTION) return Env::ACTION_LOW + (Env::ACTION_HIGH - Env::ACTION_LOW) * u01_24(word_a);     // Box.cs:85
+    else return (int32_t)__umulhi(word_a, (uint32_t)Env::ACTION_N);                                                    // Discrete.cs:27
+}
+
+// Words A (and, if asked, B) of a thread's VEC consecutive lanes gl0 .. gl0 + VEC - 1.  `one_group` (kernel-uniform: the handle's
+// lane offset is a multiple of VEC, so gl0 is) = the lanes lie in ONE group of four and share its Philox call: a dwordx4 thread pays
+// one call per step for its four actions where v1 paid four.  Otherwise (a shard that starts inside a group) every lane makes its
+// group's call and keeps its own word — the same words, four times the arithmetic.
+template <int VEC>
+__device__ __forceinline__ void thread_action_words(uint64_t seed, uint64_t gl0, uint64_t tick, bool want_aux, bool one_group,
+                                                    uint32_t (&wa)[VEC], uint32_t (&wb)[VEC]) {
+    static_assert(VEC == 1 || VEC == 2 || VEC == 4, "a thread's lanes must fit one group of four");
+    if (one_group) {
+        const PhiloxWords r = action_group_words(seed, gl0 >> 2, tick);
+        PhiloxWords c{};
+        if (want_aux) c = aux_group_words(seed, gl0 >> 2, tick);
+        const uint32_t base = (uint32_t)gl0 & 3u;
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wa[j] = r.w[j]; wb[j] = c.w[j]; }
+        } else if constexpr (VEC == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { wa[j] = base ? r.w[2 + j] : r.w[j]; wb[j] = base ? c.w[2 + j] : c.w[j]; }
+        } else {
+            wa[0] = word_of(r, base); wb[0] = word_of(c, base);
+        }
+    } else {
+        // one copy of the call in the instruction stream (a rolled loop; the results go to their registers through selects on the
+        // loop index, not through a dynamic index): the fast path above is the one that runs, this one only has to stay small
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { wa[j] = 0u; wb[j] = 0u; }
+#pragma unroll 1
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t a = action_word(seed, gl0 + (uint64_t)j, tick);
+            const uint32_t b = want_aux ? aux_word(seed, gl0 + (uint64_t)j, tick) : 0u;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { wa[k] = k == j ? a : wa[k]; wb[k] = k == j ? b : wb[k]; }
+        }
+    }
 }
 
 //   EXTRAS  bookkeeping handle (EPISODE_STATS / DONE_LIST / FINAL_OBS / per-lane seeds): running return / length in registers,
@@ -942,6 +1006,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     Act act[VEC], act_next[VEC];
     // the ring is read unless every action is sampled; epsilon-greedy (action_source 2) reads it as the POLICY's actions
     bool use_ring = true;                                          // kernel-uniform
+    const bool one_group = (a.lane_offset % (uint64_t)VEC) == 0;   // kernel-uniform: the thread's lanes share one action-stream call
     if constexpr (SAMPLE) {
         use_ring = ro.action_source == 2;
 #pragma unroll
@@ -995,12 +1060,13 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
         if (nslice == ro.ring) nslice = 0;
         if constexpr (SAMPLE) {
             if (use_ring && t + 1 < ro.steps) load_action(nslice, act_next);
+            uint32_t wa[VEC], wb[VEC];
+            thread_action_words<VEC>(ro.action_seed, a.lane_offset + (uint64_t)i0, ro.action_tick0 + (uint64_t)t, use_ring, one_group, wa, wb);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const PhiloxWords r = stream_words(kStreamAction, ro.action_seed, a.lane_offset + (uint64_t)(i0 + j), ro.action_tick0 + (uint64_t)t);
-                const Act drawn = sampled_action<Env>(r);
+                const Act drawn = sampled_action<Env>(wa[j]);
                 if constexpr (Env::BOX_ACTION) act[j] = drawn;                   // (epsilon-greedy is defined for Discrete spaces)
-                else act[j] = (ro.action_source == 2 && !(u01_24(r.w[1]) <= ro.epsilon)) ? act[j] : drawn;   // TrainingPlaySession.cs:46-52
+                else act[j] = (use_ring && !(u01_24(wb[j]) <= ro.epsilon)) ? act[j] : drawn;   // TrainingPlaySession.cs:46-52
             }
         } else {
             if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math
@@ -1394,12 +1460,12 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
         if (v.pipe_pairs) {
             // whole groups of 2 * items * 256 lanes (resolve_variant: any workgroup size divides the batch) — or, for the form with
             // the deferred reset, any batch: the last workgroups run the guarded body
-            const int64_t per_block = 2 * (int64_t)v.pipe_items * cfg.block;
-            const dim3 qgrid((unsigned)((a.n + per_block - 1) / per_block)), qblk(cfg.block);
+            const Pipe2Shape shape = pipe2_shape<Env>(a.n, v.pipe_items, cfg.block, has_split_reset<Env>() && autoreset, cfg.simds);
+            const dim3 qgrid(shape.grid), qblk(cfg.block);
 #define GYMNET_PIPE2(I)                                                                                                 \
     case I:                                                                                                             \
-        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a);                 \
-        else hipLaunchKernelGGL((step_kernel_pipe2<Env, I, false, 15>), qgrid, qblk, 0, st, a);                          \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a, shape.gens);     \
+        else hipLaunchKernelGGL((step_kernel_pipe2<Env, I, false, 15>), qgrid, qblk, 0, st, a, shape.gens);              \
         break;
             switch (v.pipe_items) {
                 GYMNET_PIPE2(2) GYMNET_PIPE2(3) GYMNET_PIPE2(4)

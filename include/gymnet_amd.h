@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define GYMNET_ABI_VERSION 5   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
+#define GYMNET_ABI_VERSION 6   /* 2: gymnet_config.d_ext_obs_alt, gymnet_device_view.{obs_buffer,d_obs_alt}, groups;
                                   3: gymnet_env_info.{traffic_bytes_per_step,state_row_in_obs}, per-element Box sampling, compact
                                      terminal observations, pinned host staging;
                                   4: GYMNET_FLAG_F64 (float64 CartPole: observation / state buffers typed by the handle,
@@ -59,7 +59,11 @@ extern "C" {
                                      COMPACT_RECORDS_ONLY / d_ext_obs(_alt) and with groups; every parameter that carries observation
                                      values (gymnet_config.d_ext_obs*, terminal observations, group replicas and host batches) is
                                      typed void* = the handle's state scalar (binary layout of the calls unchanged).  A launch-policy
-                                     value that would not take effect is rejected */
+                                     value that would not take effect is rejected;
+                                  6: ACTION STREAM v2 — no signature or struct changed, the VALUES every sampling entry point draws
+                                     did (see "batched space sampling" below): one Philox4x32-10 call now serves the four consecutive
+                                     global lanes of a group instead of one lane.  Reset draws, and therefore every result computed
+                                     from caller-supplied actions, are bit-for-bit what ABI 5 produced */
 
 typedef enum gymnet_status {
     GYMNET_OK = 0,
@@ -422,13 +426,20 @@ int gymnet_vecenv_episode_stats(gymnet_vecenv *h, float *finished_return, int32_
 int gymnet_vecenv_final_obs(gymnet_vecenv *h, void *final_obs_out);
 
 /* ---- batched space sampling (the step BEFORE the path: ActionSpace.Sample(), TrainingPlaySession.cs:46-49) -- */
-/* All sampling below draws from the ACTION stream: Philox key = seed ^ 0x9E3779B97F4A7C15, so ActionSpace.Sample() called
- * with an env's own (seed, tick) never replays the words of that env's reset draws (key = seed).
- * Discrete.Sample() without mask (Discrete.cs:17-28): start + randint(0, n).  Element i = start + hi32(w0 * n),
- * w0 = word 0 of Philox(action key, counter = (lane_offset + i, tick)). */
+/* All sampling below draws from the ACTION stream (version 2, ABI 6).  A sampled action consumes one 32-bit word and a
+ * Philox4x32-10 call yields four, so the four consecutive GLOBAL lanes of a group share one call:
+ *     word A of global lane L at tick t = word (L & 3) of Philox(key = seed ^ 0x9E3779B97F4A7C15, counter = (L >> 2, t))
+ *     word B of global lane L at tick t = word (L & 3) of Philox(key = seed ^ 0xD6E8FEB86659FD93, counter = (L >> 2, t))
+ * with L = lane_offset + i.  A is the ActionSpace.Sample() word; B is drawn only by the consumers that need a second word (the
+ * epsilon-greedy coin, the second uniform of Box.cs:82's normal).  Neither key is the reset draws' (key = seed), so
+ * ActionSpace.Sample() called with an env's own (seed, tick) never replays the words of that env's reset draws; values depend on
+ * the GLOBAL lane only, so a sharded batch samples what the whole batch would (any lane_offset, aligned to a group or not).
+ * (Version 1, ABI <= 5: a whole call per lane, counter (L, t), words 0 and 1.  The reference's own stream is NumSharp's
+ * un-vendored generator — CartPoleEnv.cs:49, Discrete.cs:17-28 — and is pinned by nothing)
+ * Discrete.Sample() without mask (Discrete.cs:17-28): start + randint(0, n).  Element i = start + hi32(word A * n). */
 int gymnet_sample_discrete_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
                                   uint64_t seed, uint64_t lane_offset, uint64_t tick);
-/* Discrete.Sample(mask) (Discrete.cs:18-26): valid = {k : mask[k] == 1}; none -> start, else start + valid[hi32(w0 * |valid|)].
+/* Discrete.Sample(mask) (Discrete.cs:18-26): valid = {k : mask[k] == 1}; none -> start, else start + valid[hi32(word A * |valid|)].
  * d_mask: device uint8, one row of n bytes per element (mask_stride = n) or ONE row shared by all elements (mask_stride = 0). */
 int gymnet_sample_discrete_masked_device(int device, void *stream, int32_t *d_out, int64_t count, int32_t n, int32_t start,
                                          const uint8_t *d_mask, int64_t mask_stride, uint64_t seed, uint64_t lane_offset, uint64_t tick);
@@ -453,7 +464,7 @@ int gymnet_vecenv_sample_actions_masked_device(gymnet_vecenv *h, int32_t *d_acti
                                                uint64_t seed, uint64_t tick);
 /* The caller's epsilon-greedy composer, batched (examples/ReinforcementLearning/ReinforcementLearning/PlaySessions/
  * TrainingPlaySession.cs:46-52: `if (Random.NextDouble() <= _epsilon) return ActionSpace.Sample(); return policy action`).
- * Lane i: u = 24-bit uniform from Philox word 1 of (seed, (global lane, tick)); out[i] = (u <= epsilon) ? the
+ * Lane i: u = 24-bit uniform from word B of (seed, global lane, tick); out[i] = (u <= epsilon) ? the
  * Discrete.Sample() draw of gymnet_vecenv_sample_actions_device for the same (seed, tick) : d_policy_actions[i].
  * Discrete action spaces only. */
 int gymnet_vecenv_compose_actions_device(gymnet_vecenv *h, const int32_t *d_policy_actions, float epsilon, int32_t *d_actions_out,

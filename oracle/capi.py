@@ -61,6 +61,7 @@ def lib():
     L.ref_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
     L.ref_reset_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u32p]
     L.ref_cartpole_reset_batch_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p, C.c_int64]
+    L.ref_action_words_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u32p, _u32p, C.c_int64]
     L.ref_discrete_sample_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _i32p, C.c_int64]
     L.ref_discrete_sample_masked_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _u8p, C.c_int64, _i32p, C.c_int64]
     L.ref_compose_discrete_batch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64]
@@ -201,6 +202,13 @@ def cartpole_reset(seed, lane0, tick, n):
     out = np.zeros((4, n), dtype=np.float32)
     lib().ref_cartpole_reset_batch_f32(seed, lane0, tick, out, n)
     return out
+
+
+def action_words(seed, lane0, tick, count):
+    """Words A and B of the action stream (version 2: one Philox call per group of four global lanes) for `count` lanes."""
+    a, b = np.zeros(count, dtype=np.uint32), np.zeros(count, dtype=np.uint32)
+    lib().ref_action_words_batch(seed, lane0, tick, a, b, count)
+    return a, b
 
 
 def discrete_sample(seed, lane0, tick, nvals, start, count):

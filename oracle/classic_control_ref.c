@@ -427,24 +427,42 @@ void ref_cartpole_autoreset_step_batch_f64(uint64_t seed, const uint64_t *lane_s
     }
 }
 
-/* Space sampling draws from the engine's ACTION stream: the same counter (lane, tick) but key = seed ^ 0x9E3779B97F4A7C15,
- * so ActionSpace.Sample() with an env's own (seed, tick) can never replay the words of that env's reset draw (key = seed). */
+/* Space sampling draws from the engine's ACTION stream, version 2 (csrc/philox.hpp): a sampled action consumes ONE 32-bit word
+ * and a Philox4x32-10 call yields four, so the four consecutive global lanes of a group share a call:
+ *     word A of global lane L at tick t = word (L & 3) of Philox(key = seed ^ 0x9E3779B97F4A7C15, counter = (L >> 2, t))
+ *     word B of global lane L at tick t = word (L & 3) of Philox(key = seed ^ 0xD6E8FEB86659FD93, counter = (L >> 2, t))
+ * A is the ActionSpace.Sample() word; B is the second word of the consumers that need one (the epsilon-greedy coin, the second
+ * uniform of Box.cs:82's normal).  The keys differ from the reset draws' (key = seed), so ActionSpace.Sample() with an env's own
+ * (seed, tick) can never replay the words of that env's reset draw.  (Version 1 made a whole call per lane, counter (L, t), and
+ * used its words 0 and 1.)  Written lane by lane on purpose — the kernels share the call per thread; the oracle recomputes it. */
 #define REF_ACTION_STREAM 0x9E3779B97F4A7C15ull
-void ref_action_words(uint64_t seed, uint64_t lane, uint64_t tick, uint32_t out[4]) {
-    ref_reset_words(seed ^ REF_ACTION_STREAM, lane, tick, out);
+#define REF_AUX_STREAM 0xD6E8FEB86659FD93ull
+uint32_t ref_action_word(uint64_t seed, uint64_t lane, uint64_t tick) {
+    uint32_t w[4];
+    ref_reset_words(seed ^ REF_ACTION_STREAM, lane >> 2, tick, w);
+    return w[lane & 3u];
+}
+uint32_t ref_aux_word(uint64_t seed, uint64_t lane, uint64_t tick) {
+    uint32_t w[4];
+    ref_reset_words(seed ^ REF_AUX_STREAM, lane >> 2, tick, w);
+    return w[lane & 3u];
+}
+/* both words of `count` consecutive lanes (tests cross-check them against the NumPy Philox twin) */
+void ref_action_words_batch(uint64_t seed, uint64_t lane0, uint64_t tick, uint32_t *word_a, uint32_t *word_b, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) {
+        word_a[i] = ref_action_word(seed, lane0 + (uint64_t)i, tick);
+        word_b[i] = ref_aux_word(seed, lane0 + (uint64_t)i, tick);
+    }
 }
 
 /* Discrete.Sample() — src/Gym/Spaces/Discrete.cs:17-28 (no mask): Start + randint(0, N).
- * Engine semantics: word 0 of the action stream at counter (lane, tick); value = start + hi32(w*n)
- * (Lemire multiply-shift; exact-uniform when n is a power of two). */
+ * Engine semantics: value = start + hi32(word A * n) (Lemire multiply-shift; exact-uniform when n is a power of two). */
 int32_t ref_discrete_sample(uint64_t seed, uint64_t lane, uint64_t tick, int32_t n, int32_t start) {
-    uint32_t w[4];
-    ref_action_words(seed, lane, tick, w);
-    return start + (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32);
+    return start + (int32_t)(((uint64_t)ref_action_word(seed, lane, tick) * (uint64_t)(uint32_t)n) >> 32);
 }
 
 /* Discrete.Sample(mask) — Discrete.cs:18-26: bmask = (mask == 1); any -> Start + choice(nonzero(bmask)); none -> Start.
- * Engine semantics: choice(k) = hi32(w0 * k) with the word the unmasked draw uses.  mask: one row of n bytes per lane
+ * Engine semantics: choice(k) = hi32(word A * k) with the word the unmasked draw uses.  mask: one row of n bytes per lane
  * (mask_stride = n) or one shared row (mask_stride = 0). */
 void ref_discrete_sample_masked_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, int32_t start,
                                       const uint8_t *mask, int64_t mask_stride, int32_t *out, int64_t count) {
@@ -453,9 +471,8 @@ void ref_discrete_sample_masked_batch(uint64_t seed, uint64_t lane0, uint64_t ti
         int32_t valid = 0, pick = 0;
         for (int32_t k = 0; k < n; ++k) valid += m[k] == 1;
         if (valid > 0) {
-            uint32_t w[4];
-            ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
-            int32_t want = (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)valid) >> 32);
+            const uint32_t wa = ref_action_word(seed, lane0 + (uint64_t)i, tick);
+            int32_t want = (int32_t)(((uint64_t)wa * (uint64_t)(uint32_t)valid) >> 32);
             for (int32_t k = 0; k < n; ++k)
                 if (m[k] == 1) { if (want == 0) { pick = k; break; } --want; }
         }
@@ -468,25 +485,22 @@ void ref_discrete_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int
     for (int64_t i = 0; i < count; ++i) out[i] = ref_discrete_sample(seed, lane0 + (uint64_t)i, tick, n, start);
 }
 
-/* The engine's batched epsilon-greedy composer (TrainingPlaySession.cs:46-52): explore iff u01_24(word 1) <= epsilon. */
+/* The engine's batched epsilon-greedy composer (TrainingPlaySession.cs:46-52): explore iff u01_24(word B) <= epsilon; the explored
+ * action is the Discrete.Sample() draw (word A) of the same (seed, lane, tick). */
 void ref_compose_discrete_batch(uint64_t seed, uint64_t lane0, uint64_t tick, int32_t n, float epsilon,
                                 const int32_t *policy, int32_t *out, int64_t count) {
     for (int64_t i = 0; i < count; ++i) {
-        uint32_t w[4];
-        ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
-        out[i] = u01_24(w[1]) <= epsilon ? (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32) : policy[i];
+        const uint64_t lane = lane0 + (uint64_t)i;
+        out[i] = u01_24(ref_aux_word(seed, lane, tick)) <= epsilon ? ref_discrete_sample(seed, lane, tick, n, 0) : policy[i];
     }
 }
 
 /* Box.Sample() bounded regime — src/Gym/Spaces/Box.cs:69-90: uniform(low, high). Engine
- * semantics (binary32): low + (high-low)*u with u = 24-bit uniform from Philox word 0. */
+ * semantics (binary32): low + (high-low)*u with u = 24-bit uniform from word A. */
 void ref_box_uniform_sample_batch(uint64_t seed, uint64_t lane0, uint64_t tick, float low, float high,
                                   float *out, int64_t count) {
-    for (int64_t i = 0; i < count; ++i) {
-        uint32_t w[4];
-        ref_action_words(seed, lane0 + (uint64_t)i, tick, w);
-        out[i] = low + (high - low) * u01_24(w[0]);
-    }
+    for (int64_t i = 0; i < count; ++i)
+        out[i] = low + (high - low) * u01_24(ref_action_word(seed, lane0 + (uint64_t)i, tick));
 }
 
 /* ------------------------------------------------------------------------------------------

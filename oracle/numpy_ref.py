@@ -105,6 +105,28 @@ def reset_words(seed, lanes, tick):
     return philox4x32_10(ctr, key)
 
 
+ACTION_STREAM = 0x9E3779B97F4A7C15
+AUX_STREAM = 0xD6E8FEB86659FD93
+
+
+def action_words(seed, lanes, tick):
+    """Words A and B of the engine's action stream, version 2 (csrc/philox.hpp): global lane L takes word (L & 3) of the call
+    with counter (L >> 2, tick), key seed ^ ACTION_STREAM (A: the ActionSpace.Sample() word) / seed ^ AUX_STREAM (B: the
+    epsilon-greedy coin, the normal regime's second uniform)."""
+    lanes = np.asarray(lanes, dtype=np.uint64)
+    pick = (lanes & np.uint64(3)).astype(np.intp)
+    idx = np.arange(lanes.shape[0])
+    a = reset_words(int(seed) ^ ACTION_STREAM, lanes >> np.uint64(2), tick)[pick, idx]
+    b = reset_words(int(seed) ^ AUX_STREAM, lanes >> np.uint64(2), tick)[pick, idx]
+    return a, b
+
+
+def discrete_sample(seed, lanes, tick, nvals, start=0):
+    """Discrete.Sample() (Discrete.cs:17-28): start + hi32(word A * n)."""
+    a, _ = action_words(seed, lanes, tick)
+    return (np.int64(start) + ((a.astype(np.uint64) * np.uint64(nvals)) >> np.uint64(32)).astype(np.int64)).astype(np.int32)
+
+
 def u01_24(words):
     return (words >> np.uint32(8)).astype(f32) * f32(1.0 / 16777216.0)
 

@@ -156,14 +156,20 @@ def other_envs(rng):
 
 
 def main():
+    """python make_golden.py [file stem ...] — all fixtures, or only the named ones (round 6 regenerated philox_resets alone, for
+    action stream v2: the draws of discrete3 / box_pm2 moved, the reset draws did not)."""
+    import sys
     capi.build()
     rng = np.random.default_rng(20261001)
-    np.savez_compressed(os.path.join(OUT, "cartpole_teacher_forced.npz"), **cartpole_teacher_forced(rng))
-    np.savez_compressed(os.path.join(OUT, "cartpole_edges.npz"), **cartpole_edges())
-    np.savez_compressed(os.path.join(OUT, "cartpole_steps_beyond_done.npz"), **cartpole_steps_beyond_done())
-    np.savez_compressed(os.path.join(OUT, "cartpole_reference_test_trace.npz"), **cartpole_reference_test_trace(rng))
-    np.savez_compressed(os.path.join(OUT, "philox_resets.npz"), **philox_and_resets())
-    np.savez_compressed(os.path.join(OUT, "other_envs.npz"), **other_envs(rng))
+    makers = [("cartpole_teacher_forced", lambda: cartpole_teacher_forced(rng)), ("cartpole_edges", cartpole_edges),
+              ("cartpole_steps_beyond_done", cartpole_steps_beyond_done),
+              ("cartpole_reference_test_trace", lambda: cartpole_reference_test_trace(rng)),
+              ("philox_resets", philox_and_resets), ("other_envs", lambda: other_envs(rng))]
+    only = set(sys.argv[1:])
+    for stem, make in makers:
+        data = make()                    # always evaluated: the makers share one generator, and its order fixes their inputs
+        if not only or stem in only:
+            np.savez_compressed(os.path.join(OUT, stem + ".npz"), **data)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -21,7 +21,7 @@ def test_header_symbols_are_all_exported(gymnet):
     assert not missing, missing
     # and the ctypes binding covers exactly the declared set
     assert declared == set(gymnet._capi.PROTOTYPES)
-    assert lib.gymnet_abi_version() == 5 == gymnet._capi.ABI_VERSION
+    assert lib.gymnet_abi_version() == 6 == gymnet._capi.ABI_VERSION
 
 
 def abi_manifest():

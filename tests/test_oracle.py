@@ -216,6 +216,23 @@ def test_reset_distribution_and_golden(oracle, golden):
         assert np.array_equal(oracle.acrobot_reset(seed, lane0, tick, 16), g["acrobot"][k])
         assert np.array_equal(oracle.discrete_sample(seed, lane0, tick, 3, 0, 32), g["discrete3"][k])
         assert np.array_equal(oracle.box_uniform_sample(seed, lane0, tick, -2.0, 2.0, 32), g["box_pm2"][k])
+        # action stream v2 (csrc/philox.hpp): lane L takes word (L & 3) of the call with counter (L >> 2, tick) — the C oracle, lane
+        # by lane, against the NumPy Philox twin, on lane offsets that start inside a group (7, 2^33 + 5) and on aligned ones
+        lanes32 = np.arange(lane0, lane0 + 32, dtype=np.uint64)
+        wa, wb = oracle.action_words(seed, lane0, tick, 32)
+        na, nb = nr.action_words(seed, lanes32, tick)
+        assert np.array_equal(wa, na) and np.array_equal(wb, nb) and not np.array_equal(wa, wb)
+        assert np.array_equal(nr.discrete_sample(seed, lanes32, tick, 3), g["discrete3"][k])
+        assert np.array_equal((f32(-2.0) + f32(4.0) * nr.u01_24(na)).astype(f32), g["box_pm2"][k])
+        # four lanes of a group share ONE call: its four words, in lane order
+        first = int(-lane0 % 4)                                                   # first lane of the batch that starts a group
+        call = nr.reset_words(seed ^ nr.ACTION_STREAM, np.array([(lane0 + first) >> 2], dtype=np.uint64), tick)[:, 0]
+        assert np.array_equal(wa[first:first + 4], call)
+        # epsilon-greedy: explores iff u01_24(word B) <= epsilon, and then takes exactly the Discrete.Sample() draw
+        pol = np.full(32, 7, np.int32)
+        comp = oracle.compose_discrete(seed, lane0, tick, 3, 0.4, pol)
+        explore = nr.u01_24(nb) <= f32(0.4)
+        assert np.array_equal(comp, np.where(explore, g["discrete3"][k], pol))
     # CartPoleEnv.Reset (CartPoleEnv.cs:63-67): 4 iid U(-0.05, 0.05) components
     big = oracle.cartpole_reset(7, 0, 3, 200_000)
     assert big.min() >= -0.05 and big.max() < 0.05
