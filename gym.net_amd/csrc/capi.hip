@@ -225,22 +225,35 @@ void default_policy(gymnet_vecenv *h) {
         // one-shot 13.7 -> 13.4 us at 2^20 lanes, bookkeeping rollout 7.5 -> 6.9 us per step, lean rollout 5.9 -> 6.0
         // (profiles/rollout_reset_forms_r05.txt); the multi-pair kernel below always draws once per thread-group of pairs
         h->lcfg = LaunchCfg{can2 ? 2 : 1, 256, 15, 0, 1, can2 ? 1 : 0, 0, h->simds};
-        if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)768 << 20)) h->lcfg.nt = 12;
+        // Stream policy by the bytes a vector step moves (round 6, profiles/f64_sizes_r06.txt; us per 2^20 lanes, one-shot kernel,
+        // nothing non-temporal | state cacheable (12) | every stream non-temporal (15)):
+        //   2^21 lanes 12.9 | 14.8 | 13.7     3 * 2^20  11.8 | 13.4 | 12.6     2^22  12.1 | 13.8 | 14.1     2^23  13.1 | 13.5 | 12.6
+        // While everything a step touches fits the 256 MiB Infinity Cache (<= 300 MiB moved: the state is rewritten in place), plain
+        // cacheable accesses win by 6-13 % — the next launch finds its inputs on the die; beyond it nothing can stay and every stream
+        // is marked non-temporal (rounds 4-5 kept the state cacheable between 96 and 768 MiB: 4-7 % slower at every size measured).
+        if (step_bytes > ((size_t)96 << 20) && step_bytes <= ((size_t)300 << 20)) h->lcfg.nt = 0;
         // The multi-pair kernel (step_kernel_pipe2<CartPole64, k>: a thread owns k lane pairs, all loads first, then advance pair after
-        // pair, ONE wave-compacted reset for all of them, then the state rows) wins where it runs as two or three waves on every
-        // SIMD — 2048 or 3072 waves of 128 * k lanes.  us per step, one-shot | 2 pairs | 4 pairs (profiles/f64_sizes_r05.txt, one box):
+        // pair, ONE wave-compacted reset for all of them, then the state rows) wins where it runs as ONE resident generation that fills
+        // the chip: four pairs hold 185 VGPRs = two waves per SIMD (2048 waves of 512 lanes), two pairs three (3072 waves of 256 lanes).
+        // us per step, one-shot | 2 pairs | 4 pairs (profiles/f64_sizes_r05.txt, one box):
         //   2^19 lanes 6.27 | 6.42 | 7.57      3 * 2^18  10.94 | 8.46 | 10.19      2^20  13.13 | 12.17 | 11.19
         //   5 * 2^18   16.64 | 16.82 | 17.40   6 * 2^18  21.17 | 19.78 | 19.58     2^21  27.72 | 28.56 | 29.64   (larger: one-shot)
         // (round 4, 271 VALU per env-step, per-pair drain-loop reset: one-shot 14.4, 2 pairs 13.1, 4 pairs 14.4 at 2^20; round 5 before
         // the deferred reset: 13.4-13.6 | 13.1-13.4 | 12.8-13.2.)  Lean variant only; without auto-reset whole 2 * k * 256-lane groups
         // only (the launcher falls back otherwise).  A wave count just under a whole number per SIMD is as good (10^6 lanes: 11.7 us against 13.0).
+        // Beyond one generation the kernel is launched slice by slice (step_kernels.hpp pipe2_chunks) and is no faster than the one-shot
+        // kernel — 2^21 lanes: 27.9 us in two slices, 35.2 as a looping grid, 27.4 one-shot with the same mask, 25.8 one-shot
+        // cacheable (profiles/f64_sizes_r06.txt): what makes 2^20 lanes fast is that the launch's written lines fit the L2s and leave
+        // after the kernel, not the launch shape — so it is not selected there.  (Round 5's window test also let FOUR pairs through at
+        // three waves per SIMD, which they cannot hold: 3 * 2^19 lanes ran at 16.6 us per 2^20 lanes against 13.3.  Fixed.)
         if (can2 && h->n >= ((int64_t)3 << 18)) {            // (below: ramp-bound, fewer and fatter waves lose)
             for (int items : {4, 2}) {
                 if (!h->autoreset && h->n % ((int64_t)512 * items) != 0) continue;     // (the auto-reset form takes any batch size)
                 const double waves_per_simd = (double)((h->n + 128 * items - 1) / ((int64_t)128 * items)) / (double)h->simds;   // MI355X: 256 CUs x 4 SIMDs
                 // NOT one wave more: the kernel holds 191 VGPRs, two waves per SIMD are resident, and a 2049th wave starts when an
                 // earlier one has finished — 2^20 + 2 lanes: 19.2 us against 11.1 (profiles/f64_sizes_r05.txt, second table)
-                if ((waves_per_simd >= 1.9 && waves_per_simd <= 2.0) || (waves_per_simd >= 2.85 && waves_per_simd <= 3.0)) { h->lcfg.items = items; break; }
+                const bool fills = items == 4 ? (waves_per_simd >= 1.9 && waves_per_simd <= 2.0) : (waves_per_simd >= 2.85 && waves_per_simd <= 3.0);
+                if (fills) { h->lcfg.items = items; h->lcfg.nt = 15; break; }
             }
         }
         return;
@@ -252,7 +265,8 @@ void default_policy(gymnet_vecenv *h) {
     // keyed on the bytes one vector step moves (lanes x algorithmic bytes per env-step):
     //  - <= 2^19 lanes (round 1-4: "<= 24 MiB per vector step"): scalar lanes — 4x the waves hide latency better than dwordx4 on a small grid;
     //  - <= 48 MiB (2^20 CartPole lanes): dwordx4, every stream non-temporal;
-    //  - <= 768 MiB (state fits the 256 MiB Infinity Cache): dwordx4, state cacheable, action / reward / done streamed
+    //  - <= 300 MiB (the step's whole footprint fits the 256 MiB Infinity Cache): dwordx4, nothing non-temporal (round 6);
+    //  - <= 768 MiB (the state fits it): dwordx4, state cacheable, action / reward / done streamed
     //    past it, so the next launch re-reads the state from the cache;
     //  - larger: nothing can stay resident — scalar lanes, every stream non-temporal;
     //  - Acrobot (RK4, ALU-bound: ~650 VALU per env-step) always takes scalar lanes: 21.7 vs 27.7 us at 2^20.
@@ -266,6 +280,15 @@ void default_policy(gymnet_vecenv *h) {
     // (profiles/small_batches_r05.txt; CartPole and Pendulum cross over at the same lane count).
     const bool one_generation = h->n <= ((int64_t)8 * h->simds * 64);
     if (alu_bound || one_generation) { h->lcfg.vec = 1; h->lcfg.nt = 15; }
+    // Round 6 (profiles/trough_r06.txt): while everything a step touches fits the 256 MiB Infinity Cache — up to ~300 MiB
+    // moved, the state being rewritten in place — and the launch is more than ~1.25 generations of waves, NO stream is marked
+    // non-temporal.  us per 2^20 lanes, mask 0 against the former choice (15 up to 48 MiB, 12 beyond), two boxes:
+    //   CartPole     5 * 2^18 lanes 6.26 / 6.56   2^21 7.03 / 7.33   3 * 2^20 6.86 / 7.54   2^22 6.72 / 7.24   6 * 2^20 6.40 / 6.78
+    //                2^23 6.80 / 6.85 (the crossover)   2^24 7.96 / 6.52 (mask 12 stays)
+    //   MountainCar  3 * 2^19 4.31 / 5.10   2^21 3.83 / 4.48   2^22 4.14 / 4.33   2^23 3.92 / 4.10   2^24 3.85 / 3.87
+    //   Pendulum     3 * 2^19 5.93 / 5.42 and 2^21 6.05 / 5.30 (loses: two of its four written rows are never read back),
+    //                2^22 5.51 / 6.27   2^23 5.68 / 5.68 — hence its later start
+    else if (h->n >= (cfg->env_id == GYMNET_ENV_PENDULUM ? (int64_t)3 << 20 : (int64_t)5 << 18) && step_bytes <= ((size_t)300 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 0; }
     else if (step_bytes <= ((size_t)48 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 15; }
     else if (step_bytes <= ((size_t)768 << 20)) { h->lcfg.vec = 4; h->lcfg.nt = 12; }
     else { h->lcfg.vec = 1; h->lcfg.nt = 15; }

@@ -58,7 +58,7 @@ constexpr int kAfterStride = 8;     // uint64 words between after_done shards (6
 // state, dwordx4 lanes)
 // lds_pipe: 1 = the multi-lane kernel in its producer / consumer form (step_kernel_lds: `items` tiles per workgroup)
 // simds: SIMD units of the handle's device (multiProcessorCount x 4; 1024 on MI355X) — sizes the resident generation of the looped
-// multi-pair kernel (step_kernels.hpp pipe2_shape) and the policy's waves-per-SIMD windows (capi.hip default_policy)
+// multi-pair kernel (step_kernels.hpp pipe2_chunks) and the policy's waves-per-SIMD windows (capi.hip default_policy)
 struct LaunchCfg { int vec; int block; int nt; int lds_bytes = 0; int items = 1; int reset_form = 0; int lds_pipe = 0; int simds = 1024; };
 
 // ---- env-dependent launchers: one translation unit per env (env_*.hip, GYMNET_DEFINE_ENV in step_kernels.hpp) ---------------

@@ -734,17 +734,21 @@ __device__ __forceinline__ void pipe2_split_body(const StepArgsT<typename Env::R
     }
 }
 
-// Round 6 — GENERATIONS.  Beyond the lanes its resident waves hold (two waves per SIMD x 1024 SIMDs x 512 lanes = 2^20 for the four-pair
-// float64 kernel) a launch used to run as several hardware-scheduled generations of workgroups, each new workgroup waiting for four
-// wave slots (one per SIMD of a CU) to drain: 2^21 lanes 29.6 us, worse than the one-shot kernel's 27.7 (profiles/f64_sizes_r05.txt).
-// The form with the deferred reset now LOOPS instead: the grid stays at one resident generation (the launcher balances it,
-// grid = ceil(workgroups / gens)), and every thread walks `gens` groups of ITEMS pairs, generation g at pair offset g * ITEMS * T.
-// No workgroup is ever launched into a draining chip, the waves drift apart so that one wave's stores overlap its neighbour's
-// loads, and the per-launch ramp is paid once.  Same pairs, same counters: bit-identical.
+// Round 6 — batches beyond ONE resident generation.  The four-pair float64 kernel holds 185 VGPRs: two waves per SIMD, 2048 waves of
+// 512 lanes = 2^20 lanes resident at once, and there it runs load burst | arithmetic | store burst as one generation (0.84 of 8 TB/s).
+// Launched over 2^21 lanes it ran as hardware-scheduled generations, every new workgroup waiting for four wave slots (one per SIMD of
+// a CU) to drain: 29.6 us, worse than the one-shot kernel's 27.7 (profiles/f64_sizes_r05.txt).  Two remedies were measured
+// (profiles/f64_sizes_r06.txt):
+//   * a grid of one resident generation whose threads LOOP over the generations: slower still (35.2 us at 2^21 lanes) — a wave's
+//     load, arithmetic and store phases are serial and two waves per SIMD cannot cover each other's memory latency; the one-generation
+//     launch is fast because the whole CHIP moves through the phases together, not because of the grid's shape.  Removed.
+//   * one launch PER generation over consecutive slices of the batch (launch_step_env below: pipe2_chunks) — each slice is exactly the
+//     2^20-lane launch, and consecutive launches on a stream overlap their ramp with the predecessor's drain the way consecutive steps
+//     of a rollout do.  Kept where it measures faster than the one-shot kernel.
 template <class Env, int ITEMS, bool AUTORESET, int NT>
 // (No occupancy hint: the float64 four-pair kernel holds 185 VGPRs = two waves per SIMD; capped at 168 for three it spills 48 bytes and
 // runs at 14.0 instead of 11.1 us per 2^20-lane step — profiles/occupancy_hints_r05.txt.)
-__global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a, const int gens) {
+__global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typename Env::Real> a) {
     const uint64_t tick = a.tick2[a.parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick2[a.parity ^ 1] = tick + 1;
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
@@ -752,15 +756,10 @@ __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typenam
     if constexpr (AUTORESET && has_split_reset<Env>()) {
         __shared__ DeferScratch<Env> scratch[256 / 64];            // one table per wave of the workgroup
         DeferScratch<Env> *sc = &scratch[threadIdx.x >> 6];
-        // ANY batch size: gens * gridDim.x workgroup-generations cover ceil(n / (2 * ITEMS * block)) groups; a workgroup whose last pair
-        // of its last item lies inside the batch runs the unguarded body (workgroup-uniform), the batch's last few the guarded one
-        for (int g = 0; g < gens; ++g) {
-            const int64_t g0 = (int64_t)g * ITEMS * T;             // pair offset of generation g
-            const int64_t wg0 = g0 + (int64_t)blockIdx.x * blockDim.x;
-            if (wg0 * 2 >= a.n) break;                             // this workgroup's share of the generation is past the end
-            if ((wg0 + blockDim.x + (int64_t)(ITEMS - 1) * T) * 2 <= a.n) pipe2_split_body<Env, ITEMS, NT, false>(a, g0 + t, T, tick, sc);
-            else pipe2_split_body<Env, ITEMS, NT, true>(a, g0 + t, T, tick, sc);
-        }
+        // ANY batch size: the grid is ceil(n / (2 * ITEMS * block)) workgroups; a workgroup whose last pair of its last item lies
+        // inside the batch runs the unguarded body (workgroup-uniform), the batch's last few run the guarded one
+        if ((((int64_t)blockIdx.x + 1) * blockDim.x + (int64_t)(ITEMS - 1) * T) * 2 <= a.n) pipe2_split_body<Env, ITEMS, NT, false>(a, t, T, tick, sc);
+        else pipe2_split_body<Env, ITEMS, NT, true>(a, t, T, tick, sc);
         return;
     }
     LaneInputs<Env, 2> in[ITEMS];
@@ -776,18 +775,33 @@ __global__ __launch_bounds__(256) void step_kernel_pipe2(const StepArgsT<typenam
     }
 }
 
-// How the multi-pair kernel's launch is shaped: `gens` generations walked by a grid of ONE resident generation.  A workgroup is four
-// waves, one per SIMD of a CU, so the chip holds (SIMDs / 4) x (waves per SIMD the kernel's registers allow) of them at once: two for
-// the four-pair float64 kernel (185 VGPRs), three for fewer pairs (tests/test_kernel_resources.py asserts both).
-struct Pipe2Shape { unsigned grid; int gens; };
-template <class Env>
-static Pipe2Shape pipe2_shape(int64_t n, int items, int block, bool looped, int simds) {
+// The slices a multi-pair step is launched in: `chunks` consecutive slices of `lanes` lanes (the last one shorter), each ONE resident
+// generation of the kernel.  A workgroup is four waves, one per SIMD of a CU, so the chip holds (SIMDs / 4) x (waves per SIMD the
+// kernel's registers allow) workgroups at once: two for the four-pair float64 kernel (185 VGPRs), three for fewer pairs
+// (tests/test_kernel_resources.py asserts both).  Only the form with the deferred reset is sliced (any batch size, lean, auto-reset).
+struct Pipe2Chunks { int64_t lanes; int chunks; };
+static inline Pipe2Chunks pipe2_chunks(int64_t n, int items, int block, bool sliced, int simds) {
     const int64_t per_block = 2 * (int64_t)items * block;
-    const int64_t wgs = n > 0 ? (n + per_block - 1) / per_block : 1;
-    if (!looped) return Pipe2Shape{(unsigned)wgs, 1};
     const int64_t resident = (int64_t)(simds > 0 ? simds : 1024) / 4 * (items >= 4 ? 2 : 3) * (256 / block);
-    const int64_t gens = (wgs + resident - 1) / resident;
-    return Pipe2Shape{(unsigned)((wgs + gens - 1) / gens), (int)gens};
+    const int64_t cap = resident * per_block;
+    if (!sliced || n <= cap) return Pipe2Chunks{n, 1};
+    return Pipe2Chunks{cap, (int)((n + cap - 1) / cap)};
+}
+
+// a StepArgs for the slice of `count` lanes that starts at lane `first` (lean variant: the bookkeeping arrays are not in use)
+template <class R>
+static StepArgsT<R> slice_of(const StepArgsT<R> &a, int64_t first, int64_t count) {
+    StepArgsT<R> s = a;
+    s.state += first; s.state_out += first;
+    if (s.obs_in) s.obs_in += first;
+    if (s.obs) s.obs += first;
+    s.action = static_cast<const char *>(a.action) + (size_t)first * 4;
+    s.reward += first; s.done += first;
+    if (s.sbd) s.sbd += first;
+    if (s.lane_seed) s.lane_seed += first;
+    s.lane_offset += (uint64_t)first;
+    s.n = count;
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1413,7 +1427,9 @@ static StepVariant resolve_variant(bool autoreset, bool extras, const LaunchCfg 
         // (the form with the deferred reset — envs whose reset is two Philox calls, auto-reset — takes any batch size)
         const bool any_n = has_split_reset<Env>() && autoreset;
         if (cfg.items > 1 && cfg.items <= 4 && !extras && cfg.vec == 2 && !cfg.lds_pipe && n > 0 && (any_n || n % (2 * (int64_t)cfg.items * 256) == 0)) {
-            v.nt = 15; v.vec = 2; v.pipe_items = cfg.items; v.pipe_pairs = true;
+            // every stream non-temporal, except that the four-pair form with the deferred reset also exists with the other two masks
+            // (the stream policy of a batch beyond one resident generation is a measured choice: capi.hip default_policy)
+            v.nt = (any_n && cfg.items == 4) ? cfg.nt : 15; v.vec = 2; v.pipe_items = cfg.items; v.pipe_pairs = true;
             return v;
         }
     }
@@ -1460,18 +1476,31 @@ static hipError_t launch_step_env(bool autoreset, bool extras, const StepArgsT<t
         if (v.pipe_pairs) {
             // whole groups of 2 * items * 256 lanes (resolve_variant: any workgroup size divides the batch) — or, for the form with
             // the deferred reset, any batch: the last workgroups run the guarded body
-            const Pipe2Shape shape = pipe2_shape<Env>(a.n, v.pipe_items, cfg.block, has_split_reset<Env>() && autoreset, cfg.simds);
-            const dim3 qgrid(shape.grid), qblk(cfg.block);
+            // one launch per resident generation (pipe2_chunks): every slice reads the same tick word and writes the same successor
+            const Pipe2Chunks ch = pipe2_chunks(a.n, v.pipe_items, cfg.block, has_split_reset<Env>() && autoreset, cfg.simds);
+            const int64_t per_block = 2 * (int64_t)v.pipe_items * cfg.block;
+            for (int c = 0; c < ch.chunks; ++c) {
+                const int64_t first = (int64_t)c * ch.lanes, count = (a.n - first < ch.lanes) ? a.n - first : ch.lanes;
+                const StepArgsT<typename Env::Real> sa = ch.chunks == 1 ? a : slice_of(a, first, count);
+                const dim3 qgrid((unsigned)((count + per_block - 1) / per_block)), qblk(cfg.block);
 #define GYMNET_PIPE2(I)                                                                                                 \
     case I:                                                                                                             \
-        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, a, shape.gens);     \
-        else hipLaunchKernelGGL((step_kernel_pipe2<Env, I, false, 15>), qgrid, qblk, 0, st, a, shape.gens);              \
+        if (autoreset) hipLaunchKernelGGL((step_kernel_pipe2<Env, I, true, 15>), qgrid, qblk, 0, st, sa);                \
+        else hipLaunchKernelGGL((step_kernel_pipe2<Env, I, false, 15>), qgrid, qblk, 0, st, sa);                         \
         break;
-            switch (v.pipe_items) {
-                GYMNET_PIPE2(2) GYMNET_PIPE2(3) GYMNET_PIPE2(4)
-                default: return hipErrorInvalidValue;
-            }
+                if constexpr (has_split_reset<Env>()) {
+                    if (autoreset && v.pipe_items == 4 && v.nt != 15) {
+                        if (v.nt == 12) hipLaunchKernelGGL((step_kernel_pipe2<Env, 4, true, 12>), qgrid, qblk, 0, st, sa);
+                        else hipLaunchKernelGGL((step_kernel_pipe2<Env, 4, true, 0>), qgrid, qblk, 0, st, sa);
+                        continue;
+                    }
+                }
+                switch (v.pipe_items) {
+                    GYMNET_PIPE2(2) GYMNET_PIPE2(3) GYMNET_PIPE2(4)
+                    default: return hipErrorInvalidValue;
+                }
 #undef GYMNET_PIPE2
+            }
             return hipGetLastError();
         }
     }
@@ -1517,7 +1546,12 @@ static int describe_step_env(bool autoreset, bool extras, LaunchCfg cfg, int64_t
     const StepVariant v = resolve_variant<Env>(autoreset, extras, cfg, n);
     const char *env = Env::NAME;
     const char *ar = autoreset ? "true" : "false";
-    if (v.pipe_pairs) return std::snprintf(buf, cap, "step_kernel_pipe2<%s,%d,%s,15>", env, v.pipe_items, ar);
+    if (v.pipe_pairs) {
+        // " x G": the step is G launches of this kernel over consecutive slices of the batch (pipe2_chunks)
+        const Pipe2Chunks ch = pipe2_chunks(n, v.pipe_items, cfg.block, has_split_reset<Env>() && autoreset, cfg.simds);
+        if (ch.chunks > 1) return std::snprintf(buf, cap, "step_kernel_pipe2<%s,%d,%s,%d> x %d", env, v.pipe_items, ar, v.nt, ch.chunks);
+        return std::snprintf(buf, cap, "step_kernel_pipe2<%s,%d,%s,%d>", env, v.pipe_items, ar, v.nt);
+    }
     if (v.lds_tiles > 1) return std::snprintf(buf, cap, "step_kernel_lds<%s,%d,%s,15>", env, v.lds_tiles, ar);
     if (v.pipe_items > 1) return std::snprintf(buf, cap, "step_kernel_pipe<%s,%d,%s,15>", env, v.pipe_items, ar);
     return std::snprintf(buf, cap, "step_kernel<%s,%d,%s,%s,%d,%d>", env, v.vec, ar, extras ? "true" : "false", v.nt, v.resetf);

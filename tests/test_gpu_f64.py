@@ -366,6 +366,36 @@ def test_f64_multi_pair_kernel_takes_any_batch_size(gpu_pkg, oracle, n):
             assert all(np.array_equal(u, v) for u, v in zip(outs[0][k], o[k]))
 
 
+@pytest.mark.parametrize("n,pol,slices", [((1 << 20) + (1 << 19) + 6, {"sequential_lanes": 4, "nt": 15}, 2), ((1 << 21) + 2, {"sequential_lanes": 4, "nt": 0}, 3),
+                                          (3 * 786432 - 510, {"sequential_lanes": 2}, 3)])
+def test_f64_multi_pair_step_beyond_one_resident_generation_is_launched_in_slices(gpu_pkg, oracle, n, pol, slices):
+    """Round 6: a multi-pair step over more lanes than the kernel's resident waves hold (2048 waves of 512 lanes for four pairs, 3072 of
+    256 for two) is launched slice by slice (step_kernels.hpp pipe2_chunks): every slice its own launch with shifted rows and lane
+    offset, all reading the same tick.  Bit-identical to the one-shot kernel over steps in which every lane is reset at least once,
+    with per-slice ragged ends, lane offsets that continue the global numbering, and the twin's reset draws."""
+    rng = np.random.default_rng(n)
+    T = 60
+    acts = rng.integers(0, 2, (T, n)).astype(np.int32)
+    outs = []
+    for p in ({"sequential_lanes": 1}, pol):
+        with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, dtype=np.float64, lane_offset=(1 << 33) + 10, launch_policy=p) as env:
+            if p["sequential_lanes"] > 1:
+                assert env.KernelName() == f"step_kernel_pipe2<CartPole64,{p['sequential_lanes']},true,{p.get('nt', 15)}> x {slices}"
+            env.Reset()
+            fin = np.zeros(n, bool)
+            for t in range(T):
+                o = env.Step(acts[t])
+                fin |= o.Done
+            outs.append((env.GetState(), o.Observation.copy(), o.Done.copy(), o.Reward.copy(), env.Tick))
+    assert fin.mean() > 0.8
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    # the last step's freshly reset lanes hold the twin's draw for their GLOBAL lane id (the slices' offsets continue the numbering)
+    d = outs[1][2]
+    fresh = oracle.cartpole_reset_f64(SEED, (1 << 33) + 10, outs[1][4] - 1, n)
+    assert d.any() and np.array_equal(outs[1][0][:, d], fresh[:, d])
+
+
 @pytest.mark.parametrize("case", ["everyone_falls", "one_thread_tail", "odd_tail", "lane_seeds"])
 def test_f64_two_lanes_per_reset_edges(gpu_pkg, oracle, case):
     """The float64 reset is two Philox calls; the compacted forms spread ONE reset over two lanes (lane 2r call 0, lane 2r + 1 call 1,

@@ -335,9 +335,20 @@ def test_f64_pair_kernel_workgroup_sizes_and_reset_forms_are_bit_identical(gpu_p
     ("CartPole-v1", "float64", (1 << 20) + 2, "step_kernel<CartPole64,2,true,false,15,1>"),         # one wave more would be a second round
     ("CartPole-v1", "float64", 3 << 18, "step_kernel_pipe2<CartPole64,2,true,15>"),
     ("CartPole-v1", "float64", 1 << 19, "step_kernel<CartPole64,2,true,false,15,1>"),
+    # round 6 (profiles/trough_r06.txt, f64_sizes_r06.txt): no stream non-temporal while a step's footprint fits the Infinity Cache
+    ("CartPole-v1", "float32", 5 << 18, "step_kernel<CartPole,4,true,false,0,1>"),
+    ("CartPole-v1", "float32", 1 << 22, "step_kernel<CartPole,4,true,false,0,1>"),
+    ("CartPole-v1", "float32", 1 << 23, "step_kernel<CartPole,4,true,false,12,1>"),                 # 328 MiB per step: the state alone stays cacheable
+    ("MountainCar-v0", "float32", 3 << 19, "step_kernel<MountainCar,4,true,false,0,1>"),
+    ("Pendulum-v1", "float32", 1 << 21, "step_kernel<Pendulum,4,true,false,12,0>"),                 # its write-only rows make it start later
+    ("Pendulum-v1", "float32", 1 << 22, "step_kernel<Pendulum,4,true,false,0,0>"),
+    ("CartPole-v1", "float64", 3 << 19, "step_kernel<CartPole64,2,true,false,0,1>"),                # (round 5 let FOUR pairs through at three waves per SIMD)
+    ("CartPole-v1", "float64", 1 << 21, "step_kernel<CartPole64,2,true,false,0,1>"),
+    ("CartPole-v1", "float64", 1 << 23, "step_kernel<CartPole64,2,true,false,15,1>"),               # 584 MiB per step: nothing can stay
 ])
 def test_default_launch_policy_by_batch_size(gpu_pkg, env_id, dtype, n, want):
-    """The launch policy's round-5 rules, as the kernel the library itself names (profiles/small_batches_r05.txt, ragged_r05.txt, f64_sizes_r05.txt)."""
+    """The launch policy's rules, as the kernel the library itself names (profiles/small_batches_r05.txt, ragged_r05.txt, f64_sizes_r05.txt;
+    round 6: trough_r06.txt, f64_sizes_r06.txt)."""
     kw = {"dtype": np.float64} if dtype == "float64" else {}
     with gpu_pkg.VectorEnv(env_id, n, seed=SEED, auto_reset=True, **kw) as env:
         assert env.KernelName() == want

@@ -17,7 +17,8 @@ pkg = ge.load_package()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
-f32 = len(sys.argv) > 1 and sys.argv[1] == "f32"
+f32 = len(sys.argv) > 1 and sys.argv[1] != "f64"
+env_name = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("f32", "f64") else "CartPole-v1"     # an env name: its float32 table
 sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1 << 20, 3 << 19, 1 << 21, 3 << 20, 1 << 22, 1 << 23, (1 << 21) + 6, 5 << 20]
 ring = 4
 
@@ -37,16 +38,17 @@ def timed(e, acts, n, launches, reps=5):
 
 
 for n in sizes:
-    acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+    acts = torch.empty((ring, n), dtype=torch.float32 if env_name == "Pendulum-v1" else torch.int32, device=dev)
     launches = max(64, min(1024, (1 << 28) // n))
     ref = None
     if f32:
         policies = [("default", {}), ("nt=15", dict(nt=15)), ("nt=12", dict(nt=12)), ("nt=0", dict(nt=0))]
     else:
-        policies = [("default", {}), ("one-shot nt=12", dict(sequential_lanes=1, nt=12)), ("one-shot nt=15", dict(sequential_lanes=1, nt=15)),
-                    ("2 pairs", dict(sequential_lanes=2)), ("3 pairs", dict(sequential_lanes=3)), ("4 pairs", dict(sequential_lanes=4))]
+        policies = [("default", {}), ("one-shot nt=12", dict(sequential_lanes=1, nt=12)), ("one-shot nt=15", dict(sequential_lanes=1, nt=15)), ("one-shot nt=0", dict(sequential_lanes=1, nt=0)),
+                    ("2 pairs", dict(sequential_lanes=2)), ("3 pairs", dict(sequential_lanes=3)), ("4 pairs nt=15", dict(sequential_lanes=4, nt=15)),
+                    ("4 pairs nt=12", dict(sequential_lanes=4, nt=12)), ("4 pairs nt=0", dict(sequential_lanes=4, nt=0))]
     for label, pol in policies:
-        with pkg.VectorEnv("CartPole-v1", n, seed=7, auto_reset=True, dtype="float32" if f32 else "float64", stream=stream.cuda_stream) as e:
+        with pkg.VectorEnv(env_name, n, seed=7, auto_reset=True, dtype="float32" if f32 else "float64", stream=stream.cuda_stream) as e:
             for t in range(ring):
                 e.SampleActionsDevice(acts[t], seed=8, tick=t)
             try:
