@@ -71,6 +71,9 @@ def parse():
     p.add_argument("--no-group-leg", action="store_true", help="N > 1: skip the single-process gymnet_group_* leg")
     p.add_argument("--no-host-boundary", action="store_true", help="skip the NDArray-shaped host path figure (gymnet_vecenv_step)")
     p.add_argument("--group-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run the gymnet_group_* leg over this many members
+    p.add_argument("--rollout-child", default="", help=argparse.SUPPRESS)   # internal: run the fused-rollout variants (comma list or "all") for a profiler
+    p.add_argument("--no-rollout-pmc", action="store_true", help="do not measure the fused rollouts' VALU instructions per env-step with a "
+                   "rocprofv3 --pmc child pass (the constants from profiles/rollout_valu.json are reported instead, labelled)")
     p.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes "
                    "(the constant from profiles/traffic.json is reported instead, labelled)")
     p.add_argument("--policy", default="", help="launch policy overrides for the headline handle, e.g. vec=4,nt=12,block=128 "
@@ -314,6 +317,143 @@ def measure_traffic(args, wide16=True, timeout=90):
                      f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} step-kernel dispatches), {how}")
 
 
+# ---- fused rollout: the VALU-issue roofline --------------------------------------------------------------------
+# The fused rollouts keep the state in registers and move 0-4 bytes per env-step: they are bound by VALU instruction ISSUE, not by
+# memory (profiles/pmc_rollout_r05.txt).  A SIMD issues one wave-instruction of 64 lanes per 4 clocks (16 lanes per clock), so
+#     issue_floor_us = lanes x VALU instructions per env-step / (16 lanes x SIMDs) / clock
+# where "VALU per env-step" = SQ_INSTS_VALU / SQ_WAVES / lanes per thread / steps per launch (an instruction of a thread that serves
+# four lanes counts a quarter for each).  Quarter-rate instructions (v_mad_u64_u32 of the Philox draws, v_rcp) hold the pipe four
+# times as long; the floor does not price that, so the fraction of a Philox-heavy variant reads low by what the draws really cost.
+ROLLOUT_VARIANTS = ("f32_ring", "f32_sampled", "f32_epsilon_greedy", "f64_ring", "f64_sampled", "f64_epsilon_greedy")
+ROLLOUT_CHILD_STEPS, ROLLOUT_CHILD_LAUNCHES = 64, 3
+ENGINE_CLOCK_GHZ = 2.4      # MI355X peak engine clock (rocminfo "Max Clock Freq": 2400 MHz); the floor is priced at the peak
+
+
+def rollout_variant_call(env, variant, acts, n, ring, steps, seed):
+    kind = variant.split("_", 1)[1]
+    if kind == "ring":
+        return lambda: env.RolloutFusedDevice(acts.data_ptr(), steps, n, ring)
+    if kind == "sampled":
+        return lambda: env.RolloutFusedDevice(None, steps, actions="sample", action_seed=seed + 1, action_tick0=0)
+    return lambda: env.RolloutFusedDevice(acts.data_ptr(), steps, n, ring, actions="epsilon_greedy", action_seed=seed + 1, action_tick0=0, epsilon=0.1)
+
+
+def rollout_child(args):
+    """`bench.py --rollout-child all|v1,v2`: each variant's fused rollout, one warm-up launch + ROLLOUT_CHILD_LAUNCHES launches of
+    ROLLOUT_CHILD_STEPS steps, in the order given — the program a profiler wraps (rocprofv3 ... -- python3 bench.py --rollout-child ...).
+    Prints one JSON line: the sequence it ran (the parent tells the dispatches of one kernel name apart by their order)."""
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    n, ring, seed = args.num_envs, 8, 0x5EED
+    want = ROLLOUT_VARIANTS if args.rollout_child == "all" else tuple(v for v in args.rollout_child.split(",") if v)
+    dev = torch.device("cuda", 0)
+    acts = torch.empty((ring, n), dtype=torch.int32, device=dev)
+    seq = []
+    for dt in ("f32", "f64"):
+        mine = [v for v in want if v.startswith(dt)]
+        if not mine:
+            continue
+        with pkg.VectorEnv(args.env, n, device=0, seed=seed, auto_reset=True, dtype="float64" if dt == "f64" else "float32") as e:
+            for t in range(ring):
+                e.SampleActionsDevice(acts[t].data_ptr(), seed=seed + 1, tick=t)
+            e.ResetDevice()
+            for v in mine:
+                fn = rollout_variant_call(e, v, acts, n, ring, ROLLOUT_CHILD_STEPS, seed)
+                for _ in range(1 + ROLLOUT_CHILD_LAUNCHES):
+                    fn()
+                e.Sync()
+                seq.append({"variant": v, "launches": 1 + ROLLOUT_CHILD_LAUNCHES, "steps": ROLLOUT_CHILD_STEPS})
+    print(json.dumps({"rollout_child": seq, "num_envs": n}), flush=True)
+
+
+def read_rollout_counters(db, seq):
+    """Per variant of `seq` (the child's own account of what it ran): the counters of its rollout_kernel dispatches, summed over a
+    dispatch's rows and averaged over the variant's timed launches (the first launch of every variant is its warm-up and is left out)."""
+    import re
+    import sqlite3
+    c = sqlite3.connect(db)
+    try:
+        rows = c.execute("select dispatch_id, kernel_name, counter_name, sum(value) from counters_collection "
+                         "where kernel_name like '%rollout_kernel%' group by dispatch_id, kernel_name, counter_name order by dispatch_id").fetchall()
+    finally:
+        c.close()
+    disp = {}
+    for did, k, cn, v in rows:
+        disp.setdefault(did, {"kernel": k})[cn] = v
+    order = [disp[d] for d in sorted(disp)]
+    if len(order) != sum(x["launches"] for x in seq):
+        raise RuntimeError(f"{len(order)} rollout_kernel dispatches in the database, the child reported {sum(x['launches'] for x in seq)}")
+    out, at = {}, 0
+    for x in seq:
+        mine = order[at + 1:at + x["launches"]]
+        at += x["launches"]
+        k = mine[0]["kernel"]
+        lanes_per_thread = int(re.search(r"rollout_kernel<[^,]+,\s*(\d+)", k).group(1))
+        cs = {cn: sum(m[cn] for m in mine) / len(mine) for cn in mine[0] if cn != "kernel"}
+        out[x["variant"]] = {"kernel": k, "lanes_per_thread": lanes_per_thread, "steps_per_launch": x["steps"], "counters": cs,
+                             "valu_per_env_step": cs["SQ_INSTS_VALU"] / cs["SQ_WAVES"] / lanes_per_thread / x["steps"]}
+    return out
+
+
+def measure_rollout_valu(args, timeout=120):
+    """VALU instructions per env-step of every fused-rollout variant, measured IN THIS RUN: one rocprofv3 --pmc child pass (SQ counters
+    only, no trace flags; the program after `--` is python3 itself, started with subprocess) over `bench.py --rollout-child all`."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out_dir = tempfile.mkdtemp(prefix="gymnet_pmc_rollout_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "-d", out_dir, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--rollout-child", "all", "--env", args.env, "--num-envs", str(args.num_envs)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        seq = None
+        for line in r.stdout.splitlines():
+            if line.startswith('{"rollout_child"'):
+                seq = json.loads(line)["rollout_child"]
+        db = None
+        for dirpath, _, files in os.walk(out_dir):
+            for f in files:
+                if f.endswith("_results.db"):
+                    db = os.path.join(dirpath, f)
+        if r.returncode != 0 or db is None or not seq:
+            raise RuntimeError(f"rocprofv3 --pmc SQ_*: rc {r.returncode}, {(r.stderr or r.stdout)[-300:]}")
+        return read_rollout_counters(db, seq)
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def valu_roofline(n, valu_per_env_step, measured_us, simds, source, quarter_rate_per_env_step=None):
+    """The fused rollout's roofline object: bound by VALU issue (see the block comment above)."""
+    lanes_per_clock = 16 * simds
+    floor_us = n * valu_per_env_step / lanes_per_clock / (ENGINE_CLOCK_GHZ * 1e3)
+    r = {"bound": "valu_issue", "valu_per_env_step": valu_per_env_step, "valu_source": source, "lanes": n, "simds": simds,
+         "issue_lanes_per_clock": lanes_per_clock, "clock_GHz": ENGINE_CLOCK_GHZ, "issue_floor_us": floor_us, "measured_us": measured_us,
+         "frac": floor_us / measured_us,
+         "formula": "issue_floor_us = lanes x valu_per_env_step / (16 x simds) / clock_GHz / 1e3; frac = issue_floor_us / measured_us"}
+    if quarter_rate_per_env_step is not None:
+        # 64-bit integer multiply-adds (the Philox rounds) and transcendentals issue at a quarter of the rate: three more issue slots each
+        w = valu_per_env_step + 3.0 * quarter_rate_per_env_step
+        r.update(quarter_rate_per_env_step=quarter_rate_per_env_step, issue_floor_weighted_us=n * w / lanes_per_clock / (ENGINE_CLOCK_GHZ * 1e3),
+                 frac_weighted=n * w / lanes_per_clock / (ENGINE_CLOCK_GHZ * 1e3) / measured_us,
+                 weighted_note="quarter-rate instructions (SQ_INSTS_VALU_INT64 + SQ_INSTS_VALU_TRANS_F32 per env-step) priced at four issue slots")
+    return r
+
+
+def write_roofline(n, written_bytes_per_env_step, measured_us):
+    """A recording rollout writes its trajectory and reads nothing: bound by the write path, whose measured pure-write ceiling on this
+    chip is 4.4-4.8 TB/s (profiles/write_path_probe_r02.txt, store_flavour_r05.txt); the fraction of the 8 TB/s spec peak beside it."""
+    gbps = written_bytes_per_env_step * n / (measured_us * 1e-6) / 1e9
+    return {"bound": "hbm_write", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+            "written_bytes_per_env_step": written_bytes_per_env_step, "bytes_per_launch_step": written_bytes_per_env_step * n, "measured_us": measured_us,
+            "measured_pure_write_GBps": [4400, 4800], "frac_of_write_ceiling": gbps / 4800.0}
+
+
 def parse_policy(text):
     pol = {}
     for item in filter(None, (x.strip() for x in text.split(","))):
@@ -456,6 +596,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.group_child:
         return group_leg(args, args.group_child)
+    if args.rollout_child:
+        return rollout_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     # lower completion latency of the closing synchronize: ROCr polls its signals instead of sleeping on an interrupt
@@ -766,7 +908,14 @@ def main():
             # 0 B per env-step from memory, ~70 more VALU per lane-step for the Philox call.
             su = fused_time(lambda: local.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, action_tick0=0))
             fused["sampled_actions"] = {"us_per_step": su, "env_steps_per_sec_per_gpu": n / (su * 1e-6), "bytes_per_env_step": 0,
-                                        "note": "actions drawn in the kernel (Philox action stream): no action ring is read, nothing recorded"}
+                                        "note": "actions drawn in the kernel (Philox action stream v2: one call per four lanes): no action ring is read, nothing recorded"}
+            # ... and composed epsilon-greedy over the ring as the policy's actions (TrainingPlaySession.cs:46-52): a second word per lane
+            if adtype == torch.int32:
+                gu = fused_time(lambda: local.RolloutFusedDevice(actions.data_ptr(), ring, n, ring, actions="epsilon_greedy", action_seed=seed + 1,
+                                                                 action_tick0=0, epsilon=0.1))
+                fused["epsilon_greedy_actions"] = {"us_per_step": gu, "env_steps_per_sec_per_gpu": n / (gu * 1e-6), "bytes_per_env_step": 4, "epsilon": 0.1,
+                                                   "over_sampled": gu / su,
+                                                   "note": "the ring holds the policy's actions; explore iff u01(word B) <= epsilon, then ActionSpace.Sample() (word A)"}
             # ... and the same recording what a replay memory stores (ReplayMemory.cs:53-67): observation, action, reward, done
             rec_o = torch.empty((ring, obs_dim, n), dtype=torch.float32, device=dev)
             rec_r = torch.empty((ring, n), dtype=torch.float32, device=dev)
@@ -777,6 +926,7 @@ def main():
             rb = 4 * obs_dim + 4 + 4 + 1
             fused["sampled_actions_recorded"] = {"us_per_step": ru, "env_steps_per_sec_per_gpu": n / (ru * 1e-6), "bytes_per_env_step": rb,
                                                  "achieved_GBps": rb * n / (ru * 1e-6) / 1e9, "frac_of_peak": rb * n / (ru * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                 "roofline": write_roofline(n, rb, ru),
                                                  "note": f"{rb} B written per env-step (obs {4 * obs_dim} + action 4 + reward 4 + done 1), nothing read"}
             del rec_o, rec_r, rec_d, rec_a
             # ... and on a BOOKKEEPING handle: episode return / length in registers, 500-step time limit, one compact
@@ -872,8 +1022,25 @@ def main():
                 g1.record(stream)
                 torch.cuda.synchronize(dev)
                 fused64_us = g0.elapsed_time(g1) * 1e3 / fsteps4
+
+                def fused64_time(fn):
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    h0.record(stream)
+                    for _ in range(fsteps4 // 256):
+                        fn()
+                    h1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    return h0.elapsed_time(h1) * 1e3 / fsteps4
+                sampled64_us = fused64_time(lambda: e4.RolloutFusedDevice(None, 256, actions="sample", action_seed=seed + 1, action_tick0=0))
+                eps64_us = fused64_time(lambda: e4.RolloutFusedDevice(a4.data_ptr(), 256, n, r4, actions="epsilon_greedy", action_seed=seed + 1,
+                                                                      action_tick0=0, epsilon=0.1))
                 f64_fig = {"kernel": e4.KernelName(), "num_envs": n, "bytes_per_env_step": 73, "launch_us": us,
                            "fused_rollout": {"us_per_step": fused64_us, "env_steps_per_sec": n / (fused64_us * 1e-6), "steps_per_launch": 256,
+                                             "sampled_actions": {"us_per_step": sampled64_us, "env_steps_per_sec": n / (sampled64_us * 1e-6)},
+                                             "epsilon_greedy_actions": {"us_per_step": eps64_us, "env_steps_per_sec": n / (eps64_us * 1e-6), "epsilon": 0.1,
+                                                                        "over_sampled": eps64_us / sampled64_us},
                                              "note": "T-step fused float64 kernel (state in registers, arithmetic-bound); open-loop rollouts only"},
                            "env_steps_per_sec": n * 1024 / w4, "achieved_GBps": 73 * n / (w4 / 1024) / 1e9,
                            "frac_of_peak": 73 * n / (w4 / 1024) / 1e9 / HBM_PEAK_GBPS,
@@ -1099,6 +1266,38 @@ def main():
                 out["roofline"]["traffic_over_moved_bytes"] = tr / out["roofline"]["bytes_per_launch"]
             except Exception as e:                               # noqa: BLE001 - the constant (labelled) stays in the line
                 out["roofline"]["traffic_measurement_error"] = repr(e)[:300]
+        if world == 1 and fused and "us_per_step" in fused and not gather_in_region and args.env == "CartPole-v1":
+            # the fused rollouts' roofline objects: VALU issue, measured with one --pmc child pass or — labelled — constants
+            try:
+                simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+                valu, src = None, None
+                if not args.no_rollout_pmc and not args.no_traffic:
+                    try:
+                        valu = measure_rollout_valu(args)
+                        src = ("measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU, one "
+                               f"child pass, {ROLLOUT_CHILD_LAUNCHES} launches of {ROLLOUT_CHILD_STEPS} steps per variant; SQ_INSTS_VALU / SQ_WAVES / lanes per thread / steps")
+                    except Exception as e:                       # noqa: BLE001
+                        out["fused_rollout"]["valu_measurement_error"] = repr(e)[:300]
+                if valu is None:
+                    vj = json.load(open(os.path.join(ROOT, "profiles", "rollout_valu.json")))
+                    valu = {k: {"valu_per_env_step": v["valu_per_env_step"], "kernel": v.get("kernel"), "counters": {}} for k, v in vj["variants"].items()}
+                    src = "NOT measured in this run: constants from profiles/rollout_valu.json — " + vj.get("_source", "")
+                targets = [("f32_ring", out["fused_rollout"]), ("f32_sampled", out["fused_rollout"].get("sampled_actions")),
+                           ("f32_epsilon_greedy", out["fused_rollout"].get("epsilon_greedy_actions"))]
+                f64r = (out.get("cartpole_f64_2p20") or {}).get("fused_rollout")
+                if f64r:
+                    targets += [("f64_ring", f64r), ("f64_sampled", f64r.get("sampled_actions")), ("f64_epsilon_greedy", f64r.get("epsilon_greedy_actions"))]
+                for key, leg in targets:
+                    if leg and key in valu and "us_per_step" in leg:
+                        cs = valu[key].get("counters") or {}
+                        q = None
+                        if cs.get("SQ_WAVES") and "SQ_INSTS_VALU_INT64" in cs:
+                            q = ((cs["SQ_INSTS_VALU_INT64"] + cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) / cs["SQ_WAVES"]
+                                 / valu[key]["lanes_per_thread"] / valu[key]["steps_per_launch"])
+                        leg["roofline"] = valu_roofline(n, valu[key]["valu_per_env_step"], leg["us_per_step"], simds, src, q)
+                        leg["roofline"]["kernel"] = valu[key].get("kernel")
+            except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
+                out["fused_rollout"]["roofline_error"] = repr(e)[:300]
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void sample_discrete_kernel(int32_t *__restric
                                                               uint64_t tick) {
     const LaneGroup g = my_lane_group(lane_offset);
     if (g.i0 >= n) return;
-    const PhiloxWords r = action_group_words(seed, g.group, tick);
+    const PhiloxWords r = action_group_words<true>(seed, g.group, tick);
     int32_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = start + (int32_t)__umulhi(r.w[j], (uint32_t)nvals);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void sample_discrete_masked_kernel(int32_t *__
                                                                      uint64_t seed, uint64_t lane_offset, uint64_t tick) {
     const LaneGroup g = my_lane_group(lane_offset);
     if (g.i0 >= n) return;
-    const PhiloxWords r = action_group_words(seed, g.group, tick);
+    const PhiloxWords r = action_group_words<true>(seed, g.group, tick);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t i = g.i0 + j;
@@ -282,13 +282,14 @@ __global__ __launch_bounds__(256) void compose_discrete_kernel(const int32_t *__
                                                                uint64_t lane_offset, uint64_t tick) {
     const LaneGroup g = my_lane_group(lane_offset);
     if (g.i0 >= n) return;
-    const PhiloxWords r = action_group_words(seed, g.group, tick), c = aux_group_words(seed, g.group, tick);
+    const PhiloxWords r = action_group_words<true>(seed, g.group, tick), c = aux_group_words<true>(seed, g.group, tick);
+    const uint32_t explore_at_or_below = coin_threshold(epsilon);
     int32_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t i = g.i0 + j;
         const int32_t pol = policy[i < 0 ? 0 : i < n ? i : n - 1];       // clamped: a lane outside the batch stores nothing
-        v[j] = u01_24(c.w[j]) <= epsilon ? (int32_t)__umulhi(r.w[j], (uint32_t)nvals) : pol;
+        v[j] = c.w[j] <= explore_at_or_below ? (int32_t)__umulhi(r.w[j], (uint32_t)nvals) : pol;     // u01_24(word B) <= epsilon
     }
     store_group<int32_t>(out, g.i0, n, v);
 }
@@ -312,9 +313,9 @@ __global__ __launch_bounds__(256) void sample_box_kernel(float *__restrict__ out
                                                          uint64_t seed, uint64_t lane_offset, uint64_t tick) {
     const LaneGroup g = my_lane_group(lane_offset);
     if (g.i0 >= n) return;
-    const PhiloxWords r = action_group_words(seed, g.group, tick);
+    const PhiloxWords r = action_group_words<true>(seed, g.group, tick);
     PhiloxWords c{};
-    if (!(low > -INFINITY) && !(high < INFINITY)) c = aux_group_words(seed, g.group, tick);     // launch-uniform
+    if (!(low > -INFINITY) && !(high < INFINITY)) c = aux_group_words<true>(seed, g.group, tick);     // launch-uniform
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = box_sample_value(low, high, r.w[j], [&]() { return c.w[j]; });

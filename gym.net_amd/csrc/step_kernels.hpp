@@ -38,10 +38,11 @@ __device__ __forceinline__ double abs_real(double x) { return __builtin_fabs(x);
 
 // The reset draw of one lane: Philox4x32-10 keyed by (seed | per-lane seed), counter = (GLOBAL lane id, engine tick).  float32 envs
 // take the four words of ONE call; CartPole64 makes its own two calls (53-bit uniforms, cartpole64.hpp).
-template <class Env>
+// UNIFORM_KEY: the key is the handle's one seed (no per-lane keys in this kernel variant) — philox.hpp on what that buys.
+template <class Env, bool UNIFORM_KEY = false>
 __device__ __forceinline__ void draw_reset(typename Env::Real (&s)[Env::S], uint64_t key, uint64_t lane, uint64_t tick) {
     if constexpr (Env::RESET_TAKES_KEY) Env::reset(s, key, lane, tick);
-    else Env::reset(s, lane_words(key, lane, tick));
+    else Env::reset(s, lane_words<UNIFORM_KEY>(key, lane, tick));
 }
 
 // Where state row k lives.  A state component that the observation repeats verbatim (Pendulum: theta_dot = obs[2]; Acrobot:
@@ -160,12 +161,17 @@ __device__ __forceinline__ void reset_pending(uint32_t pending, typename Env::Re
     while (pending) {
         const int j = __ffs(pending) - 1;
         pending &= pending - 1;
-        uint64_t key = a.seed;
-        if constexpr (LANE_SEEDS) {
-            if (a.lane_seed && i0 + j < n) key = a.lane_seed[i0 + j];
-        }
+        // (a bookkeeping kernel serves per-lane keys only when VecEnv.Seed(int[]) installed some: the handle's ONE seed otherwise — a
+        // kernel-uniform choice, and the uniform-key form of the call keeps its round keys out of the vector registers: philox.hpp)
         Real sj[S];
-        draw_reset<Env>(sj, key, a.lane_offset + (uint64_t)(i0 + j), tick);
+        bool drawn = false;
+        if constexpr (LANE_SEEDS) {
+            if (a.lane_seed) {
+                draw_reset<Env, false>(sj, i0 + j < n ? a.lane_seed[i0 + j] : a.seed, a.lane_offset + (uint64_t)(i0 + j), tick);
+                drawn = true;
+            }
+        }
+        if (!drawn) draw_reset<Env, true>(sj, a.seed, a.lane_offset + (uint64_t)(i0 + j), tick);
         Real oj[O];
         if constexpr (!Env::OBS_ALIASES_STATE) Env::observe_fresh(sj, oj);
 #pragma unroll
@@ -273,12 +279,15 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, typename En
         } else if (lane < total - base) {                      // (an active lane by construction: lane < A whenever it has a slot)
             const uint32_t sl = sc->slot[lane];
             const int64_t gl = wave_i0 + (int64_t)sl;
-            uint64_t key = a.seed;
-            if constexpr (LANE_SEEDS) {
-                if (a.lane_seed && gl < n) key = a.lane_seed[gl];
-            }
             Real sj[S];
-            draw_reset<Env>(sj, key, a.lane_offset + (uint64_t)gl, tick);
+            bool drawn = false;
+            if constexpr (LANE_SEEDS) {
+                if (a.lane_seed) {                             // kernel-uniform: per-lane keys are installed
+                    draw_reset<Env, false>(sj, gl < n ? a.lane_seed[gl] : a.seed, a.lane_offset + (uint64_t)gl, tick);
+                    drawn = true;
+                }
+            }
+            if (!drawn) draw_reset<Env, true>(sj, a.seed, a.lane_offset + (uint64_t)gl, tick);
 #pragma unroll
             for (int k = 0; k < S; ++k) sc->draw[lane][k] = sj[k];
         }
@@ -959,9 +968,9 @@ __device__ __forceinline__ void thread_action_words(uint64_t seed, uint64_t gl0,
                                                     uint32_t (&wa)[VEC], uint32_t (&wb)[VEC]) {
     static_assert(VEC == 1 || VEC == 2 || VEC == 4, "a thread's lanes must fit one group of four");
     if (one_group) {
-        const PhiloxWords r = action_group_words(seed, gl0 >> 2, tick);
+        const PhiloxWords r = action_group_words<true>(seed, gl0 >> 2, tick);       // (the action seed is a kernel argument: uniform)
         PhiloxWords c{};
-        if (want_aux) c = aux_group_words(seed, gl0 >> 2, tick);
+        if (want_aux) c = aux_group_words<true>(seed, gl0 >> 2, tick);
         const uint32_t base = (uint32_t)gl0 & 3u;
         if constexpr (VEC == 4) {
 #pragma unroll
@@ -979,8 +988,8 @@ __device__ __forceinline__ void thread_action_words(uint64_t seed, uint64_t gl0,
         for (int j = 0; j < VEC; ++j) { wa[j] = 0u; wb[j] = 0u; }
 #pragma unroll 1
         for (int j = 0; j < VEC; ++j) {
-            const uint32_t a = action_word(seed, gl0 + (uint64_t)j, tick);
-            const uint32_t b = want_aux ? aux_word(seed, gl0 + (uint64_t)j, tick) : 0u;
+            const uint32_t a = action_word<true>(seed, gl0 + (uint64_t)j, tick);
+            const uint32_t b = want_aux ? aux_word<true>(seed, gl0 + (uint64_t)j, tick) : 0u;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { wa[k] = k == j ? a : wa[k]; wb[k] = k == j ? b : wb[k]; }
         }
@@ -1021,6 +1030,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
     // the ring is read unless every action is sampled; epsilon-greedy (action_source 2) reads it as the POLICY's actions
     bool use_ring = true;                                          // kernel-uniform
     const bool one_group = (a.lane_offset % (uint64_t)VEC) == 0;   // kernel-uniform: the thread's lanes share one action-stream call
+    const uint32_t explore_at_or_below = coin_threshold(ro.epsilon);   // kernel-uniform (philox.hpp): the coin is one integer compare
     if constexpr (SAMPLE) {
         use_ring = ro.action_source == 2;
 #pragma unroll
@@ -1080,7 +1090,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
             for (int j = 0; j < VEC; ++j) {
                 const Act drawn = sampled_action<Env>(wa[j]);
                 if constexpr (Env::BOX_ACTION) act[j] = drawn;                   // (epsilon-greedy is defined for Discrete spaces)
-                else act[j] = (use_ring && !(u01_24(wb[j]) <= ro.epsilon)) ? act[j] : drawn;   // TrainingPlaySession.cs:46-52
+                else act[j] = (use_ring && !(wb[j] <= explore_at_or_below)) ? act[j] : drawn;   // u01_24(word B) <= epsilon: TrainingPlaySession.cs:46-52
             }
         } else {
             if (t + 1 < ro.steps) load_action(nslice, act_next);        // in flight during this step's math

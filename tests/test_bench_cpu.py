@@ -78,3 +78,43 @@ def test_xgmi_allgather_model_matches_the_survey_figures():
     m = b.allgather_model(8, 4 * (1 << 20) * 4)                                # 16 MiB per rank: CartPole, 2^20 lanes per GPU
     assert 105 < m["direct_us"] < 115 and 740 < m["ring_us"] < 800            # ~110 us direct, ~770 us ring
     assert b.parse_policy("vec=4, nt=12,block=128") == {"vec": 4, "nt": 12, "block": 128} and b.parse_policy("") == {}
+
+
+def test_rollout_roofline_objects_can_be_recomputed_from_their_own_fields(tmp_path):
+    """the fused rollout's roofline is VALU issue — floor = lanes x VALU per env-step / (16 lanes x SIMDs) / clock — and a
+    reader must be able to recompute every fraction from the JSON alone.  The counter reader is checked on a synthetic rocpd database:
+    dispatches of one kernel name are told apart by their order, each variant's first launch (its warm-up) is left out."""
+    import sqlite3
+    b = _bench()
+    n = 1 << 20
+    r = b.valu_roofline(n, 101.8, 2.81, 1024, "test", quarter_rate_per_env_step=1.5)
+    assert abs(r["issue_floor_us"] - n * 101.8 / (16 * 1024) / 2.4e3) < 1e-12 and abs(r["issue_floor_us"] - 2.7147) < 1e-3   # VERDICT r5's 2.71 us
+    assert abs(r["frac"] - r["issue_floor_us"] / r["measured_us"]) < 1e-15 and 0.96 < r["frac"] < 0.97
+    assert abs(r["frac_weighted"] - n * (101.8 + 4.5) / 16384 / 2.4e3 / 2.81) < 1e-12
+    w = b.write_roofline(n, 25, 4.5)
+    assert abs(w["achieved"] - 25 * n / 4.5e-6 / 1e9) < 1e-6 and abs(w["frac"] - w["achieved"] / 8000.0) < 1e-15
+    json.dumps([r, w])
+    db = str(tmp_path / "pmc_results.db")
+    c = sqlite3.connect(db)
+    c.execute("create table counters_collection (dispatch_id integer, kernel_name text, counter_name text, value real)")
+    seq = [{"variant": "f32_ring", "launches": 3, "steps": 64}, {"variant": "f32_sampled", "launches": 3, "steps": 64},
+           {"variant": "f32_epsilon_greedy", "launches": 3, "steps": 64}]
+    did = 0
+    for x, (kernel, valu) in zip(seq, (("void gymnet::rollout_kernel<gymnet::CartPole, 4, true, false, false, 1, false>(a)", 100.0),
+                                       ("void gymnet::rollout_kernel<gymnet::CartPole, 4, true, false, true, 1, false>(a)", 130.0),
+                                       ("void gymnet::rollout_kernel<gymnet::CartPole, 4, true, false, true, 1, false>(a)", 160.0))):
+        for launch in range(x["launches"]):
+            did += 1
+            for xcd in range(2):          # two rows per dispatch and counter: summed
+                c.execute("insert into counters_collection values (?,?,?,?)", (did, kernel, "SQ_WAVES", 2048.0))
+                c.execute("insert into counters_collection values (?,?,?,?)", (did, kernel, "SQ_INSTS_VALU", 2048.0 * 4 * 64 * (999.0 if launch == 0 else valu)))
+    c.execute("insert into counters_collection values (99, 'void gymnet::step_kernel<...>', 'SQ_WAVES', 1.0)")
+    c.commit(); c.close()
+    got = b.read_rollout_counters(db, seq)
+    assert [round(got[x["variant"]]["valu_per_env_step"], 6) for x in seq] == [100.0, 130.0, 160.0]
+    assert got["f32_sampled"]["lanes_per_thread"] == 4 and got["f32_epsilon_greedy"]["kernel"] == got["f32_sampled"]["kernel"]
+    import pytest
+    with pytest.raises(RuntimeError):
+        b.read_rollout_counters(db, seq[:2])                                   # the child's account and the database disagree
+    const = json.load(open(os.path.join(ROOT, "profiles", "rollout_valu.json")))
+    assert set(b.ROLLOUT_VARIANTS) <= set(const["variants"]) and all(v["valu_per_env_step"] > 50 for v in const["variants"].values())
