@@ -322,8 +322,8 @@ def measure_traffic(args, wide16=True, timeout=90):
 # memory (profiles/pmc_rollout_r05.txt).  A SIMD issues one wave-instruction of 64 lanes per 4 clocks (16 lanes per clock), so
 #     issue_floor_us = lanes x VALU instructions per env-step / (16 lanes x SIMDs) / clock
 # where "VALU per env-step" = SQ_INSTS_VALU / SQ_WAVES / lanes per thread / steps per launch (an instruction of a thread that serves
-# four lanes counts a quarter for each).  Quarter-rate instructions (v_mad_u64_u32 of the Philox draws, v_rcp) hold the pipe four
-# times as long; the floor does not price that, so the fraction of a Philox-heavy variant reads low by what the draws really cost.
+# four lanes counts a quarter for each).  Two instruction classes hold the pipe longer than 4 clocks — v_mad_u64_u32 ~5, the
+# transcendentals ~9 (tools/issue_rate_probe.hip) — and `frac_measured_rates` prices them so; the plain `frac` does not.
 ROLLOUT_VARIANTS = ("f32_ring", "f32_sampled", "f32_epsilon_greedy", "f64_ring", "f64_sampled", "f64_epsilon_greedy")
 ROLLOUT_CHILD_STEPS, ROLLOUT_CHILD_LAUNCHES = 64, 3
 ENGINE_CLOCK_GHZ = 2.4      # MI355X peak engine clock (rocminfo "Max Clock Freq": 2400 MHz); the floor is priced at the peak
@@ -409,7 +409,7 @@ def measure_rollout_valu(args, timeout=120):
         env.pop(k, None)
     out_dir = tempfile.mkdtemp(prefix="gymnet_pmc_rollout_", dir="/tmp")
     try:
-        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "-d", out_dir, "-o", "pmc", "--",
+        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "-d", out_dir, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--rollout-child", "all", "--env", args.env, "--num-envs", str(args.num_envs)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         seq = None
@@ -428,6 +428,17 @@ def measure_rollout_valu(args, timeout=120):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
+def valu_busy_in_pass(counters, simds):
+    """VALU-pipe occupancy inside the --pmc pass itself, free of any assumed clock: every counted instruction holds its SIMD for at
+    least 4 clocks, SQ_BUSY_CYCLES (summed over the shader engines, 32 SIMDs each) is the launch's length in the chip's OWN clocks:
+    busy = SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines).  tools/gpu_valu_counter_check.sh calibrates both counters on a
+    kernel of known instruction count (profiles/issue_rate_r06.txt): 65585 counted for 65536 + 49 executed, 0.95 busy for back-to-back FMAs."""
+    if not counters.get("SQ_BUSY_CYCLES") or not counters.get("SQ_INSTS_VALU"):
+        return None
+    engines = max(1, simds // 32)
+    return counters["SQ_INSTS_VALU"] * 4.0 / (simds * counters["SQ_BUSY_CYCLES"] / engines)
+
+
 def valu_roofline(n, valu_per_env_step, measured_us, simds, source, quarter_rate_per_env_step=None):
     """The fused rollout's roofline object: bound by VALU issue (see the block comment above)."""
     lanes_per_clock = 16 * simds
@@ -437,11 +448,15 @@ def valu_roofline(n, valu_per_env_step, measured_us, simds, source, quarter_rate
          "frac": floor_us / measured_us,
          "formula": "issue_floor_us = lanes x valu_per_env_step / (16 x simds) / clock_GHz / 1e3; frac = issue_floor_us / measured_us"}
     if quarter_rate_per_env_step is not None:
-        # 64-bit integer multiply-adds (the Philox rounds) and transcendentals issue at a quarter of the rate: three more issue slots each
-        w = valu_per_env_step + 3.0 * quarter_rate_per_env_step
-        r.update(quarter_rate_per_env_step=quarter_rate_per_env_step, issue_floor_weighted_us=n * w / lanes_per_clock / (ENGINE_CLOCK_GHZ * 1e3),
-                 frac_weighted=n * w / lanes_per_clock / (ENGINE_CLOCK_GHZ * 1e3) / measured_us,
-                 weighted_note="quarter-rate instructions (SQ_INSTS_VALU_INT64 + SQ_INSTS_VALU_TRANS_F32 per env-step) priced at four issue slots")
+        # the same floor with the two slower instruction classes at their MEASURED cost (tools/issue_rate_probe.hip,
+        # profiles/issue_rate_r06.txt: v_mad_u64_u32 ~5 clocks per wave, transcendentals ~9, everything else 4)
+        i64, trans = quarter_rate_per_env_step
+        clocks = 4.0 * valu_per_env_step + 1.0 * i64 + 5.0 * trans
+        r.update(int64_per_env_step=i64, trans_per_env_step=trans,
+                 issue_floor_measured_rates_us=n * clocks / 64.0 / simds / (ENGINE_CLOCK_GHZ * 1e3),
+                 frac_measured_rates=n * clocks / 64.0 / simds / (ENGINE_CLOCK_GHZ * 1e3) / measured_us,
+                 measured_rates_note="clocks per env-step = 4 x VALU + 1 x SQ_INSTS_VALU_INT64 + 5 x SQ_INSTS_VALU_TRANS_F32 (per env-step); "
+                                     "floor = lanes x clocks / 64 / simds / clock")
     return r
 
 
@@ -1066,10 +1081,11 @@ def main():
     facade = None
     if extras and args.env == "CartPole-v1":
         try:
-            facade = {"note": "N = 1 through the host boundary (Python facade, ctypes): the default goes through GYMNET_FLAG_RESIDENT — a resident "
-                              "single-wave kernel polling a mailbox in pinned host memory, no launch / synchronize per step; *_launch_path = one "
-                              "kernel launch + one synchronize per call.  The engine is built for batches"}
-            for label, dt, res in (("float64_default", "float64", True), ("float32", "float32", True), ("float64_launch_path", "float64", False)):
+            facade = {"note": "N = 1 through the host boundary (Python facade, ctypes).  float64_default = the facade as a drop-in gets it: one kernel launch + "
+                              "one synchronize per call.  *_resident = GYMNET_FLAG_RESIDENT (opt-in since round 6): a resident single-wave kernel polling a "
+                              "mailbox in pinned host memory, no launch / synchronize per step — for loops that only step (a device-wide synchronize "
+                              "elsewhere in the process waits for its ~5 ms idle timeout).  The engine is built for batches"}
+            for label, dt, res in (("float64_default", "float64", False), ("float64_resident", "float64", True), ("float32_resident", "float32", True)):
                 cp = pkg.CartPoleEnv(device=dev_index, seed=seed, dtype=dt, resident=res)
                 try:
                     cp.Reset()
@@ -1292,10 +1308,16 @@ def main():
                         cs = valu[key].get("counters") or {}
                         q = None
                         if cs.get("SQ_WAVES") and "SQ_INSTS_VALU_INT64" in cs:
-                            q = ((cs["SQ_INSTS_VALU_INT64"] + cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) / cs["SQ_WAVES"]
-                                 / valu[key]["lanes_per_thread"] / valu[key]["steps_per_launch"])
+                            per = cs["SQ_WAVES"] * valu[key]["lanes_per_thread"] * valu[key]["steps_per_launch"]
+                            q = (cs["SQ_INSTS_VALU_INT64"] / per, cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / per)
                         leg["roofline"] = valu_roofline(n, valu[key]["valu_per_env_step"], leg["us_per_step"], simds, src, q)
                         leg["roofline"]["kernel"] = valu[key].get("kernel")
+                        busy = valu_busy_in_pass(cs, simds)
+                        if busy is not None:
+                            leg["roofline"]["valu_busy_in_pmc_pass"] = busy
+                            leg["roofline"]["valu_busy_note"] = ("SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines) of the profiled launches: no assumed clock. "
+                                                                 "`frac` prices the floor at the 2.4 GHz peak clock and 4 clocks per counted instruction against the UNPROFILED time; "
+                                                                 "it can read a few percent above 1 (the short profiled launches run at a lower clock and pay a launch ramp per 64 steps)")
             except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
                 out["fused_rollout"]["roofline_error"] = repr(e)[:300]
         if not args.no_cpu_baseline:

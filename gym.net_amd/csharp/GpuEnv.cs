@@ -34,7 +34,7 @@ namespace Gym.Envs.Amd {
 
         /// maxEpisodeSteps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; the reference has none,
         /// SURVEY F6): the step that reaches the limit returns Done = true with Information["TimeLimit.truncated"] = true.
-        protected GpuEnv(GymnetEnvId env, int device, ulong seed, int maxEpisodeSteps, bool validateActions, bool float64 = false) {
+        protected GpuEnv(GymnetEnvId env, int device, ulong seed, int maxEpisodeSteps, bool validateActions, bool float64 = false, bool resident = false) {
             Native.Check(Native.gymnet_env_describe((int) env, out GymnetEnvInfo info));
             _obsDim = info.obs_dim; _boxAction = info.action_is_box != 0;
             _f64 = float64;
@@ -50,9 +50,10 @@ namespace Gym.Envs.Amd {
             if (validateActions) flags |= GymnetFlags.ValidateActions;
             if (maxEpisodeSteps > 0) flags |= GymnetFlags.EpisodeStats;
             if (float64) flags |= GymnetFlags.F64;
-            // the per-instance loop (README.md:32-52) is latency-bound: Step / Reset go through the resident kernel's mailbox
-            // (no kernel launch, no stream synchronize per call); bit-identical to the launch path
-            flags |= GymnetFlags.Resident;
+            // resident (opt-in since round 6): Step / Reset go through the resident kernel's mailbox — no kernel launch, no stream
+            // synchronize per call, bit-identical — at the price that a device-wide synchronize elsewhere in the process waits for the
+            // kernel's idle timeout (~5 ms): a host that also trains on the GPU keeps the default, one launch per call
+            if (resident) flags |= GymnetFlags.Resident;
             var cfg = new GymnetConfig {
                 struct_size = (uint) sizeof(GymnetConfig), env_id = (int) env, num_envs = 1, lane_offset = 0,
                 device = device, flags = (uint) flags, seed = seed, max_episode_steps = maxEpisodeSteps

@@ -556,8 +556,22 @@ int rollout_steps(gymnet_vecenv *h, const void *d_actions, int64_t steps, int64_
 
 namespace gymnet {
 
-// ~1.5 us per poll over PCIe: the resident kernel leaves after ~50-75 ms without a command
-constexpr uint64_t kResidentIdlePolls = 40000;
+// ~1.5 us per poll over PCIe: the resident kernel leaves after ~4-5 ms without a command (rounds 4-5: 40000 polls = 50-75 ms).  While
+// it spins it occupies the handle's stream and one wave, and anything that waits for the WHOLE device — hipDeviceSynchronize,
+// torch.cuda.synchronize(), a hipFree out of a caching allocator — or that serialises dispatch (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL)
+// waits for this timeout: it bounds what a host that mixes an env loop with other GPU work in one process can lose per
+// such call.  A loop that steps back to back never sees it; a step after a longer pause pays one relaunch (~25 us, the launch path's
+// cost).  GYMNET_FLAG_RESIDENT is opt-in in every facade for the same reason.
+constexpr uint64_t kResidentIdlePolls = 3000;
+
+// a polite busy-wait: the host thread spins on a cache line the GPU writes over PCIe
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
 
 template <class R>
 static int resident_start_typed(gymnet_vecenv *h) {
@@ -619,11 +633,26 @@ static int resident_command(gymnet_vecenv *h, uint32_t cmd, const void *actions,
                 ST_TRY(h->f64 ? resident_start_typed<double>(h) : resident_start_typed<float>(h));
                 h->resident_running = true;
             } else if (hipStreamQuery(h->stream) == hipSuccess) {
+                // the stream is empty although nobody answered: the kernel is gone.  Nothing will ever read the posted command; resync
+                // the tick from what the kernel last published so that the next call starts a fresh kernel on consistent state
                 h->resident_running = false;
+                h->tick = h->mb->tick;
+                __atomic_store_n(&h->mb->done_seq, seq, __ATOMIC_RELAXED);      // the command is void: a restarted kernel must not run it late
                 return fail(h, GYMNET_ERR_HIP, "the resident kernel ended without answering command %llu", (unsigned long long)seq);
             }
-            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(10)) return fail(h, GYMNET_ERR_HIP, "the resident kernel does not answer (10 s)");
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(10)) {
+                //  do not leave the command in the mailbox for a late-waking kernel to apply to NEWER actions: overwrite it
+                // with EXIT, wait until the kernel has left (it publishes its tick on the way out), void the sequence number
+                h->mb->cmd = kMailboxExit;
+                __atomic_store_n(&h->mb->cmd_seq, ++h->mb_seq, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(h->stream);
+                h->resident_running = false;
+                h->tick = h->mb->tick;
+                return fail(h, GYMNET_ERR_HIP, "the resident kernel did not answer command %llu within 10 s; it has been stopped and the next call starts a new one",
+                            (unsigned long long)seq);
+            }
         }
+        cpu_relax();
     }
     const char *mb_obs = reinterpret_cast<const char *>(h->mb) + kMailboxObsOffset;
     if (obs_out) std::memcpy(obs_out, mb_obs, (size_t)h->n * d.obs_dim * h->esz);

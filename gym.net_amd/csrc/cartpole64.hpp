@@ -106,17 +106,23 @@ constexpr uint64_t kStreamReset64 = 0xC2B2AE3D27D4EB4Full;
 //   (A divisor with 53 significant bits would not allow this argument: the 24-bit constant is what makes it a theorem.)
 // Below 2^-900 the product x * ZL approaches the subnormal range and the bound degrades; the step never divides such a value
 // (the three dividends are 10 + ..., masspole * cos^2 and polemass_length * thetaacc * cos: >= 2^-200 in magnitude or exactly 0).
-// Outside the theorem because ZL < 0: x = -0 yields +0 (the division: -0) and x = +-inf yields NaN (the division: +-inf).  Neither
-// can change a step's result: two of the quotients are subtracted from a non-zero term (4/3 - ..., temp - ...: a zero of either
-// sign leaves it unchanged), the third dividend is +-10 + ... (never zero), and an infinite dividend needs a state that is
-// already non-finite.  The CPU twin mirrors the fma pair, so GPU == twin holds for every input regardless.
+// Outside the theorem because ZL < 0: x = -0 yields +0 (the division: -0) and x = +-inf would yield NaN (the division: +-inf).
+// The zero cannot change a step's result: two of the quotients are subtracted from a non-zero term (4/3 - ..., temp - ...: a zero of
+// either sign leaves it unchanged), the third dividend is +-10 + ... (never zero).  The infinity CAN be reached from a finite state
+// (ADVICE r5): without auto-reset a lane stepped far past done grows without bound, polemass_length * theta_dot^2 * sin(theta)
+// overflows, and where the reference carries +-inf on (and reports done: inf > threshold) a NaN would compare false.  apply()
+// therefore returns x itself for an infinite x (= x / C, C > 0): one v_cmp_class per call and a branch nobody takes.  The CPU twin
+// mirrors both, so GPU == twin holds for every input; tests/test_gpu_f64.py steps such states against the plain division.
 struct DivByTotalMass64 {
     static constexpr double C = (double)(0.1f + 1.0f);                  // 0x1.19999ap+0 exactly
     static constexpr double ZH = 1.0 / C;                               // RN(1/C)  = 0x1.d1745c6e043b8p-1
     // RN(1/C - ZH), written out: the compile-time evaluation of (1/C - ZH) in long double is not portable between host and
     // device passes.  tools/prove_div_total_mass_f64.py derives both constants in exact arithmetic and checks these literals.
     static constexpr double ZL = -0x1.4633f3e678be9p-55;
-    __host__ __device__ __forceinline__ static double apply(double x) { return __builtin_fma(x, ZH, x * ZL); }
+    __host__ __device__ __forceinline__ static double apply(double x) {
+        if (__builtin_expect(__builtin_isinf(x), 0)) return x;          // x / C for an infinite x (the fma pair would say NaN: inf - inf)
+        return __builtin_fma(x, ZH, x * ZL);
+    }
 };
 
 struct CartPole64 {

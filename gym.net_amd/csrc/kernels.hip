@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const CompactArgsT<R>
 // per shard moved them in 304 us (1.2 us per vector step of the rollout); split eight ways the copy runs at memory speed.
 // A shard's count may exceed its capacity (records beyond it were dropped by the rollout kernel): only the kept ones move.
 constexpr int kGatherSplit = 8;
+// thread t of the (fixed) 256-thread workgroup owns shard t in the scan and in the raw-count reduction
+static_assert(kShards == 256, "gather_episodes_kernel / compact_done_kernel index the shard counters by threadIdx.x of a 256-thread workgroup");
 __global__ __launch_bounds__(256) void gather_episodes_kernel(const EpisodeGatherArgs a) {
     __shared__ uint32_t scan[kShards];
     const int t = threadIdx.x;

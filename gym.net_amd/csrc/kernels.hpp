@@ -48,7 +48,7 @@ typedef StepArgsT<double> StepArgs64;
 
 // vec: envs per thread (4 = dwordx4 streams, 1 = scalar); block: threads per workgroup;
 // nt: non-temporal mask (0 none, 12 action + reward/done streams, 15 every stream)
-constexpr int kShards = 256;        // power of two
+constexpr int kShards = 256;        // power of two; the gather kernels' workgroup size (kernels.hip static_assert)
 constexpr int kCountStride = 16;    // uint32 words between shard counters (64 bytes: one counter per cache line)
 constexpr int kAfterStride = 8;     // uint64 words between after_done shards (64 bytes)
 

@@ -210,6 +210,16 @@ __device__ __forceinline__ PhiloxWords neighbour_words(const PhiloxWords &w) {
     return o;
 }
 
+// Round 6, tools/issue_rate_probe.hip (profiles/issue_rate_r06.txt): on gfx950 a VALU instruction executed under an exec mask with 16 or
+// fewer ACTIVE lanes — any 16: the first, every fourth, lanes 16..31 — holds the SIMD ~21 cycles instead of ~4.4 (17 lanes: 4.4).  The
+// compacted reset's draw ran with the wave's ~11 finished slots as its only active lanes.  With this constant every active lane of the
+// wave makes a draw (the ones without a slot repeat slot 0's and park it in a row nobody reads): same words for the slots, full mask.
+#ifdef GYMNET_PROBE_RESET_MASKED       // probe builds only: the round 3-5 form, for the A/B
+constexpr bool kResetFullExec = false;
+#else
+constexpr bool kResetFullExec = true;
+#endif
+
 template <class Env>
 struct ResetScratch {
     uint32_t slot[64];              // rank -> owner lane * VEC + sub-lane
@@ -260,8 +270,8 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, typename En
             const uint32_t r = lane >> 1, call = lane & 1u;
             const bool draws = r < A && r < total - base;      // (lanes 2r and 2r + 1 are both active: 2r + 1 < 2A <= active)
             PhiloxWords w{};
-            if (draws) {
-                const uint32_t sl = sc->slot[r];
+            if (kResetFullExec || draws) {
+                const uint32_t sl = sc->slot[draws ? r : 0u];
                 const int64_t gl = wave_i0 + (int64_t)sl;
                 uint64_t key = a.seed;
                 if constexpr (LANE_SEEDS) {
@@ -270,14 +280,16 @@ __device__ __forceinline__ void reset_pending_wave(uint32_t pending, typename En
                 w = lane_words(Env::reset_call_key(key, call), a.lane_offset + (uint64_t)gl, tick);
             }
             const PhiloxWords other = neighbour_words(w);
-            if (draws && call == 0) {
+            if ((kResetFullExec || draws) && call == 0) {
                 Real sj[S];
                 Env::reset_from_words(sj, w, other);
 #pragma unroll
                 for (int k = 0; k < S; ++k) sc->draw[r][k] = sj[k];
             }
-        } else if (lane < total - base) {                      // (an active lane by construction: lane < A whenever it has a slot)
-            const uint32_t sl = sc->slot[lane];
+        } else if (kResetFullExec || lane < total - base) {    // (a lane with a slot is active by construction: lane < A)
+            // kResetFullExec: EVERY active lane draws — the lanes without a slot redo slot 0's draw and park it in their own row, which
+            // nobody reads (see the constant's comment: an instruction under a mask of <= 16 lanes can cost five times a full one)
+            const uint32_t sl = sc->slot[lane < total - base ? lane : 0u];
             const int64_t gl = wave_i0 + (int64_t)sl;
             Real sj[S];
             bool drawn = false;
@@ -670,15 +682,15 @@ __device__ __forceinline__ void reset_group_deferred(uint32_t pending, StateOf s
         const uint32_t r = lane >> 1, call = lane & 1u;
         const bool draws = r < total - base;
         PhiloxWords w{};
-        if (draws) {
-            const uint32_t sl = sc->slot[r];
+        if (kResetFullExec || draws) {
+            const uint32_t sl = sc->slot[draws ? r : 0u];
             const uint32_t owner = sl >> 3, q = sl & 7u;
             const int64_t gl = ((t_wave0 + owner) + (int64_t)(first_pair + (int)(q >> 1)) * T) * 2 + (q & 1u);
             w = lane_words(Env::reset_call_key(a.seed, call), a.lane_offset + (uint64_t)gl, tick);
         }
         // the even lane takes its odd neighbour's words (call 1) and converts
         const PhiloxWords other = neighbour_words(w);
-        if (draws && call == 0) {
+        if ((kResetFullExec || draws) && call == 0) {
             Real sj[S];
             Env::reset_from_words(sj, w, other);
 #pragma unroll

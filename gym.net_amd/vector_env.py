@@ -687,14 +687,16 @@ class GpuEnv:
     ENV = "CartPole-v1"
     DTYPE = np.float32          # CartPoleEnv overrides: float64, the reference's own arithmetic
 
-    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0, dtype=None, resident=True):
+    def __init__(self, device=0, seed=0, validate_actions=False, max_episode_steps=0, dtype=None, resident=False):
         """max_episode_steps > 0 adds the TimeLimit wrapper upstream gym registers with the env (500 / 200; an extension: the
         reference has no time limit): the step that reaches the limit returns Done with
         Information["TimeLimit.truncated"] = True — the same shape as the C# GpuEnv (csharp/GpuEnv.cs).
-        resident (default): Step / Reset go through GYMNET_FLAG_RESIDENT — a resident single-wave kernel polling a mailbox in pinned
-        host memory — instead of a kernel launch + synchronize per call: the per-instance loop of README.md:32-52 is latency-bound.
-        Bit-identical results.  resident=False: one launch per call (e.g. when the process issues device-wide synchronizes elsewhere
-        and must not wait for the resident kernel's idle timeout)."""
+        resident=True (opt-in since round 6): Step / Reset go through GYMNET_FLAG_RESIDENT — a resident single-wave kernel polling
+        a mailbox in pinned host memory — instead of a kernel launch + synchronize per call: ~3x lower latency for a loop that does
+        nothing but step (README.md:32-52), bit-identical results.  The price: while the kernel waits for the next command it occupies
+        the handle's stream for up to ~5 ms, and a device-wide synchronize elsewhere in the process (torch.cuda.synchronize(), a
+        caching allocator's hipFree) or serialised dispatch (rocprofv3 --pmc) waits for that — so a process that also trains on the
+        GPU keeps the default, one launch per call."""
         self._v = VectorEnv(self.ENV, 1, device=device, seed=seed, auto_reset=False, validate_actions=validate_actions,
                             episode_stats=max_episode_steps > 0, max_episode_steps=max_episode_steps,
                             dtype=self.DTYPE if dtype is None else dtype, resident=resident)

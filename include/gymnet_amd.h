@@ -336,7 +336,13 @@ typedef struct gymnet_rollout_spec {
     float   *d_ep_return;        /* [ep_capacity] episode return  (EPISODE_STATS) */
     int32_t *d_ep_length;        /* [ep_capacity] episode length  (EPISODE_STATS) */
     int64_t  ep_capacity;        /* records the arrays hold; a random-action CartPole rollout ends ~0.045 x num_envs episodes per step */
-    uint32_t *d_ep_count;        /* [2]: [0] records written, [1] episodes that ended (> [0]: capacity exceeded, records dropped) */
+    uint32_t *d_ep_count;        /* [2]: [0] records written, [1] episodes that ended.  [1] > [0]: records were dropped — because more
+                                    episodes ended than ep_capacity, OR because one SHARD's segment filled up: inside the kernel the
+                                    records are kept in 256 segments (a wave appends to segment (wave index mod 256): one atomic per
+                                    wave and flush instead of 4096 waves on one counter) of 2 * ceil(ep_capacity / 256) + 64 records
+                                    each.  Evenly finishing lanes never get near that; a batch whose finishing lanes are concentrated
+                                    in a few waves (or a capacity sized to the exact episode count) can: size ep_capacity with the
+                                    factor two in mind, or check [1] == [0] */
 } gymnet_rollout_spec;
 int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout_spec *spec);
 /* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout; float32, or float64 for a

@@ -367,8 +367,7 @@ public:
         gymnet_config cfg{};
         cfg.struct_size = sizeof cfg; cfg.env_id = GYMNET_ENV_CARTPOLE; cfg.num_envs = 1; cfg.device = device;
         cfg.flags = GYMNET_FLAG_F64 | extra_flags; cfg.seed = seed;
-        // single instance: the resident latency path (see CartPoleEnv below) whenever the extra flags allow it
-        if (!(extra_flags & (GYMNET_FLAG_DONE_LIST | GYMNET_FLAG_FINAL_OBS | GYMNET_FLAG_DOUBLE_BUFFER))) cfg.flags |= GYMNET_FLAG_RESIDENT;
+        // (the resident latency path is opt-in: pass GYMNET_FLAG_RESIDENT in extra_flags — see CartPoleEnv below for when it pays)
         check(gymnet_vecenv_create(&cfg, &h_));
     }
     CartPoleEnv64(const CartPoleEnv64 &) = delete;
@@ -396,9 +395,11 @@ private:
 /// arithmetic: 1e-5 per teacher-forced step; CartPoleEnv64 above is the reference-exact one).
 class CartPoleEnv {
 public:
-    /// GYMNET_FLAG_RESIDENT: the per-instance loop (README.md:32-52) is latency-bound — Step / Reset are served by a resident single-wave
-    /// kernel through a mailbox in pinned host memory (no launch, no synchronize per call); bit-identical to the launch path
-    explicit CartPoleEnv(int device = 0, uint64_t seed = 0, bool resident = true) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed, resident ? GYMNET_FLAG_RESIDENT : 0u) {}
+    /// resident = true (opt-in since round 6): GYMNET_FLAG_RESIDENT — Step / Reset are served by a resident single-wave kernel through a
+    /// mailbox in pinned host memory (no launch, no synchronize per call; ~3x lower latency for a loop that only steps; bit-identical).
+    /// While it waits for the next command the kernel occupies the handle's stream for up to ~5 ms: a device-wide synchronize elsewhere
+    /// in the process waits for that, which is why a host that also trains on the GPU keeps the default (one launch per call).
+    explicit CartPoleEnv(int device = 0, uint64_t seed = 0, bool resident = false) : v_(GYMNET_ENV_CARTPOLE, 1, device, seed, resident ? GYMNET_FLAG_RESIDENT : 0u) {}
     std::vector<float> Reset() { return v_.Reset(); }                           // CartPoleEnv.cs:63-67
     gymnet::Step Step(int action) { return v_.Step(std::vector<int32_t>{action})[0]; }   // CartPoleEnv.cs:137-186
     /// Env<TAction>.Step(TAction) where TAction : Enum (Env.cs:43-53): the enum's integer value is the discrete action

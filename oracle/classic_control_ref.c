@@ -274,19 +274,20 @@ double ref_div_total_mass_f64_kernel(double x) {
     const double C = (double)CP_TOTAL_MASS;
     const double ZH = 1.0 / C;
     const double ZL = -0x1.4633f3e678be9p-55;
+    if (isinf(x)) return x;                  /* = x / C (C > 0); the fma pair would give inf - inf = NaN (cartpole64.hpp) */
     return fma(x, ZH, x * ZL);
 }
 
 /* `count` pseudo-random binary64 dividends (xorshift64*, both signs, exponents spread over 2^-300 .. 2^300 with most of the mass
  * in the range the step produces, plus a few special values): the number for which the fma pair differs from IEEE x / total_mass.
- * Outside the theorem, by construction (ZL < 0): x = -0 gives +0 where the division gives -0, and x = +-inf gives NaN where the
- * division gives +-inf.  Neither is observable in a step: every quotient is added to / subtracted from a non-zero term (temp is
- * (+-10 + ...) / C itself), and an infinite dividend means the state was already non-finite. */
+ * Outside the theorem, by construction (ZL < 0): x = -0 gives +0 where the division gives -0 — not observable in a step: every
+ * quotient is added to / subtracted from a non-zero term (temp is (+-10 + ...) / C itself).  x = +-inf is returned as it is (the
+ * division's answer; the fma pair alone would give NaN) — and is among the special values checked here. */
 int64_t ref_check_div_total_mass_f64(uint64_t seed, int64_t count) {
     int64_t bad = 0;
     uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
     const double C = (double)CP_TOTAL_MASS;
-    const double special[] = { 0.0, 1.0, -1.0, 0x1.19999ap+0, -0x1.19999ap+0, 0x1.fffffffffffffp+1000, -0x1p-900, 0x1p-900 };
+    const double special[] = { 0.0, 1.0, -1.0, 0x1.19999ap+0, -0x1.19999ap+0, 0x1.fffffffffffffp+1000, -0x1p-900, 0x1p-900, INFINITY, -INFINITY };
     for (unsigned i = 0; i < sizeof special / sizeof special[0]; ++i) {
         const double a = ref_div_total_mass_f64_kernel(special[i]), b = special[i] / C;
         if (memcmp(&a, &b, sizeof a) != 0) ++bad;

@@ -396,6 +396,31 @@ def test_f64_multi_pair_step_beyond_one_resident_generation_is_launched_in_slice
     assert d.any() and np.array_equal(outs[1][0][:, d], fresh[:, d])
 
 
+def test_f64_overflowing_dividend_steps_like_the_division(gpu_pkg, oracle):
+    """the float64 kernel's `/ total_mass` is an fma pair that would turn an INFINITE dividend into NaN where the reference's
+    division hands the infinity on — and a lane stepped far past done (no auto-reset) gets there from a finite state: polemass_length *
+    theta_dot^2 * sin(theta) overflows.  The kernel (and its twin) return x for an infinite x: here states with |theta_dot| up to 1e200
+    step bit-identically to the twin (NaN == NaN) and report the reference restatement's done flags for three steps: where the plain
+    division carries an infinity (which compares: done) the kernel does too, where it yields NaN (inf - inf) so does the kernel."""
+    big = np.array([[0.0, 0.0, 0.0, 1.0, -1.0, 0.5], [0.0, 1.0, -2.0, 0.1, 0.0, 0.0], [0.3, -0.1, 0.05, 0.01, -0.2, 0.2],
+                    [1e160, -1e170, 1e200, -1e155, 3e154, 1e100]])
+    n = big.shape[1]
+    a = np.array([0, 1, 1, 0, 1, 0], np.int32)
+    with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=False, dtype=np.float64) as env:
+        env.Reset()
+        env.SetState(big)
+        s_ref = big
+        s_twin = big
+        for t in range(3):
+            out = env.Step(a)
+            s_twin, r_twin, d_twin, _ = oracle.cartpole_step(s_twin, a, dtype=np.float64, kernel_sincos=True)
+            s_ref, r_ref, d_ref, _ = oracle.cartpole_step(s_ref, a)
+            assert np.array_equal(env.GetState(), s_twin, equal_nan=True), t
+            assert np.array_equal(out.Done, d_ref.astype(bool)), t
+            assert np.array_equal(np.isinf(s_twin), np.isinf(s_ref)) and np.array_equal(np.isnan(s_twin), np.isnan(s_ref)), t
+        assert np.isinf(s_twin).any() and out.Done.any() and not out.Done.all()      # (a lane that is NaN in the REFERENCE's arithmetic too reports not-done there as well)
+
+
 @pytest.mark.parametrize("case", ["everyone_falls", "one_thread_tail", "odd_tail", "lane_seeds"])
 def test_f64_two_lanes_per_reset_edges(gpu_pkg, oracle, case):
     """The float64 reset is two Philox calls; the compacted forms spread ONE reset over two lanes (lane 2r call 0, lane 2r + 1 call 1,

@@ -54,10 +54,10 @@ def test_resident_path_is_bit_identical_to_the_launch_path(gpu_pkg, name, dtype,
 
 @pytest.mark.timeout(300)
 def test_resident_facade_loop_idle_timeout_and_errors(gpu_pkg):
-    """The README loop on the single-instance facade (which asks for the resident path): the reference-test trace shape, an idle
+    """The README loop on the single-instance facade asked for the resident path: the reference-test trace shape, an idle
     pause longer than the kernel's timeout in the middle (it leaves by itself and is restarted by the next call), and the error
     paths (invalid action before anything is posted; unsupported combinations at create)."""
-    a, b = gpu_pkg.CartPoleEnv(seed=7), gpu_pkg.CartPoleEnv(seed=7, resident=False)
+    a, b = gpu_pkg.CartPoleEnv(seed=7, resident=True), gpu_pkg.CartPoleEnv(seed=7)      # (opt-in since round 6: the default is the launch path)
     try:
         assert a._v.Resident and not b._v.Resident
         done = True
@@ -88,3 +88,37 @@ def test_resident_facade_loop_idle_timeout_and_errors(gpu_pkg):
         n = kw.pop("num_envs")
         with pytest.raises(NotImplementedError):
             gpu_pkg.VectorEnv("CartPole-v1", n, resident=True, **kw)
+
+
+@pytest.mark.timeout(300)
+def test_resident_env_interleaved_with_device_wide_synchronizes_is_bounded(gpu_pkg):
+    """the reference's usage shape is an env loop PLUS GPU training in one process.  A resident kernel that waits for its next
+    command occupies the handle's stream, and a device-wide synchronize (torch.cuda.synchronize(), a caching allocator's hipFree) waits
+    until it leaves: with rounds 4-5's 50-75 ms idle timeout a microsecond-scale step became a stall of tens of milliseconds.  The
+    timeout is ~5 ms now and the facades no longer ask for the flag by default: an iteration of step + synchronize is bounded by a
+    few milliseconds on the resident path, and costs no more than the launch path's step on the default one."""
+    import torch
+    x = torch.zeros(1 << 16, device="cuda")
+
+    def loop(env, iters=60):
+        env.Reset()
+        ts = []
+        for i in range(iters):
+            t0 = time.perf_counter()
+            if env.Step(i % 2).Done:
+                env.Reset()
+            x.add_(1.0)                                                 # "training": other GPU work of the same process
+            torch.cuda.synchronize()                                    # device-wide: waits for everything, the resident kernel included
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], max(ts[5:])
+    d, r = gpu_pkg.CartPoleEnv(seed=3), gpu_pkg.CartPoleEnv(seed=3, resident=True)
+    try:
+        assert not d._v.Resident and r._v.Resident                     # the default facade takes the launch path
+        med_d, worst_d = loop(d)
+        med_r, worst_r = loop(r)
+        assert med_d < 2e-3, med_d                                      # one launch + one synchronize per call: tens of microseconds
+        assert med_r < 20e-3 and worst_r < 100e-3, (med_r, worst_r)     # bounded by the idle timeout (~5 ms), not by 50-75 ms
+        assert int(x[0].item()) == 120
+        print(f"step + device-wide synchronize per iteration: launch path median {med_d * 1e6:.0f} us, resident path median {med_r * 1e6:.0f} us (worst {worst_r * 1e3:.1f} ms)")
+    finally:
+        d.CloseEnvironment(); r.CloseEnvironment()

@@ -753,8 +753,20 @@ def test_f64_constant_division_is_proved_and_sampled(oracle):
     C = oracle.cartpole_constants()["total_mass"]
     for x in (10.0, -10.0, 0.1000000015, 3.3e-9, -7.25e11, 1e-200, 0.0):
         assert L.ref_div_total_mass_f64_kernel(x) == x / C
-    # outside the theorem, documented (ZL < 0): the sign of a zero quotient and infinite dividends
-    assert L.ref_div_total_mass_f64_kernel(-0.0) == 0.0 and np.isnan(L.ref_div_total_mass_f64_kernel(np.inf))
+    # outside the theorem, documented (ZL < 0): the sign of a zero quotient.  An infinite dividend is handed through like the division
+    # does (round 6, ADVICE r5: the fma pair alone said NaN, and a lane stepped far past done can get there from a finite state)
+    assert L.ref_div_total_mass_f64_kernel(-0.0) == 0.0
+    assert L.ref_div_total_mass_f64_kernel(np.inf) == np.inf and L.ref_div_total_mass_f64_kernel(-np.inf) == -np.inf
+    # ... so a state whose theta_dot^2 overflows steps like the reference's arithmetic: done (inf compares), not NaN-and-false
+    big = np.array([[0.0, 0.0, 0.0], [0.0, 1.0, -2.0], [0.3, -0.1, 0.05], [1e160, -1e170, 1e200]])
+    a = np.array([0, 1, 1], np.int32)
+    twin_s, twin_r, twin_d, _ = oracle.cartpole_step(big, a, dtype=np.float64, kernel_sincos=True)
+    ref_s, ref_r, ref_d, _ = oracle.cartpole_step(big, a)
+    assert np.array_equal(twin_d, ref_d) and np.array_equal(twin_r, ref_r)
+    assert np.array_equal(np.isinf(twin_s), np.isinf(ref_s)) and np.array_equal(np.isnan(twin_s), np.isnan(ref_s))
+    nxt_t = oracle.cartpole_step(twin_s, a, dtype=np.float64, kernel_sincos=True)
+    nxt_r = oracle.cartpole_step(ref_s, a)
+    assert np.array_equal(nxt_t[2], nxt_r[2]) and nxt_r[2].all()                 # the step after: theta' = theta + tau * (+-inf) -> done
     # twin (fma pair) == the same operation sequence with the plain division, on states incl. large angles and velocities
     rng = np.random.default_rng(5)
     n = 200_000

@@ -11,12 +11,16 @@
 
 constexpr int ACC = 16;
 
-template <int ACTIVE>
+// which lanes run the loop: MODE 0 the first ACTIVE lanes; 1 every fourth lane (16 lanes, four in each 16-lane quarter); 2 lanes 16 .. 31 only;
+// 3 the first ACTIVE lanes AND lane 63
+template <int ACTIVE, int MODE = 0>
 __global__ __launch_bounds__(256) void k_fma(float *out, int iters, float a, float b) {
     float x[ACC];
 #pragma unroll
     for (int i = 0; i < ACC; ++i) x[i] = (float)(threadIdx.x + i);
-    if ((threadIdx.x & 63) < ACTIVE) {                 // the loop runs under this exec mask
+    const int lane = threadIdx.x & 63;
+    const bool on = MODE == 0 ? lane < ACTIVE : MODE == 1 ? (lane & 3) == 0 : MODE == 2 ? (lane >= 16 && lane < 32) : (lane < ACTIVE || lane == 63);
+    if (on) {                                          // the loop runs under this exec mask
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < ACC; ++i) x[i] = __builtin_fmaf(x[i], a, b);
@@ -85,6 +89,25 @@ __global__ __launch_bounds__(256) void k_rcp(float *out, int iters, float a, flo
     if (s == 12345.678f) out[0] = s;
 }
 
+// the engine clock under load: s_memtime (clock64: shader clock cycles) against s_memrealtime (wall_clock64: the constant 100 MHz counter)
+// around a long full-mask FMA loop, read by lane 0 of every 1024th workgroup while the whole chip runs the same loop
+__global__ __launch_bounds__(256) void k_clock(float *out, int iters, float a, float b, unsigned long long *ticks) {
+    float x[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) x[i] = (float)(threadIdx.x + i);
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) x[i] = __builtin_fmaf(x[i], a, b);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += x[i];
+    if (s == 12345.678f) out[0] = s;
+    if (threadIdx.x == 0 && (blockIdx.x & 1023) == 0) { ticks[2 * (blockIdx.x >> 10)] = c1 - c0; ticks[2 * (blockIdx.x >> 10) + 1] = w1 - w0; }
+}
+
 template <class K>
 static double run(K kern, int blocks, int iters, float *d) {
     hipEvent_t e0, e1;
@@ -114,12 +137,42 @@ int main() {
         const double wave_instr_per_simd = (double)wps * iters * ACC * instr_per_iter_chain;
         printf("%-34s %8.3f ms  %6.2f SIMD-cycles per wave-instruction\n", name, ms, ms * 1e-3 * ghz * 1e9 / wave_instr_per_simd);
     };
+    {
+        unsigned long long *t;
+        (void)hipMalloc(&t, 64 * sizeof(unsigned long long));
+        (void)hipMemset(t, 0, 64 * sizeof(unsigned long long));
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, d, iters * 4, 1.0000001f, 1e-9f, t);
+            (void)hipDeviceSynchronize();
+            unsigned long long h[4];
+            (void)hipMemcpy(h, t, sizeof h, hipMemcpyDeviceToHost);
+            int wall_khz = 100000;
+            (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+            printf("engine clock under load: %llu shader cycles in %llu wall ticks at %d kHz = %.3f GHz (second sample %.3f GHz)\n", h[0], h[1], wall_khz,
+                   (double)h[0] / ((double)h[1] / (wall_khz * 1e3)) / 1e9, (double)h[2] / ((double)h[3] / (wall_khz * 1e3)) / 1e9);
+        }
+    }
     report("v_fma_f32   64 of 64 lanes", run(k_fma<64>, blocks, iters, d), 1);
     report("v_fma_f32   48 of 64 lanes", run(k_fma<48>, blocks, iters, d), 1);
     report("v_fma_f32   32 of 64 lanes", run(k_fma<32>, blocks, iters, d), 1);
     report("v_fma_f32   16 of 64 lanes", run(k_fma<16>, blocks, iters, d), 1);
     report("v_fma_f32   11 of 64 lanes", run(k_fma<11>, blocks, iters, d), 1);
     report("v_fma_f32    1 of 64 lanes", run(k_fma<1>, blocks, iters, d), 1);
+    report("v_fma_f32   17 of 64 lanes", run(k_fma<17>, blocks, iters, d), 1);
+    report("v_fma_f32   24 of 64 lanes", run(k_fma<24>, blocks, iters, d), 1);
+    report("v_fma_f32   every 4th lane (16)", run(k_fma<16, 1>, blocks, iters, d), 1);
+    report("v_fma_f32   lanes 16..31 only", run(k_fma<16, 2>, blocks, iters, d), 1);
+    report("v_fma_f32   lanes 0..10 and 63", run(k_fma<11, 3>, blocks, iters, d), 1);
+    {   // the same at ONE wave per SIMD and at 2: is it a matter of how many waves share the SIMD?
+        const int b1 = cus * 1, b2 = cus * 2;
+        auto rep2 = [&](const char *name, double ms, int w) {
+            printf("%-34s %8.3f ms  %6.2f SIMD-cycles per wave-instruction (%d wave(s) per SIMD)\n", name, ms, ms * 1e-3 * ghz * 1e9 / ((double)w * iters * ACC), w);
+        };
+        rep2("v_fma_f32   64 of 64 lanes", run(k_fma<64>, b1, iters, d), 1);
+        rep2("v_fma_f32   11 of 64 lanes", run(k_fma<11>, b1, iters, d), 1);
+        rep2("v_fma_f32   64 of 64 lanes", run(k_fma<64>, b2, iters, d), 2);
+        rep2("v_fma_f32   11 of 64 lanes", run(k_fma<11>, b2, iters, d), 2);
+    }
     report("v_mad_u64_u32 + v_xor (per pair)", run(k_mad64, blocks, iters, d), 1);
     report("xor + add (per pair)", run(k_xor, blocks, iters, d), 1);
     report("v_fma_f64", run(k_fma64, blocks, iters, d), 1);
