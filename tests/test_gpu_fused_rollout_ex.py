@@ -220,3 +220,81 @@ def test_sampled_action_rollout_at_2p20_lanes_equals_the_oracle_replay(gpu_pkg, 
         want = np.concatenate(want)
         assert counts[0] == counts[1] == len(want) and np.array_equal(got_rec, want)
         assert np.array_equal(got_ret, want[:, 2].astype(np.float32))              # CartPole: reward 1 per step, return == length
+
+
+@pytest.mark.parametrize("name,dtype,actions,lane_offset,launch", [
+    ("CartPole-v1", np.float32, "epsilon_greedy", 8, {"vec": 4}),    # four lanes per thread sharing ONE call per stream (words A and B)
+    ("CartPole-v1", np.float32, "epsilon_greedy", 7, {"vec": 4}),    # a shard that starts INSIDE a group of four lanes: the per-lane word path
+    ("CartPole-v1", np.float32, "sample", 3, None),                  # one lane per thread (the default at this size), word (L & 3) of its group's call
+    ("CartPole-v1", np.float64, "sample", 0, None),                  # the reference-arithmetic handle: its twin and its two-call reset draws
+    ("CartPole-v1", np.float64, "epsilon_greedy", (1 << 20) + 2, None),
+    ("Acrobot-v1", np.float32, "sample", 0, None),                   # derived observation, three actions
+    ("Acrobot-v1", np.float32, "epsilon_greedy", 6, {"vec": 2}),     # two lanes per thread (the packed form), lane offset 6: word base 2
+])
+def test_bookkeeping_rollout_variants_equal_the_oracle_replay(gpu_pkg, oracle, name, dtype, actions, lane_offset, launch):
+    """the fused bookkeeping rollout's remaining variants replayed on the CPU — not against the stepwise HIP path but
+    against the oracle: ActionSpace.Sample() / the epsilon-greedy composer from the oracle's action-stream words (TrainingPlaySession.cs:
+    46-52, Discrete.cs:17-28), the step from the oracle's kernel-semantics restatement (float32 twin; the float64 twin for the F64
+    handle; Acrobot's RK4 with its derived observation), the fused reset from the oracle's Philox draws (two calls per lane for F64),
+    the episode bookkeeping (return, length, a 13-step time limit) in NumPy.  2^16 lanes, 40 steps in ONE launch: the state, the
+    running statistics, the actions taken, the last step's observations and every (t, lane, return, length) record must match."""
+    import torch
+    n, T, limit, tick0, eps, ring = 1 << 16, 40, 13, 77, 0.35, 5
+    f64 = dtype == np.float64
+    nvals = 2 if name.startswith("CartPole") else 3
+    rng = np.random.default_rng(5)
+    policy = rng.integers(0, nvals, (ring, n)).astype(np.int32)
+    with gpu_pkg.VectorEnv(name, n, seed=SEED, auto_reset=True, dtype=dtype, lane_offset=lane_offset, episode_stats=True, max_episode_steps=limit,
+                           launch_policy=launch) as env:
+        env.ResetDevice()
+        D = env.ObsDim
+        ep = _episode_buffers(torch, n * 8)
+        rec_a = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+        rec_o = torch.zeros((T, D, n), dtype=torch.float64 if f64 else torch.float32, device="cuda")
+        pol_d = torch.from_numpy(policy).cuda()
+        torch.cuda.synchronize()
+        env.RolloutFusedDevice(pol_d if actions == "epsilon_greedy" else None, T, n, ring, actions=actions, action_seed=ASEED, action_tick0=tick0,
+                               epsilon=eps, rec_actions=rec_a, rec_obs=rec_o, episodes=ep)
+        env.Sync()
+        # ---- the replay ----
+        if f64:
+            s = oracle.cartpole_reset_f64(SEED, lane_offset, 0, n)
+        else:
+            s = oracle.env_reset(name, SEED, lane_offset, 0, n)
+        ln, ret = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        want, want_ret = [], []
+        got_a = rec_a.cpu().numpy()
+        last_obs = None
+        for t in range(T):
+            if actions == "sample":
+                a = oracle.discrete_sample(ASEED, lane_offset, tick0 + t, nvals, 0, n)
+            else:
+                a = oracle.compose_discrete(ASEED, lane_offset, tick0 + t, nvals, eps, policy[t % ring])
+            assert np.array_equal(got_a[t], a), t
+            if f64:
+                stepped, r, d, _ = oracle.cartpole_step(s, a, dtype=np.float64, kernel_sincos=True)
+                obs = stepped
+                fresh = oracle.cartpole_reset_f64(SEED, lane_offset, 1 + t, n)
+                fresh_obs = fresh
+            else:
+                stepped, obs, r, d = oracle.env_step(name, s, a, dtype=np.float32)
+                fresh, fresh_obs = oracle.env_reset(name, SEED, lane_offset, 1 + t, n, with_obs=True)
+            ln += 1
+            ret += r.astype(np.float32)
+            fin = d.astype(bool) | (ln >= limit)
+            s = np.where(fin, fresh, stepped)
+            last_obs = np.where(fin, fresh_obs, obs)
+            lanes = np.nonzero(fin)[0]
+            want.append(np.stack([np.full(len(lanes), t), lanes, ln[fin]], axis=1))
+            want_ret.append(ret[fin].copy())
+            ln[fin] = 0; ret[fin] = 0.0
+        assert np.array_equal(env.GetState(), s)
+        assert np.array_equal(rec_o[T - 1].cpu().numpy(), last_obs)                  # the observation AFTER the last step (fresh for reset lanes)
+        assert np.array_equal(env.GetArray("episode_length"), ln) and np.array_equal(env.GetArray("episode_return"), ret)
+        got_rec, got_ret, counts = _records(ep)
+        want = np.concatenate(want)
+        assert counts[0] == counts[1] == len(want) > n and np.array_equal(got_rec, want)
+        assert np.array_equal(got_ret, np.concatenate(want_ret))
+        explored = (got_a != policy[np.arange(T) % ring]).mean() if actions == "epsilon_greedy" else None
+        if explored is not None:
+            assert abs(explored - eps * (1 - 1 / nvals)) < 0.01                      # explored AND drew a different action
