@@ -323,7 +323,7 @@ def measure_traffic(args, wide16=True, timeout=90):
 #     issue_floor_us = lanes x VALU instructions per env-step / (16 lanes x SIMDs) / clock
 # where "VALU per env-step" = SQ_INSTS_VALU / SQ_WAVES / lanes per thread / steps per launch (an instruction of a thread that serves
 # four lanes counts a quarter for each).  Two instruction classes hold the pipe longer than 4 clocks — v_mad_u64_u32 ~5, the
-# transcendentals ~9 (tools/issue_rate_probe.hip) — and `frac_measured_rates` prices them so; the plain `frac` does not.
+# transcendentals ~9, float64 arithmetic ~5.3 (tools/issue_rate_probe.hip) — and `frac_measured_rates` prices them so; the plain `frac` does not.
 ROLLOUT_VARIANTS = ("f32_ring", "f32_sampled", "f32_epsilon_greedy", "f64_ring", "f64_sampled", "f64_epsilon_greedy")
 ROLLOUT_CHILD_STEPS, ROLLOUT_CHILD_LAUNCHES = 64, 3
 ENGINE_CLOCK_GHZ = 2.4      # MI355X peak engine clock (rocminfo "Max Clock Freq": 2400 MHz); the floor is priced at the peak
@@ -409,7 +409,8 @@ def measure_rollout_valu(args, timeout=120):
         env.pop(k, None)
     out_dir = tempfile.mkdtemp(prefix="gymnet_pmc_rollout_", dir="/tmp")
     try:
-        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "-d", out_dir, "-o", "pmc", "--",
+        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64",
+               "SQ_INSTS_VALU_MUL_F64", "-d", out_dir, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--rollout-child", "all", "--env", args.env, "--num-envs", str(args.num_envs)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         seq = None
@@ -448,14 +449,15 @@ def valu_roofline(n, valu_per_env_step, measured_us, simds, source, quarter_rate
          "frac": floor_us / measured_us,
          "formula": "issue_floor_us = lanes x valu_per_env_step / (16 x simds) / clock_GHz / 1e3; frac = issue_floor_us / measured_us"}
     if quarter_rate_per_env_step is not None:
-        # the same floor with the two slower instruction classes at their MEASURED cost (tools/issue_rate_probe.hip,
-        # profiles/issue_rate_r06.txt: v_mad_u64_u32 ~5 clocks per wave, transcendentals ~9, everything else 4)
-        i64, trans = quarter_rate_per_env_step
-        clocks = 4.0 * valu_per_env_step + 1.0 * i64 + 5.0 * trans
-        r.update(int64_per_env_step=i64, trans_per_env_step=trans,
+        # the same floor with the slower instruction classes at their MEASURED cost (tools/issue_rate_probe.hip,
+        # profiles/issue_rate_r06.txt: v_mad_u64_u32 ~5 clocks per wave, transcendentals ~9, float64 arithmetic ~5.3, everything else 4)
+        i64, trans, f64ops = (tuple(quarter_rate_per_env_step) + (0.0,))[:3]
+        clocks = 4.0 * valu_per_env_step + 1.0 * i64 + 5.0 * trans + 1.3 * f64ops
+        r.update(int64_per_env_step=i64, trans_per_env_step=trans, f64_arith_per_env_step=f64ops,
                  issue_floor_measured_rates_us=n * clocks / 64.0 / simds / (ENGINE_CLOCK_GHZ * 1e3),
                  frac_measured_rates=n * clocks / 64.0 / simds / (ENGINE_CLOCK_GHZ * 1e3) / measured_us,
-                 measured_rates_note="clocks per env-step = 4 x VALU + 1 x SQ_INSTS_VALU_INT64 + 5 x SQ_INSTS_VALU_TRANS_F32 (per env-step); "
+                 measured_rates_note="clocks per env-step = 4 x VALU + 1 x SQ_INSTS_VALU_INT64 + 5 x SQ_INSTS_VALU_TRANS_F32 + 1.3 x SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 "
+                                     "(per env-step: v_mad_u64_u32 ~5 clocks, transcendentals ~9, float64 arithmetic ~5.3 — profiles/issue_rate_r06.txt); "
                                      "floor = lanes x clocks / 64 / simds / clock")
     return r
 
@@ -1290,7 +1292,7 @@ def main():
                 if not args.no_rollout_pmc and not args.no_traffic:
                     try:
                         valu = measure_rollout_valu(args)
-                        src = ("measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU, one "
+                        src = ("measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, one "
                                f"child pass, {ROLLOUT_CHILD_LAUNCHES} launches of {ROLLOUT_CHILD_STEPS} steps per variant; SQ_INSTS_VALU / SQ_WAVES / lanes per thread / steps")
                     except Exception as e:                       # noqa: BLE001
                         out["fused_rollout"]["valu_measurement_error"] = repr(e)[:300]
@@ -1309,7 +1311,8 @@ def main():
                         q = None
                         if cs.get("SQ_WAVES") and "SQ_INSTS_VALU_INT64" in cs:
                             per = cs["SQ_WAVES"] * valu[key]["lanes_per_thread"] * valu[key]["steps_per_launch"]
-                            q = (cs["SQ_INSTS_VALU_INT64"] / per, cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / per)
+                            q = (cs["SQ_INSTS_VALU_INT64"] / per, cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / per,
+                                 (cs.get("SQ_INSTS_VALU_FMA_F64", 0.0) + cs.get("SQ_INSTS_VALU_ADD_F64", 0.0) + cs.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / per)
                         leg["roofline"] = valu_roofline(n, valu[key]["valu_per_env_step"], leg["us_per_step"], simds, src, q)
                         leg["roofline"]["kernel"] = valu[key].get("kernel")
                         busy = valu_busy_in_pass(cs, simds)

@@ -218,7 +218,7 @@ namespace Gym.Envs.Amd {
         public new void Seed(int seed) => SeedAll(seed);
         public new void Seed(int[] seed) => SeedLanes(seed);
 
-        /// VecEnv.Seed(int) (VecEnv.cs:44-46).  DEVIATION (DESIGN.md §1): one Philox key for the batch, lanes differ by counter.
+        /// VecEnv.Seed(int) (VecEnv.cs:44-46).  DEVIATION (INTEGRATION.md §0): one Philox key for the batch, lanes differ by counter.
         private void SeedAll(int seed) => Native.Check(Native.gymnet_vecenv_seed(_h, (ulong) seed));
 
         private void SeedLanes(int[] seed) {                                                                     // VecEnv.cs:48-53

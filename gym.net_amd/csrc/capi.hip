@@ -295,7 +295,7 @@ void default_policy(gymnet_vecenv *h) {
     if (!can_vec4) h->lcfg.vec = 1;
     // Acrobot's wide form is TWO lanes per thread whose arithmetic rides the packed FP32 instructions (envs.hpp).  Opt-in
     // (gymnet_launch_policy.vec = 2): bit-identical, 287 instead of 454 VALU per env-step, and slower — 15.0 vs 14.2 us at 2^20
-    // lanes, 13.6 vs 12.3 us per 2^20 lanes at 2^23 (profiles/acrobot_probes_r02.txt).
+    // lanes, 13.6 vs 12.3 us per 2^20 lanes at 2^23 (profiles/acrobot_probes_r02.txt, docs/ledger.md §4a).
     const bool can_vec2 = aligned_to(h->d_state, 8) && aligned_to(h->d_obs, 8) && (h->sstride % 2 == 0) && (h->ostride % 2 == 0) &&
                           (!h->d_obs_alt || aligned_to(h->d_obs_alt, 8));
     // Acrobot's multi-lane kernel (step_kernel_pipe: all loads first, then compute / store lane after lane) wins where the

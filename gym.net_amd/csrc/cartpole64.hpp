@@ -119,8 +119,17 @@ struct DivByTotalMass64 {
     // RN(1/C - ZH), written out: the compile-time evaluation of (1/C - ZH) in long double is not portable between host and
     // device passes.  tools/prove_div_total_mass_f64.py derives both constants in exact arithmetic and checks these literals.
     static constexpr double ZL = -0x1.4633f3e678be9p-55;
+    // GUARD_INF = false: for the kernels that fuse the auto-reset.  There an infinite dividend cannot matter: it needs theta_dot^2 (or
+    // the acceleration it feeds) to overflow, |theta_dot| > 1e154, and such a lane's theta + tau * theta_dot is beyond the threshold in
+    // the SAME step — done is computed from the positions, which use the OLD velocities — so its whole state is overwritten by the
+    // reset draw.  (The one observable trace: a terminal observation kept under GYMNET_FLAG_FINAL_OBS shows NaN velocities for such a
+    // lane where the division would show +-inf.)  The guard costs three v_cmp_class + branches per env-step — 8 of 142 VALU in the
+    // float64 rollout, 5.14 -> 5.44 us per vector step — and stays wherever the state survives the step (no auto-reset).
+    template <bool GUARD_INF = true>
     __host__ __device__ __forceinline__ static double apply(double x) {
-        if (__builtin_expect(__builtin_isinf(x), 0)) return x;          // x / C for an infinite x (the fma pair would say NaN: inf - inf)
+        if constexpr (GUARD_INF) {
+            if (__builtin_expect(__builtin_isinf(x), 0)) return x;      // x / C for an infinite x (the fma pair would say NaN: inf - inf)
+        }
         return __builtin_fma(x, ZH, x * ZL);
     }
 };
@@ -154,20 +163,23 @@ struct CartPole64 {
     static constexpr float theta_threshold = 0.20943951606750488f;   // (float)(12 * 2 * Math.PI / 360)
     static constexpr float x_threshold = 2.4f;
 
-    __device__ __forceinline__ static double div_tm(double x) { return DivByTotalMass64::apply(x); }
+    template <bool GUARD_INF>
+    __device__ __forceinline__ static double div_tm(double x) { return DivByTotalMass64::apply<GUARD_INF>(x); }
 
     // :141-167, statement for statement; C#'s usual arithmetic conversions written out (float op double -> double)
-    template <bool SMALL_ANGLE = false>
+    // AUTORESET: the caller overwrites a done lane's state in the same launch (see DivByTotalMass64::apply on what that allows)
+    template <bool SMALL_ANGLE = false, bool AUTORESET = false>
     __device__ __forceinline__ static void step(double (&st)[S], int32_t a, float &reward, bool &done) {
+        constexpr bool G = !AUTORESET;
         double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];                                  // :141-144
         const float force = a == 1 ? force_mag : -force_mag;                                                // :146
         double sintheta, costheta;
         sincos_f64<SMALL_ANGLE>(theta, sintheta, costheta);                                                 // :147-148
         // `/ total_mass` (:149-151) is IEEE division by a constant, evaluated as DivByTotalMass64 (proved bit-identical, above)
-        const double temp = div_tm((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta);                    // :149
+        const double temp = div_tm<G>((double)force + (double)polemass_length * theta_dot * theta_dot * sintheta);                    // :149
         const double thetaacc = ((double)gravity * sintheta - costheta * temp)
-                                / ((double)length * (4.0 / 3.0 - div_tm((double)masspole * costheta * costheta)));              // :150
-        const double xacc = temp - div_tm((double)polemass_length * thetaacc * costheta);                     // :151
+                                / ((double)length * (4.0 / 3.0 - div_tm<G>((double)masspole * costheta * costheta)));              // :150
+        const double xacc = temp - div_tm<G>((double)polemass_length * thetaacc * costheta);                     // :151
         x = x + (double)tau * x_dot;                                                                        // :154
         x_dot = x_dot + (double)tau * xacc;                                                                 // :155
         theta = theta + (double)tau * theta_dot;                                                            // :156

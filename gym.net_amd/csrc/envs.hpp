@@ -35,7 +35,7 @@ namespace gymnet {
 // matters.  The Acrobot step's arithmetic alone (tools/acrobot_alu_probe.hip, 8 waves per SIMD, no memory traffic) takes
 // 7.4 us per 2^20 env-steps as 454 scalar instructions (2.4 SIMD-cycles each in this mix) and 8.2 us as 287 packed + 287
 // scalar instructions per PAIR: a v_pk_*_f32 occupies the SIMD about as long as the two scalar instructions it replaces
-// (~5 cycles, tools/valu_probe.hip), and the per-element leftovers are not free.  DESIGN.md §4a.
+// (~5 cycles, tools/valu_probe.hip), and the per-element leftovers are not free.  docs/ledger.md §4a.
 // ---------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 namespace vm {
@@ -203,7 +203,8 @@ struct CartPole {
 
     // :146-167.  Any action != 1 pushes left (validity is only Debug.Assert'ed, :139).
     // SMALL_ANGLE: the caller guarantees |theta| <= kSmallAngle; the results are bit-identical either way (sincos_tiny).
-    template <bool SMALL_ANGLE = false>
+    // (AUTORESET: accepted for the interface it shares with CartPole64, where it drops a guard; nothing depends on it here)
+    template <bool SMALL_ANGLE = false, bool AUTORESET = false>
     __device__ __forceinline__ static void step(float (&s)[S], Action a, float &reward, bool &done) {
         const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const float force = (a == 1) ? force_mag : -force_mag;                                   // :146
@@ -411,7 +412,7 @@ struct Acrobot {
     // 1/P for P = d1 * det.  With c2 in [-1, 1]: d1 = c2 + 3.5 in [2.5, 4.5], det = 2.8125 - c2^2/4 in [2.5625, 2.8125], so
     // P lies in [6.4, 11.6] — no scaling, no special cases.  Quadratic minimax seed on [6.25, 11.75] (relative error 7.7e-3)
     // + two Newton steps r <- r + r(1 - P r): 6 full-rate fma instead of the 10-instruction IEEE division sequence around a
-    // quarter-rate v_rcp_f32.  Result within 0.55 ulp of 1/P over the whole range (2e6 random P),
+    // quarter-rate v_rcp_f32.  Result within 0.55 ulp of 1/P over the whole range (2e6 random P, docs/ledger.md §4a),
     // and — being fma only — reproduced bit for bit by the CPU restatement.
     template <class T>
     __device__ __forceinline__ static T recip_p(T P) {

@@ -82,7 +82,7 @@ __device__ __forceinline__ void count_after_done(const Args &a, const bool (&aft
 template <class Env, bool AUTORESET, bool SMALL_ANGLE = false>
 __device__ __forceinline__ void advance_sublane(typename Env::Real (&sj)[Env::S], typename Env::Action act, int32_t &sbd, float &rw,
                                                 bool &dn, bool &after, bool in_range, typename Env::Real (&oj)[Env::O]) {
-    if constexpr (Env::HAS_SMALL_ANGLE_PATH) Env::template step<SMALL_ANGLE>(sj, act, rw, dn);
+    if constexpr (Env::HAS_SMALL_ANGLE_PATH) Env::template step<SMALL_ANGLE, AUTORESET>(sj, act, rw, dn);
     else if constexpr (Env::OBS_ALIASES_STATE) Env::step(sj, act, rw, dn);
     else Env::step_observe(sj, act, rw, dn, oj);          // observation of the new (pre-reset) state
     if constexpr (!AUTORESET && Env::HAS_SBD) {

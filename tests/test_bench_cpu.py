@@ -87,10 +87,10 @@ def test_rollout_roofline_objects_can_be_recomputed_from_their_own_fields(tmp_pa
     import sqlite3
     b = _bench()
     n = 1 << 20
-    r = b.valu_roofline(n, 101.8, 2.81, 1024, "test", quarter_rate_per_env_step=(6.0, 0.5))
+    r = b.valu_roofline(n, 101.8, 2.81, 1024, "test", quarter_rate_per_env_step=(6.0, 0.5, 10.0))
     assert abs(r["issue_floor_us"] - n * 101.8 / (16 * 1024) / 2.4e3) < 1e-12 and abs(r["issue_floor_us"] - 2.7147) < 1e-3   # VERDICT r5's 2.71 us
     assert abs(r["frac"] - r["issue_floor_us"] / r["measured_us"]) < 1e-15 and 0.96 < r["frac"] < 0.97
-    assert abs(r["frac_measured_rates"] - n * (4 * 101.8 + 6.0 + 2.5) / 64 / 1024 / 2.4e3 / 2.81) < 1e-12
+    assert abs(r["frac_measured_rates"] - n * (4 * 101.8 + 6.0 + 2.5 + 13.0) / 64 / 1024 / 2.4e3 / 2.81) < 1e-12
     w = b.write_roofline(n, 25, 4.5)
     assert abs(w["achieved"] - 25 * n / 4.5e-6 / 1e9) < 1e-6 and abs(w["frac"] - w["achieved"] / 8000.0) < 1e-15
     json.dumps([r, w])

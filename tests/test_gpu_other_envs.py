@@ -267,7 +267,7 @@ def test_scalar_broadcast_on_a_box_action_space(gpu_pkg):
 def test_acrobot_kernel_forms_are_bit_identical(gpu_pkg, monkeypatch):
     """Acrobot's step has three kernel forms: one lane per thread (one-shot), launch policy vec = 2 — both envs of a thread ride the
     v_pk_*_f32 instructions (envs.hpp step_observe_x2, dwordx2 streams; opt-in: half the VALU count and still slower,
-    DESIGN.md §4a) — and sequential_lanes = k — k lanes per thread, all loads first, then compute / store lane after lane
+    docs/ledger.md §4a) — and sequential_lanes = k — k lanes per thread, all loads first, then compute / store lane after lane
     (step_kernel_pipe; the default around 2^20 lanes).  Per lane all three run the same IEEE sequence, so everything must
     agree bit for bit: one-launch steps with an odd lane count (clamped loads / suppressed stores in the tail), the
     bookkeeping variant (which falls back to the one-shot kernel), the fused rollout, with and without auto-reset."""

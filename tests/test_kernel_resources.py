@@ -1,5 +1,5 @@
 """The register budget the launch policy relies on, asserted from the gfx950 assembly (no GPU): how many waves per SIMD each bench kernel can
-hold decides whether a 2^20-lane launch is ONE generation of waves (profiles/occupancy_hints_r05.txt), and a spilling step
+hold decides whether a 2^20-lane launch is ONE generation of waves (docs/ledger.md §4d, profiles/occupancy_hints_r05.txt), and a spilling step
 kernel would be a silent slowdown.  CartPole in both state scalars (the headline and the reference-arithmetic kernel); ~1 minute of hipcc."""
 import os
 import sys

@@ -78,13 +78,12 @@ for v in bench.ROLLOUT_VARIANTS:
         per = cs["SQ_WAVES"] * counters[v]["lanes_per_thread"] * counters[v]["steps_per_launch"]
         e.update(valu_per_env_step=counters[v]["valu_per_env_step"], lanes_per_thread=counters[v]["lanes_per_thread"],
                  int64_per_env_step=cs.get("SQ_INSTS_VALU_INT64", 0.0) / per, trans_per_env_step=cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / per,
-                 salu_per_env_step=cs.get("SQ_INSTS_SALU", 0.0) / per,
-                 wait_inst_over_wave_cycles=(cs["SQ_WAIT_INST_ANY"] / cs["SQ_WAVE_CYCLES"]) if cs.get("SQ_WAVE_CYCLES") else None)
+                 f64_arith_per_env_step=(cs.get("SQ_INSTS_VALU_FMA_F64", 0.0) + cs.get("SQ_INSTS_VALU_ADD_F64", 0.0) + cs.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / per)
         busy = bench.valu_busy_in_pass(cs, SIMDS)
         if busy is not None:
             e["valu_busy_in_pmc_pass"] = busy
         e["issue_floor_us"] = N * e["valu_per_env_step"] / (16 * SIMDS) / (CLOCK * 1e3)
-        clocks = 4.0 * e["valu_per_env_step"] + e["int64_per_env_step"] + 5.0 * e["trans_per_env_step"]
+        clocks = 4.0 * e["valu_per_env_step"] + e["int64_per_env_step"] + 5.0 * e["trans_per_env_step"] + 1.3 * e["f64_arith_per_env_step"]
         e["issue_floor_measured_rates_us"] = N * clocks / 64.0 / SIMDS / (CLOCK * 1e3)
         if "rocprof_us_per_step" in e:
             e["frac_rocprof"] = e["issue_floor_us"] / e["rocprof_us_per_step"]
@@ -98,7 +97,7 @@ for v in bench.ROLLOUT_VARIANTS:
     if e:
         out["variants"][v] = e
         g = lambda k, p=3: (f"{e[k]:.{p}f}" if e.get(k) is not None else "-")   # noqa: E731
-        txt.append(f"{v:20s} VALU/env-step {g('valu_per_env_step', 1):>6s} (int64 {g('int64_per_env_step', 2)}, trans {g('trans_per_env_step', 2)})  floor {g('issue_floor_us')} us  "
+        txt.append(f"{v:20s} VALU/env-step {g('valu_per_env_step', 1):>6s} (int64 {g('int64_per_env_step', 2)}, trans {g('trans_per_env_step', 2)}, f64 {g('f64_arith_per_env_step', 1)})  floor {g('issue_floor_us')} us (measured rates {g('issue_floor_measured_rates_us')})  "
                    f"rocprof {g('rocprof_us_per_step')} us/step (frac {g('frac_rocprof')})  unprofiled {g('unprofiled_us_per_step')} (frac {g('frac_unprofiled')})  {e.get('kernel', '')[:70]}\n")
 # the 2^27-lane point
 big = {}
