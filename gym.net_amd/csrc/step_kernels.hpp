@@ -1012,9 +1012,12 @@ __device__ __forceinline__ void thread_action_words(uint64_t seed, uint64_t gl0,
 //           truncation, dense last-finished-episode views, per-rollout compact episode records, the done list of the LAST step
 //   SAMPLE  the actions are drawn in the kernel (RolloutArgs::action_source 1 or 2) instead of read from the ring
 //   RESETF  1 = the wave-compacted reset (reset_pending_wave) per step instead of the per-thread drain loop
-// Episode records of a rollout are STAGED per wave in LDS (64 records: ~5 steps' worth at CartPole's rate) and flushed with one atomic
+// Episode records of a rollout are STAGED per wave in LDS (kStageRecords: ~22 steps' worth at CartPole's rate) and flushed with one atomic
 // and full-line stores; appending each step's ~11 records directly cost one atomic round trip per wave and step on the critical path.
-struct EpisodeStage { int32_t t[64], lane[64]; float ret[64]; int32_t len[64]; };
+// (Round 6: 256 records per wave instead of 64 — a wave flushes every ~22 steps instead of every ~5; each flush is an atomic round trip
+// the wave waits for.  4 KiB of LDS per wave, 16 KiB per workgroup.)
+constexpr uint32_t kStageRecords = 256;
+struct EpisodeStage { int32_t t[kStageRecords], lane[kStageRecords]; float ret[kStageRecords]; int32_t len[kStageRecords]; };
 
 //   RECORDS the rollout keeps compact episode records (RolloutArgs::ep_*; bookkeeping handles): a variant of its own, so that the
 //           rollouts that keep none do not carry the staging code's registers (128-VGPR budget, above)
@@ -1185,8 +1188,8 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
                 // lane hitting the time limit in the same step) flushes and appends directly.
                 uint32_t off[VEC];
                 const uint32_t total = rank_finished<VEC>(finished, off);
-                if (total && staged + total > 64u) flush_stage();   // wave-uniform
-                if (total > 64u) {
+                if (total && staged + total > kStageRecords) flush_stage();   // wave-uniform
+                if (total > kStageRecords) {
                     const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
                     const uint32_t shard = wave_shard();
                     uint32_t base = 0;
