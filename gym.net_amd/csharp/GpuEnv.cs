@@ -125,23 +125,23 @@ namespace Gym.Envs.Amd {
     /// CartPoleEnv (src/Gym.Environments/Envs/Classic/CartPoleEnv.cs) on the GPU engine.  The viewer-delegate ctor argument of
     /// the reference (CartPoleEnv.cs:54-61) has no counterpart: nothing is rendered.
     public sealed class GpuCartPoleEnv : GpuEnv {
-        public GpuCartPoleEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false, bool float64 = true)
-            : base(GymnetEnvId.CartPole, device, seed, maxEpisodeSteps, validateActions, float64) { }
+        public GpuCartPoleEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false, bool float64 = true, bool resident = false)
+            : base(GymnetEnvId.CartPole, device, seed, maxEpisodeSteps, validateActions, float64, resident) { }
     }
 
     /// Pendulum-v1 / MountainCar-v0 / Acrobot-v1: unchecked roadmap items of the reference (README.md:69-76), upstream gym semantics.
     public sealed class GpuPendulumEnv : GpuEnv {
-        public GpuPendulumEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0)
-            : base(GymnetEnvId.Pendulum, device, seed, maxEpisodeSteps, false) { }
+        public GpuPendulumEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool resident = false)
+            : base(GymnetEnvId.Pendulum, device, seed, maxEpisodeSteps, false, false, resident) { }
     }
 
     public sealed class GpuMountainCarEnv : GpuEnv {
-        public GpuMountainCarEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
-            : base(GymnetEnvId.MountainCar, device, seed, maxEpisodeSteps, validateActions) { }
+        public GpuMountainCarEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false, bool resident = false)
+            : base(GymnetEnvId.MountainCar, device, seed, maxEpisodeSteps, validateActions, false, resident) { }
     }
 
     public sealed class GpuAcrobotEnv : GpuEnv {
-        public GpuAcrobotEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false)
-            : base(GymnetEnvId.Acrobot, device, seed, maxEpisodeSteps, validateActions) { }
+        public GpuAcrobotEnv(int device = 0, ulong seed = 0, int maxEpisodeSteps = 0, bool validateActions = false, bool resident = false)
+            : base(GymnetEnvId.Acrobot, device, seed, maxEpisodeSteps, validateActions, false, resident) { }
     }
 }
