@@ -468,7 +468,9 @@ def write_roofline(n, written_bytes_per_env_step, measured_us):
     gbps = written_bytes_per_env_step * n / (measured_us * 1e-6) / 1e9
     return {"bound": "hbm_write", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
             "written_bytes_per_env_step": written_bytes_per_env_step, "bytes_per_launch_step": written_bytes_per_env_step * n, "measured_us": measured_us,
-            "measured_pure_write_GBps": [4400, 4800], "frac_of_write_ceiling": gbps / 4800.0}
+            "measured_pure_write_GBps": [4400, 4800], "frac_of_write_ceiling": gbps / 4800.0,
+            "write_ceiling_note": "4.4-4.8 TB/s is what the ONE-STEP kernels' write pattern reaches (rounds 2-5 probes); a rollout's append-only trajectory "
+                                  "streams can exceed it — `frac` (of the 8 TB/s spec peak) is the figure to quote"}
 
 
 def parse_policy(text):
@@ -1318,9 +1320,10 @@ def main():
                         busy = valu_busy_in_pass(cs, simds)
                         if busy is not None:
                             leg["roofline"]["valu_busy_in_pmc_pass"] = busy
-                            leg["roofline"]["valu_busy_note"] = ("SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines) of the profiled launches: no assumed clock. "
-                                                                 "`frac` prices the floor at the 2.4 GHz peak clock and 4 clocks per counted instruction against the UNPROFILED time; "
-                                                                 "it can read a few percent above 1 (the short profiled launches run at a lower clock and pay a launch ramp per 64 steps)")
+                            leg["roofline"]["valu_busy_note"] = ("SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines) of the profiled launches: no assumed clock.  Both it and "
+                                                                 "`frac` (4 clocks per counted instruction, 2.4 GHz, against the UNPROFILED time) are MODEL fractions: above 1 means the chip "
+                                                                 "retires this instruction mix faster than 4 clocks per counted instruction (calibration on a pure FMA loop: 0.95) — "
+                                                                 "read them as 'at the VALU-issue ceiling to within +-10 %' (DESIGN.md §5)")
             except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
                 out["fused_rollout"]["roofline_error"] = repr(e)[:300]
         if not args.no_cpu_baseline:
