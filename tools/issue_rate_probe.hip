@@ -89,6 +89,36 @@ __global__ __launch_bounds__(256) void k_rcp(float *out, int iters, float a, flo
     if (s == 12345.678f) out[0] = s;
 }
 
+// Do instructions of DIFFERENT classes overlap on a SIMD?  Each thread runs 8 float32 FMA chains and 8 chains of a second class per loop trip
+// (independent of each other); if the classes share one issue slot the time is the sum of the two halves run alone, if the second class has a
+// pipe of its own it is closer to the longer half.  MODE 0: both; 1: only the float32 half; 2: only the second half.
+// CLASS 0: v_fma_f64, 1: v_mad_u64_u32, 2: v_rcp_f32, 3: v_cvt_f64_f32 + v_cmp_gt_f64-ish (conversion + compare, the `done` arithmetic)
+template <int CLASS, int MODE>
+__global__ __launch_bounds__(256) void k_mix(float *out, int iters, float a, float b) {
+    float x[8];
+    double y[8];
+    uint32_t z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = (float)(threadIdx.x + i); y[i] = (double)(threadIdx.x + i) + 0.5; z[i] = threadIdx.x * 2654435761u + i; }
+    const double ad = (double)a, bd = (double)b;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE != 2) x[i] = __builtin_fmaf(x[i], a, b);
+            if (MODE != 1) {
+                if (CLASS == 0) y[i] = __builtin_fma(y[i], ad, bd);
+                else if (CLASS == 1) { const uint64_t p = (uint64_t)0xD2511F53u * z[i]; z[i] = (uint32_t)(p >> 32) + (uint32_t)p; }     // mad (the add folds into it)
+                else if (CLASS == 2) { float r = __uint_as_float(z[i] | 0x3f800000u); r = __builtin_amdgcn_rcpf(r); z[i] = __float_as_uint(r); }
+                else { const double d = (double)__uint_as_float(z[i] | 0x3f000000u); z[i] += d > y[i] ? 3u : 1u; }
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i] + (float)y[i] + (float)z[i];
+    if (s == 12345.678f) out[0] = s;
+}
+
 // the engine clock under load: s_memtime (clock64: shader clock cycles) against s_memrealtime (wall_clock64: the constant 100 MHz counter)
 // around a long full-mask FMA loop, read by lane 0 of every 1024th workgroup while the whole chip runs the same loop
 __global__ __launch_bounds__(256) void k_clock(float *out, int iters, float a, float b, unsigned long long *ticks) {
@@ -172,6 +202,17 @@ int main() {
         rep2("v_fma_f32   11 of 64 lanes", run(k_fma<11>, b1, iters, d), 1);
         rep2("v_fma_f32   64 of 64 lanes", run(k_fma<64>, b2, iters, d), 2);
         rep2("v_fma_f32   11 of 64 lanes", run(k_fma<11>, b2, iters, d), 2);
+    }
+    {
+        const char *cls[4] = {"v_fma_f64", "v_mad_u64_u32", "v_rcp_f32 (+ or / bitcast)", "cvt_f64_f32 + cmp_f64 + cndmask + add"};
+        auto three = [&](int c, double both, double f32only, double other) {
+            printf("mix 8 x v_fma_f32 + 8 x %-38s both %7.3f ms   float32 half alone %7.3f   other half alone %7.3f   sum of halves %7.3f   overlap %4.0f %% of the shorter half\n",
+                   cls[c], both, f32only, other, f32only + other, 100.0 * (f32only + other - both) / (f32only < other ? f32only : other));
+        };
+        three(0, run(k_mix<0, 0>, blocks, iters, d), run(k_mix<0, 1>, blocks, iters, d), run(k_mix<0, 2>, blocks, iters, d));
+        three(1, run(k_mix<1, 0>, blocks, iters, d), run(k_mix<1, 1>, blocks, iters, d), run(k_mix<1, 2>, blocks, iters, d));
+        three(2, run(k_mix<2, 0>, blocks, iters, d), run(k_mix<2, 1>, blocks, iters, d), run(k_mix<2, 2>, blocks, iters, d));
+        three(3, run(k_mix<3, 0>, blocks, iters, d), run(k_mix<3, 1>, blocks, iters, d), run(k_mix<3, 2>, blocks, iters, d));
     }
     report("v_mad_u64_u32 + v_xor (per pair)", run(k_mad64, blocks, iters, d), 1);
     report("xor + add (per pair)", run(k_xor, blocks, iters, d), 1);
