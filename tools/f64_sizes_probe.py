@@ -45,6 +45,7 @@ for n in sizes:
         policies = [("default", {}), ("nt=15", dict(nt=15)), ("nt=12", dict(nt=12)), ("nt=0", dict(nt=0))]
     else:
         policies = [("default", {}), ("one-shot nt=12", dict(sequential_lanes=1, nt=12)), ("one-shot nt=15", dict(sequential_lanes=1, nt=15)), ("one-shot nt=0", dict(sequential_lanes=1, nt=0)),
+                    ("one-shot nt=0 rf=0", dict(sequential_lanes=1, nt=0, reset_form=0)), ("one-shot nt=15 rf=0", dict(sequential_lanes=1, nt=15, reset_form=0)),
                     ("2 pairs", dict(sequential_lanes=2)), ("3 pairs", dict(sequential_lanes=3)), ("4 pairs nt=15", dict(sequential_lanes=4, nt=15)),
                     ("4 pairs nt=12", dict(sequential_lanes=4, nt=12)), ("4 pairs nt=0", dict(sequential_lanes=4, nt=0))]
     for label, pol in policies:
