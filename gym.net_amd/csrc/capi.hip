@@ -560,7 +560,7 @@ namespace gymnet {
 // it spins it occupies the handle's stream and one wave, and anything that waits for the WHOLE device — hipDeviceSynchronize,
 // torch.cuda.synchronize(), a hipFree out of a caching allocator — or that serialises dispatch (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL)
 // waits for this timeout: it bounds what a host that mixes an env loop with other GPU work in one process can lose per
-// such call.  A loop that steps back to back never sees it; a step after a longer pause pays one relaunch (~25 us, the launch path's
+// such call.  A loop that steps back to back never sees it; a step after a longer pause pays one relaunch (~20 us, the launch path's
 // cost).  GYMNET_FLAG_RESIDENT is opt-in in every facade for the same reason.
 constexpr uint64_t kResidentIdlePolls = 3000;
 
