@@ -815,7 +815,9 @@ def main():
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "action_ring": ring,
                        "launch": ("one kernel launch per step, eager (python loop)" if (args.no_graph or gather_in_region) else
                                   "one kernel launch per step; gymnet_vecenv_rollout_device: " +
-                                  ("hipGraph replay" if n * bytes_per_step < (24 << 20) else "back-to-back stream launches")),
+                                  ("hipGraph replay" if (parse_policy(args.policy).get("graph", -1) == 1 or
+                                                         (parse_policy(args.policy).get("graph", -1) != 0 and n * bytes_per_step < (24 << 20)))
+                                   else "back-to-back stream launches")),
                        "launch_policy": launch_policy,
                        "timing": f"median of {repeats} bracketed {K}-step regions (>= {args.min_seconds * 1e3:.0f} ms timed in total)",
                        "backend": ("rccl" if backend == "nccl" else backend + " (ranks SHARE the GPUs that exist: plumbing check, not a multi-GPU measurement)") if use_dist else "single process",

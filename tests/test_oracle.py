@@ -781,3 +781,26 @@ def test_f64_constant_division_is_proved_and_sampled(oracle):
     xacc = temp - pml * thacc * cs / C
     want = np.stack([s[0] + tau * s[1], s[1] + tau * xacc, s[2] + tau * s[3], s[3] + tau * thacc])
     assert np.array_equal(got, want)
+
+
+def test_action_stream_is_sharding_invariant_for_ragged_shard_plans(oracle):
+    """Action stream v2 keys a call by the GLOBAL lane's group (lane >> 2): a batch cut into shards whose offsets are not multiples of
+    four (rank r owns [r N / G, (r + 1) N / G), here 10 lanes over 3 ranks and 1003 over 8) samples, composes and draws its
+    masks exactly as the whole batch does — shard by shard, from the shard's own lane offset."""
+    for n, g in ((10, 3), (1003, 8), (4099, 5)):
+        whole_a, whole_b = oracle.action_words(0xABCD, 0, 9, n)
+        whole_d = oracle.discrete_sample(0xABCD, 0, 9, 3, 0, n)
+        whole_x = oracle.box_uniform_sample(0xABCD, 0, 9, -2.0, 2.0, n)
+        pol = (np.arange(n) % 3).astype(np.int32)
+        whole_c = oracle.compose_discrete(0xABCD, 0, 9, 3, 0.5, pol)
+        off = 0
+        for r in range(g):
+            assert off == n * r // g
+            cnt = n * (r + 1) // g - n * r // g                          # gym.net_amd/sharding.py ShardPlan.offset / count
+            a, b = oracle.action_words(0xABCD, off, 9, cnt)
+            assert np.array_equal(a, whole_a[off:off + cnt]) and np.array_equal(b, whole_b[off:off + cnt])
+            assert np.array_equal(oracle.discrete_sample(0xABCD, off, 9, 3, 0, cnt), whole_d[off:off + cnt])
+            assert np.array_equal(oracle.box_uniform_sample(0xABCD, off, 9, -2.0, 2.0, cnt), whole_x[off:off + cnt])
+            assert np.array_equal(oracle.compose_discrete(0xABCD, off, 9, 3, 0.5, pol[off:off + cnt]), whole_c[off:off + cnt])
+            off += cnt
+        assert off == n
