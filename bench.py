@@ -963,10 +963,13 @@ def main():
                     be.ResetDevice()
                     bu = fused_time(lambda: be.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, episodes=ep))
                     cnt = keep["count"].cpu().numpy()
+                    bf = fused_time(lambda: be.RolloutFusedDevice(None, ring, actions="sample", action_seed=seed + 1, episodes=dict(ep, no_overflow=True)))
                     fused["sampled_actions_with_episode_records"] = {
                         "us_per_step": bu, "env_steps_per_sec_per_gpu": n / (bu * 1e-6), "episodes_per_launch": int(cnt[1]), "records_kept": int(cnt[0]),
+                        "us_per_step_no_overflow_variant": bf,
                         "note": "bookkeeping handle (EPISODE_STATS, max_episode_steps 500): episode statistics in registers + one compact "
-                                "(t, lane, return, length) record per finished episode, gathered after the launch"}
+                                "(t, lane, return, length) record per finished episode, gathered after the launch; default = nothing lost below the capacity "
+                                "(per-shard segments spill to a shared overflow segment), *_no_overflow_variant = GYMNET_RECORDS_NO_OVERFLOW"}
         except Exception as e:                                   # noqa: BLE001 - a secondary figure never costs the headline
             fused = {"error": repr(e)[:300]}
 

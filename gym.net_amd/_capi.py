@@ -46,6 +46,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
 
 GATHER_NONE, GATHER_DIRECT, GATHER_RCCL = 0, 1, 2
 ABI_VERSION = 6
+RECORDS_NO_OVERFLOW = 1      # gymnet_rollout_spec.record_flags
 
 
 class Config(C.Structure):
@@ -105,7 +106,7 @@ ACTIONS_RING, ACTIONS_SAMPLE, ACTIONS_EPSILON_GREEDY = 0, 1, 2
 class RolloutSpec(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("action_source", C.c_int32), ("d_actions", C.c_void_p), ("steps", C.c_int64),
                 ("action_stride", C.c_int64), ("ring", C.c_int64), ("action_seed", C.c_uint64), ("action_tick0", C.c_uint64),
-                ("epsilon", C.c_float), ("reserved", C.c_int32), ("d_rec_obs", C.c_void_p), ("d_rec_reward", C.c_void_p),
+                ("epsilon", C.c_float), ("record_flags", C.c_int32), ("d_rec_obs", C.c_void_p), ("d_rec_reward", C.c_void_p),
                 ("d_rec_done", C.c_void_p), ("d_rec_actions", C.c_void_p),
                 ("d_ep_step", C.c_void_p), ("d_ep_lane", C.c_void_p), ("d_ep_return", C.c_void_p), ("d_ep_length", C.c_void_p),
                 ("ep_capacity", C.c_int64), ("d_ep_count", C.c_void_p)]

@@ -75,12 +75,14 @@ namespace Gym.Envs.Amd {
     [StructLayout(LayoutKind.Sequential)]
     public struct GymnetRolloutBuffers { public IntPtr d_obs; public IntPtr d_reward; public IntPtr d_done; }
 
+    /// gymnet_rollout_spec.record_flags: NoOverflow = the 8 % faster records variant that may drop records of very unevenly finishing lanes
+    public static class GymnetRecordFlags { public const int None = 0, NoOverflow = 1; }
     /// gymnet_vecenv_rollout_fused_ex_device (ABI 5): action source (0 ring, 1 ActionSpace.Sample() drawn in the kernel, 2 epsilon-greedy
     /// over the ring as the policy's actions), dense recording, and the compact records of the episodes that end during the rollout.
     [StructLayout(LayoutKind.Sequential)]
     public struct GymnetRolloutSpec {
         public uint struct_size; public int action_source; public IntPtr d_actions; public long steps; public long action_stride; public long ring;
-        public ulong action_seed; public ulong action_tick0; public float epsilon; public int reserved;
+        public ulong action_seed; public ulong action_tick0; public float epsilon; public int record_flags;
         public IntPtr d_rec_obs; public IntPtr d_rec_reward; public IntPtr d_rec_done; public IntPtr d_rec_actions;
         public IntPtr d_ep_step; public IntPtr d_ep_lane; public IntPtr d_ep_return; public IntPtr d_ep_length; public long ep_capacity; public IntPtr d_ep_count;
     }

@@ -1143,18 +1143,21 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
 namespace {
 
 // segment buffers of the fused rollout's episode records: kShards segments of `cap` records each (t, lane, return, length) +
-// the shard counters.  Random lanes do not fill the shards evenly, so a segment gets twice its share of the caller's capacity.
+// the shard counters.  Random lanes do not fill the shards evenly, so a segment gets twice its share of the caller's capacity —
+// and what a shard still cannot hold (lanes that finish very unevenly) goes to ONE shared overflow segment of `capacity` records
+// (round 6): records are dropped only when more episodes end than the caller's arrays hold.
 int ensure_episode_segments(gymnet_vecenv *h, int64_t capacity) {
     const int64_t cap = 2 * ((capacity + kShards - 1) / kShards) + 64;
-    if (h->d_ep_seg && cap <= h->ep_seg_cap) return GYMNET_OK;
+    if (h->d_ep_seg && cap <= h->ep_seg_cap && capacity <= h->ep_ov_cap) return GYMNET_OK;
     HIP_TRY(h, hipStreamSynchronize(h->stream));          // a previous rollout's gather may still read the old segments
     if (h->d_ep_seg) (void)hipFree(h->d_ep_seg);
-    h->d_ep_seg = nullptr; h->ep_seg_cap = 0;
+    h->d_ep_seg = nullptr; h->ep_seg_cap = 0; h->ep_ov_cap = 0;
     void *q = nullptr;
-    const size_t bytes = (size_t)kShards * (size_t)cap * 16 + (size_t)kShards * kCountStride * 4 + 8;
+    // four arrays of [kShards segments of cap | one overflow segment of capacity] records, then kShards + 1 counters (a cache line each)
+    const size_t bytes = ((size_t)kShards * (size_t)cap + (size_t)capacity) * 16 + (size_t)(kShards + 1) * kCountStride * 4 + 8;
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess) return fail(h, GYMNET_ERR_OOM, "hipMalloc(%zu bytes) for the rollout's episode records failed: %s", bytes, hipGetErrorString(e));
-    h->d_ep_seg = q; h->ep_seg_cap = cap;
+    h->d_ep_seg = q; h->ep_seg_cap = cap; h->ep_ov_cap = capacity;
     return GYMNET_OK;
 }
 
@@ -1168,19 +1171,23 @@ int rollout_fused_typed(gymnet_vecenv *h, const gymnet_rollout_spec &sp, LaunchC
     r.action_source = sp.action_source; r.epsilon = sp.epsilon; r.action_seed = sp.action_seed; r.action_tick0 = sp.action_tick0;
     if (episodes) {
         char *seg = static_cast<char *>(h->d_ep_seg);
-        const size_t one = (size_t)kShards * (size_t)h->ep_seg_cap * 4;
+        const size_t one = ((size_t)kShards * (size_t)h->ep_seg_cap + (size_t)h->ep_ov_cap) * 4;
         r.ep_t = reinterpret_cast<int32_t *>(seg); r.ep_lane = reinterpret_cast<int32_t *>(seg + one);
         r.ep_ret = h->d_ep_ret ? reinterpret_cast<float *>(seg + 2 * one) : nullptr;
         r.ep_len = h->d_ep_ret ? reinterpret_cast<int32_t *>(seg + 3 * one) : nullptr;
         r.ep_count = reinterpret_cast<uint32_t *>(seg + 4 * one);
         r.ep_cap = h->ep_seg_cap;
-        HIP_TRY(h, hipMemsetAsync(r.ep_count, 0, (size_t)kShards * kCountStride * 4, h->stream));
+        r.ov_cap = sp.ep_capacity < h->ep_ov_cap ? sp.ep_capacity : h->ep_ov_cap;
+        r.records_no_overflow = (sp.record_flags & GYMNET_RECORDS_NO_OVERFLOW) ? 1 : 0;
+        // the kShards + 1 counters, zeroed on the stream by a kernel of our own
+        HIP_TRY(h, launch_fill_i32(reinterpret_cast<int32_t *>(r.ep_count), 0, (int64_t)(kShards + 1) * kCountStride, h->stream));
     }
     HIP_TRY(h, launch_rollout_fused(h->cfg.env_id, h->autoreset, h->extras, a, r, cfg, h->stream));
     if (episodes) {
         EpisodeGatherArgs g{};
         g.counts = r.ep_count; g.cap = r.ep_cap;
         g.ep_t = r.ep_t; g.ep_lane = r.ep_lane; g.ep_ret = r.ep_ret; g.ep_len = r.ep_len;
+        g.ov_cap = r.ov_cap;
         g.out_t = sp.d_ep_step; g.out_lane = sp.d_ep_lane; g.out_ret = sp.d_ep_return; g.out_len = sp.d_ep_length;
         g.out_capacity = sp.ep_capacity; g.out_count = sp.d_ep_count;
         HIP_TRY(h, launch_gather_episodes(g, h->stream));

@@ -100,6 +100,7 @@ struct gymnet_vecenv {
     uint64_t mb_seq = 0;                   // sequence number of the last command posted
     void *d_ep_seg = nullptr;      // fused rollout: segmented episode records + shard counters (allocated on first use, grown on demand)
     int64_t ep_seg_cap = 0;        // records per shard segment
+    int64_t ep_ov_cap = 0;         // records of the shared overflow segment (= the largest ep_capacity asked for so far)
     uint64_t seed = 0, tick = 0, lane_steps = 0, step_launches = 0;
     int tslot = 0;                 // which half of d_tick2 the NEXT launch reads (it writes the other half)
     int last_cparity = -1;

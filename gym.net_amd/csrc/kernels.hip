@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const CompactArgsT<R>
 // arrays; same shape as compact_done_kernel — every workgroup recomputes the scan of the 256 shard counts in LDS — but with
 // kGatherSplit workgroups per shard (blockIdx.y): a 256-step CartPole rollout at 2^20 lanes leaves 12 M records, and one workgroup
 // per shard moved them in 304 us (1.2 us per vector step of the rollout); split eight ways the copy runs at memory speed.
-// A shard's count may exceed its capacity (records beyond it were dropped by the rollout kernel): only the kept ones move.
+// A shard's count may exceed its capacity: the records beyond it went to the shared overflow segment (RolloutArgs::ov_*), which the
+// extra row of workgroups (blockIdx.x == kShards) appends after the last shard's records.
 constexpr int kGatherSplit = 8;
 // thread t of the (fixed) 256-thread workgroup owns shard t in the scan and in the raw-count reduction
 static_assert(kShards == 256, "gather_episodes_kernel / compact_done_kernel index the shard counters by threadIdx.x of a 256-thread workgroup");
@@ -106,6 +107,22 @@ __global__ __launch_bounds__(256) void gather_episodes_kernel(const EpisodeGathe
         __syncthreads();
     }
     const int shard = blockIdx.x;
+    if (shard == kShards) {
+        // the extra row of workgroups: the shared overflow segment (segment kShards of the same arrays), appended after the last shard's records
+        const uint32_t ovraw = a.counts[kShards * kCountStride];
+        const uint32_t ovcnt = (int64_t)ovraw < a.ov_cap ? ovraw : (uint32_t)a.ov_cap;
+        const uint32_t start = scan[kShards - 1];
+        const int64_t seg0 = (int64_t)kShards * a.cap;
+        for (uint32_t k = blockIdx.y * 256 + t; k < ovcnt; k += 256 * kGatherSplit) {
+            const uint32_t dst = start + k;
+            if ((int64_t)dst >= a.out_capacity) continue;
+            if (a.out_t) a.out_t[dst] = a.ep_t[seg0 + k];
+            if (a.out_lane) a.out_lane[dst] = a.ep_lane[seg0 + k];
+            if (a.out_ret && a.ep_ret) a.out_ret[dst] = a.ep_ret[seg0 + k];
+            if (a.out_len && a.ep_len) a.out_len[dst] = a.ep_len[seg0 + k];
+        }
+        return;
+    }
     const uint32_t raw_s = a.counts[shard * kCountStride];
     const uint32_t cnt = (int64_t)raw_s < a.cap ? raw_s : (uint32_t)a.cap;
     const uint32_t start = scan[shard] - cnt;
@@ -117,8 +134,9 @@ __global__ __launch_bounds__(256) void gather_episodes_kernel(const EpisodeGathe
         __syncthreads();
         for (int d = kShards / 2; d > 0; d >>= 1) { if (t < d) raw_sum[t] += raw_sum[t + d]; __syncthreads(); }
         if (t == 0) {
-            const uint32_t kept = scan[kShards - 1];
-            a.out_count[0] = (int64_t)kept < a.out_capacity ? kept : (uint32_t)a.out_capacity;
+            const uint32_t ovraw = a.counts[kShards * kCountStride];
+            const uint64_t kept = (uint64_t)scan[kShards - 1] + ((int64_t)ovraw < a.ov_cap ? ovraw : (uint32_t)a.ov_cap);
+            a.out_count[0] = (int64_t)kept < a.out_capacity ? (uint32_t)kept : (uint32_t)a.out_capacity;
             a.out_count[1] = raw_sum[0];
         }
     }
@@ -421,7 +439,7 @@ hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const S
 }
 
 hipError_t launch_gather_episodes(const EpisodeGatherArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(gather_episodes_kernel, dim3(kShards, kGatherSplit), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gather_episodes_kernel, dim3(kShards + 1, kGatherSplit), dim3(256), 0, st, a);     // + 1: the overflow segment's row
     return hipGetLastError();
 }
 

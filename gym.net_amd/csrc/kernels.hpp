@@ -96,8 +96,16 @@ struct RolloutArgsT {
     // (ep_count[shard * kCountStride], one atomic per wave and step that has a finished lane), record p of shard s at s * ep_cap + p
     int32_t *ep_t, *ep_lane;      // step index inside the rollout, lane
     float *ep_ret; int32_t *ep_len;
-    uint32_t *ep_count;           // [kShards * kCountStride], zeroed by the launcher; counts beyond ep_cap are dropped records
+    uint32_t *ep_count;           // [kShards * kCountStride], zeroed by the launcher; counts beyond ep_cap go to the overflow segment
     int64_t ep_cap;
+    // Round 6: ONE overflow segment shared by all shards, for the records a shard's own segment cannot hold (lanes that finish
+    // unevenly: a few waves producing most of the episodes).  It is "segment kShards" of the same four arrays — record p at
+    // kShards * ep_cap + p, its counter at ep_count[kShards * kCountStride] — so the kernel needs no pointers of its own for it (the
+    // rollout kernels are short of scalar registers: six more argument words cost the records variant 0.5 us per vector step).  The
+    // counter counts every overflowed record; the first ov_cap are kept.  ov_cap = the caller's ep_capacity: records are dropped only
+    // beyond ep_capacity in TOTAL.  records_no_overflow (GYMNET_RECORDS_NO_OVERFLOW): the kernel variant without the spill path.
+    int64_t ov_cap;
+    int32_t records_no_overflow;
 };
 typedef RolloutArgsT<float> RolloutArgs;
 typedef RolloutArgsT<double> RolloutArgs64;
@@ -168,6 +176,7 @@ hipError_t launch_rollout_fused(int env_id, bool autoreset, bool extras, const S
 struct EpisodeGatherArgs {
     const uint32_t *counts; int64_t cap;
     const int32_t *ep_t, *ep_lane; const float *ep_ret; const int32_t *ep_len;
+    int64_t ov_cap;                // the shared overflow segment = segment kShards of the same arrays (RolloutArgs)
     int32_t *out_t, *out_lane; float *out_ret; int32_t *out_len;
     int64_t out_capacity; uint32_t *out_count;
 };

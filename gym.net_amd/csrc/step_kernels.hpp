@@ -1019,9 +1019,12 @@ __device__ __forceinline__ void thread_action_words(uint64_t seed, uint64_t gl0,
 constexpr uint32_t kStageRecords = 256;
 struct EpisodeStage { int32_t t[kStageRecords], lane[kStageRecords]; float ret[kStageRecords]; int32_t len[kStageRecords]; };
 
-//   RECORDS the rollout keeps compact episode records (RolloutArgs::ep_*; bookkeeping handles): a variant of its own, so that the
+//   RECORDS 1 / 2: the rollout keeps compact episode records (RolloutArgs::ep_*; bookkeeping handles) — 1 (the default): what a shard's segment
+//           cannot hold spills to the shared overflow segment, nothing is lost below the caller's capacity; 2 (GYMNET_RECORDS_NO_OVERFLOW):
+//           no spill path — its mere presence costs the kernel 8 % (a call, or a cold block, inside a loop whose registers are capped
+//           at 128), and an evenly finishing batch never takes it.  A variant of its own, so that the
 //           rollouts that keep none do not carry the staging code's registers (128-VGPR budget, above)
-template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE, int RESETF = 0, bool RECORDS = false>
+template <class Env, int VEC, bool AUTORESET, bool GUARD, bool EXTRAS, bool SAMPLE, int RESETF = 0, int RECORDS = 0>
 __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real> &a, const RolloutArgsT<typename Env::Real> &ro,
                                              const int64_t i0, const uint64_t tick0, ResetScratch<Env> *sc = nullptr, EpisodeStage *stage = nullptr) {
     constexpr int S = Env::S, O = Env::O;
@@ -1082,11 +1085,31 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
             base = __shfl(base, leader);
             for (uint32_t b0 = 0; b0 < staged; b0 += A) {
                 const uint32_t q = b0 + lane_id();
-                if (q < staged && (int64_t)(base + q) < ro.ep_cap) {   // beyond the capacity: counted, not kept
+                if (q < staged && (int64_t)(base + q) < ro.ep_cap) {
                     const int64_t pos = (int64_t)shard * ro.ep_cap + base + q;
                     ro.ep_t[pos] = stage->t[q];
                     ro.ep_lane[pos] = stage->lane[q];
                     if (ro.ep_ret) { ro.ep_ret[pos] = stage->ret[q]; ro.ep_len[pos] = stage->len[q]; }
+                }
+            }
+            // what the shard's segment cannot hold goes to the shared overflow segment: one more atomic, only for a shard that is full
+            if constexpr (RECORDS == 1) {
+                // "segment kShards" of the same arrays, counter ep_count[kShards * kCountStride]; a wave-uniform branch nobody takes in an evenly
+                // finishing batch (measured as this block and as a noinline call: the same 8 %, and the call adds a stack frame)
+                if (__builtin_expect((int64_t)base + (int64_t)staged > ro.ep_cap, 0)) {
+                    const uint32_t first_ov = (int64_t)base < ro.ep_cap ? (uint32_t)(ro.ep_cap - (int64_t)base) : 0u;
+                    uint32_t ovbase = 0;
+                    if ((int)lane_id() == leader) ovbase = atomicAdd(&ro.ep_count[kShards * kCountStride], staged - first_ov);
+                    ovbase = __shfl(ovbase, leader);
+                    for (uint32_t b0 = 0; b0 < staged; b0 += A) {
+                        const uint32_t q = b0 + lane_id();
+                        if (q >= first_ov && q < staged && (int64_t)(ovbase + (q - first_ov)) < ro.ov_cap) {   // beyond ep_capacity in total: counted, not kept
+                            const int64_t pos = (int64_t)kShards * ro.ep_cap + ovbase + (q - first_ov);
+                            ro.ep_t[pos] = stage->t[q];
+                            ro.ep_lane[pos] = stage->lane[q];
+                            if (ro.ep_ret) { ro.ep_ret[pos] = stage->ret[q]; ro.ep_len[pos] = stage->len[q]; }
+                        }
+                    }
                 }
             }
             wave_lds_fence();
@@ -1260,7 +1283,7 @@ __device__ __forceinline__ void rollout_body(const StepArgsT<typename Env::Real>
 // (four blocks of four waves per CU) they fit in one — 4.1 -> 3.2 us per vector step with episode statistics, 7.3 -> 6.3 with sampled
 // actions and episode records, at the price of 36-92 bytes of scratch (profiles/occupancy_hints_r05.txt).  The float64 variants lose under
 // the same cap (bookkeeping rollout with the compacted reset 6.9 -> 7.7 us) and are left alone.
-template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0, bool RECORDS = false>
+template <class Env, int VEC, bool AUTORESET, bool EXTRAS = false, bool SAMPLE = false, int RESETF = 0, int RECORDS = 0>
 __global__ __launch_bounds__(256, sizeof(typename Env::Real) == 4 ? 4 : 1) void rollout_kernel(const StepArgsT<typename Env::Real> a, const RolloutArgsT<typename Env::Real> ro) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     ResetScratch<Env> *sc = nullptr;
@@ -1608,8 +1631,10 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
     const bool records = extras && r.ep_lane != nullptr;
 #define GYMNET_ROLL(V, AR, RF)                                                                                                     \
     do {                                                                                                                          \
-        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF, true>), grid, blk, 0, st, a, r); \
-                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF, true>), grid, blk, 0, st, a, r); }     \
+        if (records && r.records_no_overflow) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF, 2>), grid, blk, 0, st, a, r); \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF, 2>), grid, blk, 0, st, a, r); }        \
+        else if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF, 1>), grid, blk, 0, st, a, r); \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF, 1>), grid, blk, 0, st, a, r); }        \
         else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, true, RF>), grid, blk, 0, st, a, r);   \
                            else hipLaunchKernelGGL((rollout_kernel<Env, V, AR, true, false, RF>), grid, blk, 0, st, a, r); }       \
         else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, V, AR, false, true, RF>), grid, blk, 0, st, a, r);       \
@@ -1627,8 +1652,10 @@ static hipError_t launch_rollout_env(bool autoreset, bool extras, const StepArgs
             const dim3 grid4(grid_for(threads4 > 0 ? threads4 : 1, 256));
 #define GYMNET_ROLL4(AR, RF)                                                                                                        \
     do {                                                                                                                            \
-        if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF, true>), grid4, blk, 0, st, a, r);  \
-                       else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF, true>), grid4, blk, 0, st, a, r); }      \
+        if (records && r.records_no_overflow) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF, 2>), grid4, blk, 0, st, a, r);  \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF, 2>), grid4, blk, 0, st, a, r); }         \
+        else if (records) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF, 1>), grid4, blk, 0, st, a, r);  \
+                       else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF, 1>), grid4, blk, 0, st, a, r); }         \
         else if (extras) { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, true, RF>), grid4, blk, 0, st, a, r);    \
                            else hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, true, false, RF>), grid4, blk, 0, st, a, r); }        \
         else        { if (sample) hipLaunchKernelGGL((rollout_kernel<Env, FAT, AR, false, true, RF>), grid4, blk, 0, st, a, r);        \

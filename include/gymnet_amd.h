@@ -313,6 +313,11 @@ int gymnet_vecenv_rollout_fused_device(gymnet_vecenv *h, const void *d_actions, 
  *     EPSILON_GREEDY: gymnet_vecenv_compose_actions_device over the ring as the policy's actions — so a random rollout reads no
  *     action ring at all (0 B instead of 4 B per env-step), and d_rec_actions records what was taken.
  * Results are bit-identical to `steps` x (sample / compose, then gymnet_vecenv_step_device).  Stream-ordered, non-blocking. */
+/* gymnet_rollout_spec.record_flags.  By default a rollout that keeps episode records loses none below ep_capacity.  NO_OVERFLOW selects the
+ * kernel variant without the overflow path (8 % faster with records): episodes of lanes that finish very UNEVENLY — a few waves producing
+ * most of them — can then be dropped below ep_capacity (a per-shard limit of 2 * ceil(ep_capacity / 256) + 64 records; d_ep_count[1] > [0]
+ * says so).  Evenly finishing batches, e.g. random rollouts, never notice the difference. */
+#define GYMNET_RECORDS_NO_OVERFLOW 1
 typedef enum gymnet_action_source { GYMNET_ACTIONS_RING = 0, GYMNET_ACTIONS_SAMPLE = 1, GYMNET_ACTIONS_EPSILON_GREEDY = 2 } gymnet_action_source;
 typedef struct gymnet_rollout_spec {
     uint32_t struct_size;        /* = sizeof(gymnet_rollout_spec) */
@@ -324,7 +329,7 @@ typedef struct gymnet_rollout_spec {
     uint64_t action_seed;        /* SAMPLE / EPSILON_GREEDY: Philox action stream key ... */
     uint64_t action_tick0;       /* ... and tick of step 0 (step t draws with tick action_tick0 + t) */
     float    epsilon;            /* EPSILON_GREEDY: exploration probability, [0, 1] */
-    int32_t  reserved;
+    int32_t  record_flags;       /* episode records: 0, or GYMNET_RECORDS_NO_OVERFLOW (ABI 5 called this field `reserved`: 0 = the default) */
     /* dense per-step recording (the members of gymnet_rollout_buffers); any pointer NULL = not recorded */
     void    *d_rec_obs;          /* [steps][obs_dim][num_envs] observation AFTER step t; float32 — float64 for a GYMNET_FLAG_F64 handle */
     float   *d_rec_reward;       /* [steps][num_envs] */
@@ -336,13 +341,13 @@ typedef struct gymnet_rollout_spec {
     float   *d_ep_return;        /* [ep_capacity] episode return  (EPISODE_STATS) */
     int32_t *d_ep_length;        /* [ep_capacity] episode length  (EPISODE_STATS) */
     int64_t  ep_capacity;        /* records the arrays hold; a random-action CartPole rollout ends ~0.045 x num_envs episodes per step */
-    uint32_t *d_ep_count;        /* [2]: [0] records written, [1] episodes that ended.  [1] > [0]: records were dropped — because more
-                                    episodes ended than ep_capacity, OR because one SHARD's segment filled up: inside the kernel the
-                                    records are kept in 256 segments (a wave appends to segment (wave index mod 256): one atomic per
-                                    wave and flush instead of 4096 waves on one counter) of 2 * ceil(ep_capacity / 256) + 64 records
-                                    each.  Evenly finishing lanes never get near that; a batch whose finishing lanes are concentrated
-                                    in a few waves (or a capacity sized to the exact episode count) can: size ep_capacity with the
-                                    factor two in mind, or check [1] == [0] */
+    uint32_t *d_ep_count;        /* [2]: [0] records written, [1] episodes that ended.  [1] > [0] exactly when more episodes ended than
+                                    ep_capacity: then ep_capacity records are kept (which ones is unspecified) and the rest are only
+                                    counted.  (Inside the kernel the records live in 256 per-shard segments — a wave appends to segment
+                                    (wave index mod 256) with one atomic per flush — of 2 * ceil(ep_capacity / 256) + 64 records each;
+                                    what a shard cannot hold, e.g. when a few waves produce most of the episodes, spills to one shared
+                                    overflow segment of ep_capacity records, so an uneven batch loses nothing — unless record_flags asks
+                                    for GYMNET_RECORDS_NO_OVERFLOW, round 5's behaviour.) */
 } gymnet_rollout_spec;
 int gymnet_vecenv_rollout_fused_ex_device(gymnet_vecenv *h, const gymnet_rollout_spec *spec);
 /* Pack the SoA observations into row-major [num_envs, obs_dim] on the device (the NDArray layout; float32, or float64 for a

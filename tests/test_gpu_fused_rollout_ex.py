@@ -149,11 +149,12 @@ def test_fused_rollout_ex_argument_errors_and_capacity(gpu_pkg):
 
 def test_episode_records_with_skewed_finishing_lanes_and_a_tight_capacity(gpu_pkg):
     """inside the kernel the episode records live in 256 per-shard segments of 2 * ceil(capacity / 256) + 64 records (a wave
-    appends to segment wave-index mod 256).  Lanes that finish EVENLY never notice; here only the lanes of TWO waves of the same shard finish (their poles
-    start at the edge of the angle threshold; every other lane starts upright and an alternating push keeps it up for the whole
-    rollout), with a capacity sized to the true episode count: records
-    beyond the shard's segment are COUNTED, not kept, exactly as include/gymnet_amd.h says — count[1] is the true number of episodes,
-    count[0] what the arrays hold, every kept record is a real episode — and a capacity with the documented factor keeps them all."""
+    appends to segment wave-index mod 256).  Lanes that finish EVENLY never fill one; here only the lanes of TWO waves of the same
+    shard finish (their poles start at the edge of the angle threshold; every other lane starts upright and an alternating push keeps
+    it up for the whole rollout), with a capacity sized to EXACTLY the true episode count.  Round 5 dropped the hot shard's excess;
+    now it spills to the shared overflow segment and nothing is lost: count[0] == count[1] == the truth, same records as with a
+    roomy capacity.  One record fewer than the truth and exactly one is dropped (counted, not kept; the kept ones are real).  The
+    opt-in variant without the overflow path behaves as round 5 did."""
     import torch
     n, T = 64 * 300, 24                                  # 300 waves of 64 lanes (a batch this small runs one lane per thread)
     acts = torch.zeros((2, n), dtype=torch.int32, device="cuda")
@@ -163,28 +164,33 @@ def test_episode_records_with_skewed_finishing_lanes_and_a_tight_capacity(gpu_pk
     hot_lanes = np.r_[0:64, 64 * 256:64 * 257]                               # waves 0 and 256: the SAME shard (wave index mod 256)
     s[2, hot_lanes] = 0.2                                                    # theta just inside the threshold -> these poles fall at once
 
-    def run(cap):                                                            # a fresh handle per run: same seed, same ticks, same reset draws
+    def run(cap, **more):                                                    # a fresh handle per run: same seed, same ticks, same reset draws
         with gpu_pkg.VectorEnv("CartPole-v1", n, seed=SEED, auto_reset=True, episode_stats=True) as env:
             env.ResetDevice()
             env.SetState(s)
-            ep = _episode_buffers(torch, cap)
+            ep = dict(_episode_buffers(torch, cap), **more)
             env.RolloutFusedDevice(acts, T, n, 2, episodes=ep)
             env.Sync()
             rec, ret, c = _records(ep)
-            return rec, c
-    rec, c = run(1 << 16)                                                    # roomy: the truth
+            return rec, ret, c
+    rec, ret, c = run(1 << 16)                                               # roomy: the truth
     truth = int(c[1])
-    wave0 = int(np.isin(rec[:, 1], hot_lanes).sum())
-    assert c[0] == c[1] and wave0 >= 128 and truth < 2 * wave0               # (nearly) every episode ends in the two hot waves
-    tight = truth                                                            # "sized to the true episode count"
-    rec_t, c_t = run(tight)
-    per_shard = 2 * ((tight + 255) // 256) + 64
-    assert c_t[1] == truth                                                   # every episode is counted
-    assert wave0 > per_shard and c_t[0] < c_t[1] and c_t[0] >= per_shard     # the hot shard overflowed: dropped, not corrupted
+    hot = int(np.isin(rec[:, 1], hot_lanes).sum())
+    assert c[0] == c[1] and hot >= 128 and truth < 2 * hot                   # (nearly) every episode ends in the two hot waves
+    per_shard = 2 * ((truth + 255) // 256) + 64
+    assert hot > per_shard                                                   # the hot shard's own segment cannot hold them ...
+    rec_t, ret_t, c_t = run(truth)                                           # ... "sized to the true episode count"
+    assert c_t[0] == c_t[1] == truth and np.array_equal(rec_t, rec) and np.array_equal(ret_t, ret)     # ... and nothing is lost
+    rec_s, ret_s, c_s = run(truth - 1)                                       # one short: one dropped, counted
+    assert c_s[1] == truth and c_s[0] == truth - 1
     keep = {tuple(r) for r in rec.tolist()}
-    assert all(tuple(r) in keep for r in rec_t.tolist())                     # what IS kept are real episodes
-    rec_f, c_f = run(max(truth, 128 * wave0))                                # the documented factor: 2 * capacity / 256 >= the busiest shard
-    assert c_f[0] == c_f[1] == truth and np.array_equal(rec_f, rec)
+    assert all(tuple(r) in keep for r in rec_s.tolist())
+    # GYMNET_RECORDS_NO_OVERFLOW (episodes["no_overflow"]): the 8 % faster kernel variant without the spill path — round 5's behaviour: the
+    # hot shard's excess is counted, not kept; a roomy capacity keeps everything
+    rec_f, ret_f, c_f = run(truth, no_overflow=True)
+    assert c_f[1] == truth and per_shard <= c_f[0] < truth and all(tuple(r) in keep for r in rec_f.tolist())
+    rec_g, ret_g, c_g = run(1 << 16, no_overflow=True)
+    assert c_g[0] == c_g[1] == truth and np.array_equal(rec_g, rec)
 
 
 def test_sampled_action_rollout_at_2p20_lanes_equals_the_oracle_replay(gpu_pkg, oracle):

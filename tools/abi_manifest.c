@@ -46,7 +46,7 @@ int main(void) {
     BEGIN(gymnet_rollout_spec);
     F(gymnet_rollout_spec, struct_size); F(gymnet_rollout_spec, action_source); F(gymnet_rollout_spec, d_actions); F(gymnet_rollout_spec, steps);
     F(gymnet_rollout_spec, action_stride); F(gymnet_rollout_spec, ring); F(gymnet_rollout_spec, action_seed); F(gymnet_rollout_spec, action_tick0);
-    F(gymnet_rollout_spec, epsilon); F(gymnet_rollout_spec, reserved); F(gymnet_rollout_spec, d_rec_obs); F(gymnet_rollout_spec, d_rec_reward);
+    F(gymnet_rollout_spec, epsilon); F(gymnet_rollout_spec, record_flags); F(gymnet_rollout_spec, d_rec_obs); F(gymnet_rollout_spec, d_rec_reward);
     F(gymnet_rollout_spec, d_rec_done); F(gymnet_rollout_spec, d_rec_actions); F(gymnet_rollout_spec, d_ep_step); F(gymnet_rollout_spec, d_ep_lane);
     F(gymnet_rollout_spec, d_ep_return); F(gymnet_rollout_spec, d_ep_length); F(gymnet_rollout_spec, ep_capacity); F(gymnet_rollout_spec, d_ep_count);
     END();

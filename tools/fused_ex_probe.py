@@ -53,4 +53,5 @@ for label, kw in (("EPISODE_STATS", dict(episode_stats=True, max_episode_steps=5
         print(f"   sampled actions, no episode records     {timed(lambda: e.RolloutFusedDevice(None, ring, actions='sample', action_seed=7)):7.3f} us/step")
         print(f"   sampled actions + episode records       {timed(lambda: e.RolloutFusedDevice(None, ring, actions='sample', action_seed=7, episodes=bufs)):7.3f} us/step"
               f"   (records kept / episodes ended: {bufs['count'].cpu().numpy().tolist()})")
+        print(f"   ... the same, GYMNET_RECORDS_NO_OVERFLOW  {timed(lambda: e.RolloutFusedDevice(None, ring, actions='sample', action_seed=7, episodes=dict(bufs, no_overflow=True))):7.3f} us/step")
         print(f"   one launch per step (stepwise EXTRAS)   {timed(lambda: e.RolloutDevice(acts, ring, n, ring), launches=4):7.3f} us/step")
