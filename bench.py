@@ -374,13 +374,16 @@ def read_rollout_counters(db, seq):
     import sqlite3
     c = sqlite3.connect(db)
     try:
-        rows = c.execute("select dispatch_id, kernel_name, counter_name, sum(value) from counters_collection "
+        cols = [r[1] for r in c.execute("pragma table_info(counters_collection)").fetchall()]
+        dur = "max(duration)" if "duration" in cols else "0"
+        rows = c.execute(f"select dispatch_id, kernel_name, counter_name, sum(value), {dur} from counters_collection "
                          "where kernel_name like '%rollout_kernel%' group by dispatch_id, kernel_name, counter_name order by dispatch_id").fetchall()
     finally:
         c.close()
     disp = {}
-    for did, k, cn, v in rows:
+    for did, k, cn, v, d in rows:
         disp.setdefault(did, {"kernel": k})[cn] = v
+        disp[did]["_duration_ns"] = d
     order = [disp[d] for d in sorted(disp)]
     if len(order) != sum(x["launches"] for x in seq):
         raise RuntimeError(f"{len(order)} rollout_kernel dispatches in the database, the child reported {sum(x['launches'] for x in seq)}")
@@ -390,7 +393,7 @@ def read_rollout_counters(db, seq):
         at += x["launches"]
         k = mine[0]["kernel"]
         lanes_per_thread = int(re.search(r"rollout_kernel<[^,]+,\s*(\d+)", k).group(1))
-        cs = {cn: sum(m[cn] for m in mine) / len(mine) for cn in mine[0] if cn != "kernel"}
+        cs = {cn: sum(m[cn] for m in mine) / len(mine) for cn in mine[0] if cn != "kernel"}     # (incl. "_duration_ns": the profiled launch's length)
         out[x["variant"]] = {"kernel": k, "lanes_per_thread": lanes_per_thread, "steps_per_launch": x["steps"], "counters": cs,
                              "valu_per_env_step": cs["SQ_INSTS_VALU"] / cs["SQ_WAVES"] / lanes_per_thread / x["steps"]}
     return out
@@ -410,7 +413,7 @@ def measure_rollout_valu(args, timeout=120):
     out_dir = tempfile.mkdtemp(prefix="gymnet_pmc_rollout_", dir="/tmp")
     try:
         cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64",
-               "SQ_INSTS_VALU_MUL_F64", "-d", out_dir, "-o", "pmc", "--",
+               "SQ_INSTS_VALU_MUL_F64", "GRBM_GUI_ACTIVE", "-d", out_dir, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--rollout-child", "all", "--env", args.env, "--num-envs", str(args.num_envs)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         seq = None
@@ -431,13 +434,20 @@ def measure_rollout_valu(args, timeout=120):
 
 def valu_busy_in_pass(counters, simds):
     """VALU-pipe occupancy inside the --pmc pass itself, free of any assumed clock: every counted instruction holds its SIMD for at
-    least 4 clocks, SQ_BUSY_CYCLES (summed over the shader engines, 32 SIMDs each) is the launch's length in the chip's OWN clocks:
-    busy = SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines).  tools/gpu_valu_counter_check.sh calibrates both counters on a
-    kernel of known instruction count (profiles/issue_rate_r06.txt): 65585 counted for 65536 + 49 executed, 0.95 busy for back-to-back FMAs."""
-    if not counters.get("SQ_BUSY_CYCLES") or not counters.get("SQ_INSTS_VALU"):
-        return None
-    engines = max(1, simds // 32)
-    return counters["SQ_INSTS_VALU"] * 4.0 / (simds * counters["SQ_BUSY_CYCLES"] / engines)
+    least 4 clocks, and GRBM_GUI_ACTIVE (summed over the chip's XCDs, 128 SIMDs each) is the launch's length in the chip's OWN clocks:
+    busy = SQ_INSTS_VALU x 4 / simds / (GRBM_GUI_ACTIVE / XCDs).  (tools/gpu_busy_check_r06.sh: GRBM_GUI_ACTIVE / 8 / duration = 2.23 GHz
+    for a 181 us rollout launch — the ramping clock tools/issue_rate_probe.hip reads from s_memtime — whereas SQ_BUSY_CYCLES / 32 shader
+    engines under-counts the launch's length by ~10 % for these kernels and made the first version of this figure read 1.08-1.11.)
+    Returns (busy, cycles) or (None, None)."""
+    if not counters.get("SQ_INSTS_VALU"):
+        return None, None
+    if counters.get("GRBM_GUI_ACTIVE"):
+        cycles = counters["GRBM_GUI_ACTIVE"] / max(1, simds // 128)
+    elif counters.get("SQ_BUSY_CYCLES"):
+        cycles = counters["SQ_BUSY_CYCLES"] / max(1, simds // 32)
+    else:
+        return None, None
+    return counters["SQ_INSTS_VALU"] * 4.0 / simds / cycles, cycles
 
 
 def valu_roofline(n, valu_per_env_step, measured_us, simds, source, quarter_rate_per_env_step=None):
@@ -1322,13 +1332,16 @@ def main():
                                  (cs.get("SQ_INSTS_VALU_FMA_F64", 0.0) + cs.get("SQ_INSTS_VALU_ADD_F64", 0.0) + cs.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / per)
                         leg["roofline"] = valu_roofline(n, valu[key]["valu_per_env_step"], leg["us_per_step"], simds, src, q)
                         leg["roofline"]["kernel"] = valu[key].get("kernel")
-                        busy = valu_busy_in_pass(cs, simds)
+                        busy, cycles = valu_busy_in_pass(cs, simds)
                         if busy is not None:
                             leg["roofline"]["valu_busy_in_pmc_pass"] = busy
-                            leg["roofline"]["valu_busy_note"] = ("SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / shader engines) of the profiled launches: no assumed clock.  Both it and "
-                                                                 "`frac` (4 clocks per counted instruction, 2.4 GHz, against the UNPROFILED time) are MODEL fractions: above 1 means the chip "
-                                                                 "retires this instruction mix faster than 4 clocks per counted instruction (calibration on a pure FMA loop: 0.95) — "
-                                                                 "read them as 'at the VALU-issue ceiling to within +-10 %' (DESIGN.md §5)")
+                            if cs.get("_duration_ns"):
+                                leg["roofline"]["clock_GHz_in_pmc_pass"] = cycles / cs["_duration_ns"]
+                                leg["roofline"]["us_per_step_in_pmc_pass"] = cs["_duration_ns"] / 1e3 / valu[key]["steps_per_launch"]
+                            leg["roofline"]["valu_busy_note"] = ("SQ_INSTS_VALU x 4 / simds / (GRBM_GUI_ACTIVE / XCDs) of the profiled 64-step launches: the VALU pipe's occupancy in the "
+                                                                 "chip's own clocks, no assumed frequency (those short launches run at the ramping clock beside it, 2.0-2.3 GHz). "
+                                                                 "`frac` prices the floor at the 2.4 GHz peak clock and 4 clocks per counted instruction against the UNPROFILED "
+                                                                 "256-step time; both are model fractions good to a few percent (DESIGN.md §5)")
             except Exception as e:                               # noqa: BLE001 - a secondary figure never costs the headline
                 out["fused_rollout"]["roofline_error"] = repr(e)[:300]
         if not args.no_cpu_baseline:

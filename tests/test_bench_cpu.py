@@ -96,7 +96,7 @@ def test_rollout_roofline_objects_can_be_recomputed_from_their_own_fields(tmp_pa
     json.dumps([r, w])
     db = str(tmp_path / "pmc_results.db")
     c = sqlite3.connect(db)
-    c.execute("create table counters_collection (dispatch_id integer, kernel_name text, counter_name text, value real)")
+    c.execute("create table counters_collection (dispatch_id integer, kernel_name text, counter_name text, value real, duration integer)")
     seq = [{"variant": "f32_ring", "launches": 3, "steps": 64}, {"variant": "f32_sampled", "launches": 3, "steps": 64},
            {"variant": "f32_epsilon_greedy", "launches": 3, "steps": 64}]
     did = 0
@@ -106,13 +106,17 @@ def test_rollout_roofline_objects_can_be_recomputed_from_their_own_fields(tmp_pa
         for launch in range(x["launches"]):
             did += 1
             for xcd in range(2):          # two rows per dispatch and counter: summed
-                c.execute("insert into counters_collection values (?,?,?,?)", (did, kernel, "SQ_WAVES", 2048.0))
-                c.execute("insert into counters_collection values (?,?,?,?)", (did, kernel, "SQ_INSTS_VALU", 2048.0 * 4 * 64 * (999.0 if launch == 0 else valu)))
-    c.execute("insert into counters_collection values (99, 'void gymnet::step_kernel<...>', 'SQ_WAVES', 1.0)")
+                c.execute("insert into counters_collection values (?,?,?,?,?)", (did, kernel, "SQ_WAVES", 2048.0, 180000))
+                c.execute("insert into counters_collection values (?,?,?,?,?)", (did, kernel, "SQ_INSTS_VALU", 2048.0 * 4 * 64 * (999.0 if launch == 0 else valu), 180000))
+    c.execute("insert into counters_collection values (99, 'void gymnet::step_kernel<...>', 'SQ_WAVES', 1.0, 5000)")
     c.commit(); c.close()
     got = b.read_rollout_counters(db, seq)
     assert [round(got[x["variant"]]["valu_per_env_step"], 6) for x in seq] == [100.0, 130.0, 160.0]
     assert got["f32_sampled"]["lanes_per_thread"] == 4 and got["f32_epsilon_greedy"]["kernel"] == got["f32_sampled"]["kernel"]
+    assert got["f32_ring"]["counters"]["_duration_ns"] == 180000
+    busy, cycles = b.valu_busy_in_pass({"SQ_INSTS_VALU": 1.003e8, "GRBM_GUI_ACTIVE": 3.221e6, "SQ_BUSY_CYCLES": 1.158e7}, 1024)
+    assert abs(cycles - 3.221e6 / 8) < 1 and abs(busy - 1.003e8 * 4 / 1024 / (3.221e6 / 8)) < 1e-12 and 0.96 < busy < 0.98     # (gpu_busy_check_r06.sh's dispatch)
+    assert b.valu_busy_in_pass({"SQ_INSTS_VALU": 1.0}, 1024) == (None, None)
     import pytest
     with pytest.raises(RuntimeError):
         b.read_rollout_counters(db, seq[:2])                                   # the child's account and the database disagree

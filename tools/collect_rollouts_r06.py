@@ -76,12 +76,15 @@ for v in bench.ROLLOUT_VARIANTS:
     if v in counters:
         cs = counters[v]["counters"]
         per = cs["SQ_WAVES"] * counters[v]["lanes_per_thread"] * counters[v]["steps_per_launch"]
+        cs = dict(cs)
         e.update(valu_per_env_step=counters[v]["valu_per_env_step"], lanes_per_thread=counters[v]["lanes_per_thread"],
                  int64_per_env_step=cs.get("SQ_INSTS_VALU_INT64", 0.0) / per, trans_per_env_step=cs.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / per,
                  f64_arith_per_env_step=(cs.get("SQ_INSTS_VALU_FMA_F64", 0.0) + cs.get("SQ_INSTS_VALU_ADD_F64", 0.0) + cs.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / per)
-        busy = bench.valu_busy_in_pass(cs, SIMDS)
+        busy, cycles = bench.valu_busy_in_pass(cs, SIMDS)
         if busy is not None:
             e["valu_busy_in_pmc_pass"] = busy
+            if cs.get("_duration_ns"):
+                e["clock_GHz_in_pmc_pass"] = cycles / cs["_duration_ns"]
         e["issue_floor_us"] = N * e["valu_per_env_step"] / (16 * SIMDS) / (CLOCK * 1e3)
         clocks = 4.0 * e["valu_per_env_step"] + e["int64_per_env_step"] + 5.0 * e["trans_per_env_step"] + 1.3 * e["f64_arith_per_env_step"]
         e["issue_floor_measured_rates_us"] = N * clocks / 64.0 / SIMDS / (CLOCK * 1e3)

@@ -57,6 +57,7 @@ block = f"Median of {nbox} boxes of the pool, none selected (`profiles/roofline_
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 busy = f"float32 {med(R['f32_ring'], 'valu_busy_in_pmc_pass', 2)} / {med(R['f32_sampled'], 'valu_busy_in_pmc_pass', 2)} / {med(R['f32_epsilon_greedy'], 'valu_busy_in_pmc_pass', 2)} for ring / sampled / ε-greedy"
+s = s.replace("{{BUSY}}", busy)
 if "{{TABLE}}" in s:
     s = s.replace("{{TABLE}}", "<!-- r06:begin tables -->\n" + block + "<!-- r06:end tables -->").replace("{{NBOX}}", str(nbox))
     s = s.replace("{{BIGFRAC}}", med(big, "frac_rocprof", 2)).replace("{{BUSY}}", busy)

@@ -33,7 +33,7 @@ done
 mkdir -p $O/rollout
 timeout 600 python3 $R/bench.py > $O/bench_default.log 2> $O/bench_default.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/rollout/stats -o s -- python3 $R/bench.py --rollout-child all > $O/rollout/stats.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_BUSY_CYCLES -d $O/rollout/SQ -o pmc -- python3 $R/bench.py --rollout-child all > $O/rollout/SQ.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/rollout/SQ -o pmc -- python3 $R/bench.py --rollout-child all > $O/rollout/SQ.log 2>&1
 # (c) 2^27 lanes: nothing stays in the 256 MiB Infinity Cache
 mkdir -p $O/big
 BIG="$B --num-envs 134217728 --ring 2 --min-seconds 0"

@@ -72,13 +72,14 @@ if rb:
                         "unprofiled_us_per_step": "the default bench line's fused legs: HIP events over >= 1024 steps",
                         "frac_rocprof / frac_unprofiled": "issue_floor_us over the respective duration",
                         "issue_floor_measured_rates_us": "the floor with v_mad_u64_u32 at 5, transcendentals at 9 and float64 arithmetic at 5.3 clocks (profiles/issue_rate_r06.txt)",
-                        "valu_busy_in_pmc_pass": "SQ_INSTS_VALU x 4 / (simds x SQ_BUSY_CYCLES / 32 shader engines): VALU-pipe occupancy of the profiled launches in the chip's own clocks"},
+                        "valu_busy_in_pmc_pass": "SQ_INSTS_VALU x 4 / simds / (GRBM_GUI_ACTIVE / 8 XCDs): VALU-pipe occupancy of the profiled launches in the chip's own clocks",
+                        "clock_GHz_in_pmc_pass": "GRBM_GUI_ACTIVE / 8 / the profiled launch's duration"},
             "variants": {}}
     names = [v for v in any_box["variants"]]
     for v in names:
         e = {"kernel": next((rb[b]["variants"][v].get("kernel") for b in rb if v in rb[b]["variants"] and rb[b]["variants"][v].get("kernel")), None)}
         for fig in ("valu_per_env_step", "int64_per_env_step", "trans_per_env_step", "f64_arith_per_env_step", "issue_floor_us", "issue_floor_measured_rates_us",
-                    "rocprof_us_per_step", "frac_rocprof", "unprofiled_us_per_step", "frac_unprofiled", "frac_unprofiled_measured_rates", "valu_busy_in_pmc_pass"):
+                    "rocprof_us_per_step", "frac_rocprof", "unprofiled_us_per_step", "frac_unprofiled", "frac_unprofiled_measured_rates", "valu_busy_in_pmc_pass", "clock_GHz_in_pmc_pass"):
             vals = {b: rb[b]["variants"][v][fig] for b in rb if v in rb[b]["variants"] and rb[b]["variants"][v].get(fig) is not None}
             if vals:
                 e[fig] = spread(vals)
